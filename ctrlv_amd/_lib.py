@@ -1,0 +1,90 @@
+"""ctypes binding of libctrlv_hip.so (include/ctrlv_hip.h).  No torch types cross this boundary."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libctrlv_hip.so")
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of `ctrlv_gemm_desc`."""
+    _fields_ = [
+        ("A", c_void_p), ("A2", c_void_p), ("W", c_void_p), ("out", c_void_p),
+        ("bias", c_void_p), ("R1", c_void_p), ("R2", c_void_p), ("V", c_void_p),
+        ("M", c_int), ("N", c_int), ("Cin", c_int), ("taps", c_int),
+        ("lda", c_int), ("lda2", c_int), ("c_split", c_int),
+        ("mode", c_int),
+        ("H", c_int), ("Wd", c_int), ("Ho", c_int), ("Wo", c_int), ("stride", c_int), ("up", c_int),
+        ("F", c_int), ("S", c_int),
+        ("ldo", c_int), ("n_store", c_int),
+        ("ldr1", c_int), ("ldr2", c_int),
+        ("s_acc", c_float), ("s1", c_float), ("s2", c_float),
+        ("vmode", c_int), ("vdiv", c_int), ("vmod", c_int), ("vS", c_int), ("ldv", c_int),
+        ("act", c_int), ("geglu", c_int), ("out_f32", c_int), ("tile", c_int),
+    ]
+
+
+# name -> (restype, argtypes); lists every symbol include/ctrlv_hip.h declares (tests/test_abi.py checks this)
+SIGNATURES = {
+    "ctrlv_abi_version": (c_int, []),
+    "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
+    "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
+    "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctrlv_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "ctrlv_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
+    "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctrlv_nchw_to_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ctrlv_rows_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctrlv_im2col3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctrlv_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "ctrlv_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctrlv_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
+                                     c_float, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class CtrlvHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libctrlv_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CtrlvHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  ctrlv_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header / library out of sync
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().ctrlv_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """Map the C status convention (include/ctrlv_hip.h) onto the reference's exception types: bad shapes /
+    arguments -> ValueError (as controlnet.py:80-98, pipeline_video_control.py:51-68), HIP failures -> RuntimeError."""
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()} (status {rc})"
+    if rc in (-1, -2):
+        raise ValueError(msg)
+    raise CtrlvHipError(msg)

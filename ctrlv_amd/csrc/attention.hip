@@ -1,0 +1,308 @@
+// Self-attention cores for gfx950 (head_dim 64, bf16 in/out, fp32 softmax + accumulation).
+//
+// Both kernels compute S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (K tile = A operand, Q = B operand) so that each
+// lane owns ONE query row and the 16 accumulator registers of a 32-key tile are that row's scores: the online
+// softmax is in-register (one v_permlane32_swap to merge the two half-waves) and the exponentiated tile is, after a
+// bf16 pack, directly the B operand of O^T += V^T . P (guide section 3 "accumulator tile as the next MFMA's operand").
+// V^T fragments come from a row-major V tile in LDS through ds_read_b64_tr_b16 (hardware transpose).
+// K/V tiles are staged by LDS-DMA (global_load_lds_dwordx4) with the bank-conflict swizzle on the source address.
+//
+//   spatial : 128 queries x 64-key tiles per workgroup (4 waves x 32 rows), 2-stage K/V ring, S up to 9216.
+//   temporal: one wave per (clip, pixel, head): 25 frames padded to one 32x32 tile; the (b f) s c <-> (b s) f c
+//             permutes of TemporalBasicTransformerBlock are row-stride arithmetic (stride S*3C between frames).
+#include "common.h"
+
+namespace {
+
+constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+
+__device__ __forceinline__ float half_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// V^T fragment (A operand of O^T += V^T.P) for 16 keys starting at `kbase` (+4 for the upper half-wave, folded
+// into voff by the caller) and 32 d-columns: two transposed 4x16 block reads.
+__device__ __forceinline__ bf16x8 vt_frag(const char* vt, int voff_lo, int voff_hi) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + voff_lo));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + voff_hi));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// byte offset inside a row-major [keys][64] bf16 V tile (128-B rows) of (key, d) with the tr-read swizzle:
+// 16-B chunk index ^= ((key>>1)&1)<<2  (keeps the 4 rows of a transposed block on distinct banks)
+__device__ __forceinline__ int v_off(int key, int d) {
+  const int chunk = (d >> 3) ^ (((key >> 1) & 1) << 2);
+  return key * 128 + chunk * 16 + (d & 7) * 2;
+}
+
+__device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)p[8 * s + j];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------- spatial
+__global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           int S, int C) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB)
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const long row0 = (long)img * S;
+  const int ld = 3 * C;
+  const bf16_t* qp = qkv + head * 64;
+  const bf16_t* kp = qp + C;
+  const bf16_t* vp = qp + 2 * C;
+
+  const int qrow = blockIdx.x * 128 + wid * 32 + r32;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qrow < S) v = *(const uint4*)(qp + (row0 + qrow) * ld + 16 * ks + 8 * hsel);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  const int prow = lane >> 3, pslot = lane & 7;
+  const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
+  auto issue = [&](int t, int stage) {
+    char* ks_ = smem + stage * 16384;
+    char* vs_ = ks_ + 8192;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int rt = (q * 4 + wid) * 8 + prow;
+      const int key = t * 64 + rt;
+      const bool ok = key < S;
+      const long roff = (row0 + key) * ld;
+      const char* pk = ok ? (const char*)(kp + roff + (pslot ^ ((rt >> 1) & 7)) * 8) : zsrc;
+      const char* pv = ok ? (const char*)(vp + roff + (pslot ^ (((rt >> 1) & 1) << 2)) * 8) : zsrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // per-lane V^T read offsets (relative to a 16-key step base): row (i>>2) (+4 for upper half), col 16*((lane>>4)&1)+4*(i&3)
+  const int i16 = lane & 15;
+  const int vkey = 4 * hsel + (i16 >> 2);
+  const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+
+  const int nt = (S + 63) / 64;
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    const char* kst = smem + (t & 1) * 16384;
+    const char* vst = kst + 8192;
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+      }
+    }
+    if (t == nt - 1 && (S & 63)) {  // key masking on a ragged last tile
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = t * 64 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
+          if (key >= S) sacc[kt][e] = -INFINITY;
+        }
+    }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+    mx = half_max(mx) * kScaleLog2;
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(sacc[kt][e] * kScaleLog2 - m_new);
+        sacc[kt][e] = p;
+        rs += p;
+      }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = pack_p(sacc[kt], s);
+        const int kb = kt * 32 + 16 * s + vkey;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const float l_tot = half_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  if (qrow < S) {
+    bf16_t* op = out + (row0 + qrow) * C + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dcol = dt * 32 + 8 * q + 4 * hsel;
+        uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
+                              pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
+        *(uint2*)(op + dcol) = pk;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- temporal
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            int B, int F, int S, int C) {
+  __shared__ __attribute__((aligned(1024))) char smem[4 * 4096];  // one 32x64 V tile per wave
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int heads = C >> 6;
+  const long nprob = (long)B * S * heads;
+  const long pid = (long)blockIdx.x * 4 + wid;
+  if (pid >= nprob) return;  // whole-wave exit (no workgroup barrier is used below)
+  const int head = (int)(pid % heads);
+  const long bs = pid / heads;
+  const int b = (int)(bs / S), s = (int)(bs % S);
+  const int ld = 3 * C;
+  const long fstride = (long)S * ld;  // qkv elements between consecutive frames of one (b, s)
+  const bf16_t* qp = qkv + ((long)b * F * S + s) * ld + head * 64;
+  const bf16_t* kp = qp + C;
+  const bf16_t* vp = qp + 2 * C;
+  const int r32 = lane & 31, hsel = lane >> 5;
+
+  char* vst = smem + wid * 4096;
+  const int prow = lane >> 3, pslot = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int key = q * 8 + prow;
+    const char* pv = key < F ? (const char*)(vp + key * fstride + (pslot ^ (((key >> 1) & 1) << 2)) * 8)
+                             : (const char*)g_ctrlv_zeros + pslot * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vst + q * 1024), 16, 0, 0);
+  }
+  bf16x8 qf[4], kf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 vq = make_uint4(0, 0, 0, 0), vk = make_uint4(0, 0, 0, 0);
+    if (r32 < F) {
+      vq = *(const uint4*)(qp + r32 * fstride + 16 * ks + 8 * hsel);
+      vk = *(const uint4*)(kp + r32 * fstride + 16 * ks + 8 * hsel);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8, vq);
+    kf[ks] = __builtin_bit_cast(bf16x8, vk);
+  }
+  f32x16 sacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = (e & 3) + 8 * (e >> 2) + 4 * hsel;
+    if (key >= F) sacc[e] = -INFINITY;
+    mx = fmaxf(mx, sacc[e]);
+  }
+  mx = half_max(mx) * kScaleLog2;
+  float rs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float p = __builtin_amdgcn_exp2f(sacc[e] * kScaleLog2 - mx);
+    sacc[e] = p;
+    rs += p;
+  }
+  const float inv = 1.0f / half_sum(rs);
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  const int i16 = lane & 15;
+  const int vkey = 4 * hsel + (i16 >> 2);
+  const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own LDS-DMA has landed
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const bf16x8 pf = pack_p(sacc, st);
+    const int kb = 16 * st + vkey;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+      oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+    }
+  }
+  if (r32 < F) {
+    bf16_t* op = out + ((long)(b * F + r32) * S + s) * C + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dcol = dt * 32 + 8 * q + 4 * hsel;
+        uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
+                              pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
+        *(uint2*)(op + dcol) = pk;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
+  CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
+  CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
+  dim3 grid((S + 127) / 128, C / 64, n_img);
+  hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
+                     (bf16_t*)out, S, C);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_attention_temporal(const void* qkv, void* out, int B, int F, int S, int C,
+                                        ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(qkv && out, "attention_temporal: null pointer");
+  CTRLV_CHECK_SHAPE(B > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_temporal: C=%d must be a multiple of 64", C);
+  CTRLV_CHECK_SHAPE(F > 0 && F <= 32, "attention_temporal: F=%d frames must be in [1, 32]", F);
+  const long nprob = (long)B * S * (C / 64);
+  hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((nprob + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, (bf16_t*)out, B, F, S, C);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}

@@ -1,0 +1,317 @@
+// Gather-GEMM for gfx950: one kernel family for nn.Linear, 1x1 / 3x3 / stride-2 / upsample-fused Conv2d and the
+// (3,1,1) temporal Conv3d of the SVD UNet / ControlNet, on channels-last bf16 rows.
+//
+//   out[m, n] = epilogue( sum_{tap, c} A[src_row(m, tap), c] * W[n, tap*Cin + c] )
+//
+// Structure (MI355X-first, see DESIGN.md "gather-GEMM"):
+//   * BM x BN x 64 tiles; both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): the LDS image is
+//     lane-linear (8 rows x 128 B per wave-instruction) and the bank-conflict swizzle is applied on the per-lane
+//     SOURCE address (guide rule 21); conv halos / padding rows / tile overhang read a 256-B zero page, so the
+//     3x3 and temporal taps are pure address arithmetic -- no im2col, no halo copies in HBM.
+//   * two LDS stages, the DMA of K-step t+1 is in flight while the MFMAs of step t run.
+//   * v_mfma_f32_32x32x16_bf16 with the WEIGHT tile as the A operand, so every lane ends up owning one output ROW
+//     (m) and 4 consecutive columns per accumulator quad: the epilogue reads residuals / writes bf16 as 8-byte
+//     vectors and the per-row broadcast vectors (temb, frame pos-emb, 1-key cross-attention) cost one index per lane.
+//   * XCD-aware block remap so the N-tiles that share an A row-panel (and the M-tiles that share conv halo rows)
+//     sit in one XCD's L2.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace {
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc d) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid / WN, wc = wid % WN;
+
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int tiles_m = (d.M + BM - 1) / BM;
+  const int t_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int bm = (t_id / tiles_n) * BM, bn = (t_id % tiles_n) * BN;
+
+  const int kpt = d.Cin >> 6;             // K-steps per tap
+  const int nk = d.taps * kpt;
+  const long ktot = (long)d.taps * d.Cin;
+
+  // ---- per-lane gather state for the A rows this lane stages (fixed over the K loop)
+  const int prow = lane >> 3, pslot = lane & 7;
+  int a_y0[A_INSTR], a_x0[A_INSTR];       // mode 1: top-left input coord (pre-upsample grid is y>>up); mode 2: frame
+  long a_base[A_INSTR];                   // mode 0/2: row index m; mode 1: first pixel row of the image
+  int a_coff[A_INSTR];                    // logical 16-B chunk (x8 channels) this lane fetches
+  bool a_ok[A_INSTR];
+#pragma unroll
+  for (int q = 0; q < A_INSTR; ++q) {
+    const int rt = (q * NW + wid) * 8 + prow;
+    const int m = bm + rt;
+    a_coff[q] = (pslot ^ ((rt >> 1) & 7)) * 8;
+    a_ok[q] = m < d.M;
+    a_y0[q] = 0; a_x0[q] = 0; a_base[q] = m;
+    if (d.mode == 1) {
+      const int hw = d.Ho * d.Wo;
+      const int n_img = m / hw, rem = m - n_img * hw;
+      const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
+      a_y0[q] = yo * d.stride - 1;
+      a_x0[q] = xo * d.stride - 1;
+      a_base[q] = (long)n_img * d.H * d.Wd;
+    } else if (d.mode == 2) {
+      a_y0[q] = (m / d.S) % d.F;
+    }
+  }
+  int b_coff[B_INSTR];
+  long b_row[B_INSTR];
+  bool b_ok[B_INSTR];
+#pragma unroll
+  for (int q = 0; q < B_INSTR; ++q) {
+    const int rt = (q * NW + wid) * 8 + prow;
+    const int n = bn + rt;
+    b_coff[q] = (pslot ^ ((rt >> 1) & 7)) * 8;
+    b_ok[q] = n < d.N;
+    b_row[q] = (long)n * ktot;
+  }
+  const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
+  const int hlim = d.H << d.up, wlim = d.Wd << d.up;
+
+  auto issue = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+    const int tap = kt / kpt;
+    int cc = (kt - tap * kpt) << 6;
+    const bf16_t* src = (const bf16_t*)d.A;
+    int ld = d.lda;
+    if (d.A2 != nullptr && cc >= d.c_split) {
+      src = (const bf16_t*)d.A2; ld = d.lda2; cc -= d.c_split;
+    }
+    const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+    for (int q = 0; q < A_INSTR; ++q) {
+      bool ok = a_ok[q];
+      long row = a_base[q];
+      if (d.mode == 1) {
+        const int yi = a_y0[q] + dy, xi = a_x0[q] + dx;
+        ok = ok && (unsigned)yi < (unsigned)hlim && (unsigned)xi < (unsigned)wlim;
+        row += (long)(yi >> d.up) * d.Wd + (xi >> d.up);
+      } else if (d.mode == 2) {
+        const int ff = a_y0[q] + tap - 1;
+        ok = ok && (unsigned)ff < (unsigned)d.F;
+        row += (long)(tap - 1) * d.S;
+      }
+      const char* p = ok ? (const char*)(src + row * ld + cc + a_coff[q]) : zsrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
+    }
+    const bf16_t* wsrc = (const bf16_t*)d.W + (long)kt * 64;
+#pragma unroll
+    for (int q = 0; q < B_INSTR; ++q) {
+      const char* p = b_ok[q] ? (const char*)(wsrc + b_row[q] + b_coff[q]) : zsrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (q * NW + wid) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets: row (lane&31) of the 32-row sub-tile, 16-B chunk (2*ks + lane>>5) ^ swizzle
+  const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
+  const int a_frag_base = (wr * WTM + r32) * 128;
+  const int b_frag_base = A_BYTES + (wc * WTN + r32) * 128;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((ks * 2 + hsel) ^ sw) * 16;
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_frag_base + i * 32 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + b_frag_base + j * 32 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns row m; accumulator quad q holds columns n0 + 8q + 4h + {0..3}
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = bm + wr * WTM + i * 32 + r32;
+    if (m >= d.M) continue;
+    const float* vrow = nullptr;
+    if (d.vmode == 1) {
+      vrow = d.V + (long)((m / d.vdiv) % d.vmod) * d.ldv;
+    } else if (d.vmode == 2) {
+      vrow = d.V + (long)(((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod) * d.ldv;
+    }
+    if (d.geglu) {
+#pragma unroll
+      for (int j = 0; j + 1 < TN; j += 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;  // "a" column in the interleaved weight order
+          if (ncol >= d.N) continue;
+          const int ocol = ((bn + wc * WTN + j * 32) >> 1) + 8 * q + 4 * hsel;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = acc[i][j][4 * q + e], g = acc[i][j + 1][4 * q + e];
+            if (d.bias) { a += d.bias[ncol + e]; g += d.bias[ncol + 32 + e]; }
+            o[e] = a * gelu_erf_f(g);
+          }
+          if (ocol < d.n_store) {
+            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pk;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;
+          if (ncol >= d.N || ncol >= d.n_store) continue;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
+          if (d.bias) {
+            const float4 b = *(const float4*)(d.bias + ncol);
+            o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= d.s_acc;
+          if (d.R1) {
+            const uint2 rv = *(const uint2*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ncol);
+            o[0] += d.s1 * __uint_as_float(rv.x << 16); o[1] += d.s1 * __uint_as_float(rv.x & 0xffff0000u);
+            o[2] += d.s1 * __uint_as_float(rv.y << 16); o[3] += d.s1 * __uint_as_float(rv.y & 0xffff0000u);
+          }
+          if (d.R2) {
+            const uint2 rv = *(const uint2*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ncol);
+            o[0] += d.s2 * __uint_as_float(rv.x << 16); o[1] += d.s2 * __uint_as_float(rv.x & 0xffff0000u);
+            o[2] += d.s2 * __uint_as_float(rv.y << 16); o[3] += d.s2 * __uint_as_float(rv.y & 0xffff0000u);
+          }
+          if (vrow) {
+            const float4 vv = *(const float4*)(vrow + ncol);
+            o[0] += vv.x; o[1] += vv.y; o[2] += vv.z; o[3] += vv.w;
+          }
+          if (d.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+          }
+          if (d.out_f32) {
+            *(float4*)((float*)d.out + (long)m * d.ldo + ncol) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ncol) = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kfn = gemm_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kfn, dim3(tiles), dim3(WM * WN * 64), smem, stream, d);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void ctrlv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int ctrlv_last_error(char* buf, size_t n) {
+  if (buf && n) {
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_err);
+}
+extern "C" int ctrlv_abi_version(void) { return 1; }
+
+extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
+  CTRLV_CHECK_ARG(dp != nullptr, "ctrlv_gemm: null descriptor");
+  ctrlv_gemm_desc d = *dp;
+  hipStream_t stream = (hipStream_t)stream_;
+  CTRLV_CHECK_ARG(d.A && d.W && d.out, "ctrlv_gemm: A, W and out must be non-null");
+  CTRLV_CHECK_SHAPE(d.M > 0 && d.N > 0 && d.Cin > 0, "ctrlv_gemm: M, N, Cin must be positive (M=%d N=%d Cin=%d)", d.M,
+                    d.N, d.Cin);
+  CTRLV_CHECK_SHAPE(d.Cin % 64 == 0, "ctrlv_gemm: Cin=%d must be a multiple of 64 (pad the weight / im2col)", d.Cin);
+  CTRLV_CHECK_SHAPE(d.N % 32 == 0, "ctrlv_gemm: N=%d must be a multiple of 32 (pad the weight rows)", d.N);
+  CTRLV_CHECK_SHAPE(d.lda % 8 == 0 && (d.A2 == nullptr || (d.lda2 % 8 == 0 && d.c_split % 64 == 0)),
+                    "ctrlv_gemm: lda/lda2 must be multiples of 8 and c_split a multiple of 64");
+  CTRLV_CHECK_SHAPE(d.ldo % 4 == 0 && d.n_store % 4 == 0, "ctrlv_gemm: ldo and n_store must be multiples of 4");
+  if (d.mode == 0) {
+    CTRLV_CHECK_SHAPE(d.taps == 1, "ctrlv_gemm: mode 0 needs taps == 1");
+  } else if (d.mode == 1) {
+    CTRLV_CHECK_SHAPE(d.taps == 9 && d.H > 0 && d.Wd > 0 && d.Ho > 0 && d.Wo > 0 && (d.stride == 1 || d.stride == 2) &&
+                          (d.up == 0 || d.up == 1),
+                      "ctrlv_gemm: bad conv2d geometry");
+    CTRLV_CHECK_SHAPE(d.M % (d.Ho * d.Wo) == 0, "ctrlv_gemm: M must be a multiple of Ho*Wo in conv2d mode");
+    CTRLV_CHECK_SHAPE(((d.H << d.up) + 2 - 3) / d.stride + 1 == d.Ho && ((d.Wd << d.up) + 2 - 3) / d.stride + 1 == d.Wo,
+                      "ctrlv_gemm: conv2d output size %dx%d inconsistent with input %dx%d stride %d up %d", d.Ho, d.Wo,
+                      d.H, d.Wd, d.stride, d.up);
+  } else if (d.mode == 2) {
+    CTRLV_CHECK_SHAPE(d.taps == 3 && d.F > 0 && d.S > 0 && d.M % (d.F * d.S) == 0, "ctrlv_gemm: bad temporal geometry");
+  } else {
+    CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown mode %d", d.mode);
+  }
+  CTRLV_CHECK_ARG(d.vmode >= 0 && d.vmode <= 2, "ctrlv_gemm: bad vmode");
+  if (d.vmode) CTRLV_CHECK_ARG(d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv % 4 == 0 && (d.vmode == 1 || d.vS > 0), "ctrlv_gemm: bad row-vector table");
+  if (d.geglu) {
+    CTRLV_CHECK_SHAPE(d.N % 64 == 0, "ctrlv_gemm: GEGLU needs N %% 64 == 0");
+    CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !d.out_f32, "ctrlv_gemm: GEGLU epilogue takes bias only");
+  }
+  int tile = d.tile;
+  if (tile == 0) {
+    const long big_m = d.M >= 8192;
+    if (d.geglu) tile = (big_m && d.N % 256 == 0) ? 2 : 1;
+    else if (big_m && d.N % 256 == 0) tile = 2;
+    else if (big_m && d.N % 128 == 0) tile = 4;
+    else if (big_m && d.N % 64 == 0 && d.N % 128 != 0) tile = 3;
+    else tile = 1;
+  }
+  switch (tile) {
+    case 1: return launch<128, 128, 2, 2>(d, stream);
+    case 2: return launch<256, 256, 2, 4>(d, stream);
+    case 3: return launch<256, 64, 4, 1>(d, stream);
+    case 4: return launch<256, 128, 4, 2>(d, stream);
+    default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
+  }
+  return CTRLV_OK;
+}

@@ -1,0 +1,256 @@
+// GroupNorm(32)(+SiLU) and LayerNorm on channels-last bf16 rows, gfx950.  HBM-bound kernels: 16-byte vector
+// loads/stores (8 bf16 per lane), fp32 math, wave64 shuffle reductions, fp64 final combine of the split statistics.
+//
+// GroupNorm is a split reduction (SURVEY hard part H3: the 5-D temporal norm has only B*32 statistics rows of
+// up to 2.3 M elements each): pass 1 writes per-(image, row-chunk, group) partial (sum, sumsq); pass 2 reduces the
+// partials of its statistics row (deterministic order, fp64) and streams x -> y = silu(x*a_c + b_c).
+// Algorithmic traffic: 2 reads + 1 write of the tensor (the second read of mid-size tensors is served by L2 /
+// Infinity Cache).
+#include "common.h"
+
+namespace {
+
+struct GnShape {
+  int n_img, S, C, imgs_per_stat, c_split, n_chunks, rows_per_chunk, CV, RPP;
+};
+
+__device__ __forceinline__ uint4 gn_load(const bf16_t* x, const bf16_t* x2, int c_split, int C, long row, int c0) {
+  if (x2 != nullptr && c0 >= c_split) return *(const uint4*)(x2 + row * (C - c_split) + (c0 - c_split));
+  const int ld = x2 != nullptr ? c_split : C;
+  return *(const uint4*)(x + row * ld + c0);
+}
+
+__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
+                                float* __restrict__ partials) {
+  extern __shared__ float red[];  // [RPP][C][2]
+  const int tid = threadIdx.x;
+  const int col = tid % s.CV, rsub = tid / s.CV;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * s.rows_per_chunk;
+  const int r1 = min(s.S, r0 + s.rows_per_chunk);
+  const int c0 = col * 8;
+  float sm[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
+  for (int r = r0 + rsub; r < r1; r += s.RPP) {
+    const uint4 v = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0);
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[((rsub * s.C) + c0 + e) * 2 + 0] = sm[e];
+    red[((rsub * s.C) + c0 + e) * 2 + 1] = sq[e];
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int cpg = s.C / 32;
+    float a = 0.f, b = 0.f;
+    for (int rs = 0; rs < s.RPP; ++rs)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+        a += red[(rs * s.C + c) * 2 + 0];
+        b += red[(rs * s.C + c) * 2 + 1];
+      }
+    const int stat = n / s.imgs_per_stat;
+    const int gchunk = (n % s.imgs_per_stat) * s.n_chunks + chunk;
+    const long o = (((long)stat * s.imgs_per_stat * s.n_chunks + gchunk) * 32 + tid) * 2;
+    partials[o] = a;
+    partials[o + 1] = b;
+  }
+}
+
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
+                                const float* __restrict__ partials, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int silu, bf16_t* __restrict__ y) {
+  __shared__ double dred[8][32][2];
+  __shared__ float mean_s[32], rstd_s[32];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int stat = n / s.imgs_per_stat;
+  const int tot_chunks = s.imgs_per_stat * s.n_chunks;
+  // ---- reduce the partials of this statistics row: 8 slices x 32 groups, fp64
+  if (tid < 256) {
+    const int g = tid & 31, sl = tid >> 5;
+    double a = 0.0, b = 0.0;
+    const float* p = partials + ((long)stat * tot_chunks) * 64;
+    for (int k = sl; k < tot_chunks; k += 8) {
+      a += (double)p[(k * 32 + g) * 2];
+      b += (double)p[(k * 32 + g) * 2 + 1];
+    }
+    dred[sl][g][0] = a;
+    dred[sl][g][1] = b;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double a = 0.0, b = 0.0;
+    for (int sl = 0; sl < 8; ++sl) { a += dred[sl][tid][0]; b += dred[sl][tid][1]; }
+    const double cnt = (double)(s.C / 32) * (double)s.S * (double)s.imgs_per_stat;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (tid >= s.CV * s.RPP) return;
+  const int col = tid % s.CV, rsub = tid / s.CV;
+  const int c0 = col * 8, cpg = s.C / 32;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c0 + e) / cpg;
+    a[e] = rstd_s[g] * gamma[c0 + e];
+    b[e] = beta[c0 + e] - mean_s[g] * a[e];
+  }
+  const int r0 = chunk * s.rows_per_chunk;
+  const int r1 = min(s.S, r0 + s.rows_per_chunk);
+  for (int r = r0 + rsub; r < r1; r += s.RPP) {
+    const long row = (long)n * s.S + r;
+    const uint4 v = gn_load(x, x2, s.c_split, s.C, row, c0);
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * a[e] + b[e];
+      f[e] = silu ? silu_f(t) : t;
+    }
+    *(uint4*)(y + row * s.C + c0) = pack_bf16x8(f);
+  }
+}
+
+int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x2, GnShape* s) {
+  CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 32 == 0 && C % 8 == 0 && C <= 8192,
+                    "groupnorm: C=%d must be a multiple of 32 (and of 8), <= 8192", C);
+  CTRLV_CHECK_SHAPE(imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "groupnorm: n_img %% imgs_per_stat != 0");
+  if (has_x2) CTRLV_CHECK_SHAPE(c_split > 0 && c_split < C && c_split % 8 == 0, "groupnorm: bad c_split %d", c_split);
+  s->n_img = n_img; s->S = S; s->C = C; s->imgs_per_stat = imgs_per_stat; s->c_split = c_split;
+  s->CV = C / 8;
+  s->RPP = s->CV >= 256 ? 1 : 256 / s->CV;
+  int target = 2048 / n_img; if (target < 1) target = 1;
+  int nc = (S + 63) / 64; if (nc > target) nc = target; if (nc < 1) nc = 1;
+  s->rows_per_chunk = (S + nc - 1) / nc;
+  s->n_chunks = (S + s->rows_per_chunk - 1) / s->rows_per_chunk;
+  return CTRLV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, int M, int C,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
+                                                 bf16_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int CV = C >> 3;
+  float g[NV][8], b[NV][8];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int cv = lane + k * 64;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { g[k][e] = gamma[cv * 8 + e]; b[k][e] = beta[cv * 8 + e]; }
+    }
+  }
+  const float inv_c = 1.0f / (float)C;
+  for (long m = (long)blockIdx.x * 4 + wid; m < M; m += (long)gridDim.x * 4) {
+    float f[NV][8];
+    float s = 0.f;
+    const float* vrow = V ? V + (long)((m / vdiv) % vmod) * ldv : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+        const uint4 v = *(const uint4*)(x + m * C + cv * 8);
+        unpack_bf16x8(v, f[k]);
+        if (vrow) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[k][e] += vrow[cv * 8 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[k][e];
+      }
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dlt = f[k][e] - mean; q += dlt * dlt; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[k][e] - mean) * rstd * g[k][e] + b[k][e];
+        *(uint4*)(y + m * C + cv * 8) = pack_bf16x8(o);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat) {
+  GnShape s;
+  int rc = gn_shape(n_img, S, C, imgs_per_stat, 0, false, &s);
+  return rc < 0 ? rc : s.n_chunks;
+}
+
+extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split, int n_img, int S, int C,
+                                     int imgs_per_stat, float* partials, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(x && partials, "groupnorm_stats: null pointer");
+  GnShape s;
+  int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
+  if (rc < 0) return rc;
+  const int nt = s.CV * s.RPP;
+  const size_t smem = (size_t)s.RPP * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)x2, s, partials);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img, int S, int C,
+                                     int imgs_per_stat, const float* partials, const float* gamma, const float* beta,
+                                     float eps, int silu, void* y, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_apply: null pointer");
+  GnShape s;
+  int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
+  if (rc < 0) return rc;
+  int nt = s.CV * s.RPP;
+  if (nt < 256) nt = 256;  // the partial reduction uses 256 threads
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (const bf16_t*)x2, s, partials, gamma, beta, eps, silu, (bf16_t*)y);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps,
+                               const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
+  CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: C=%d must be a multiple of 8, <= 2048", C);
+  if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm: bad row-vector table");
+  const int nv = (C / 8 + 63) / 64;
+  long blocks = ((long)M + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+#define LN_LAUNCH(NV)                                                                                             \
+  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, M, C, gamma, beta, \
+                     eps, V, vdiv, vmod, ldv, (bf16_t*)y)
+  switch (nv) {
+    case 1: LN_LAUNCH(1); break;
+    case 2: LN_LAUNCH(2); break;
+    case 3: LN_LAUNCH(3); break;
+    default: LN_LAUNCH(4); break;
+  }
+#undef LN_LAUNCH
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}

@@ -1,0 +1,153 @@
+"""Tensor-level wrappers over the C ABI (include/ctrlv_hip.h).  Inputs are torch CUDA tensors used purely as
+device-memory handles; every call enqueues on torch's current HIP stream.  No wrapper has a fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.CtrlvHipError(f"ctrlv_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
+
+
+def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
+         R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
+         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0):
+    """out = epilogue(gather-GEMM(A[, A2], W)).  `conv` = (H, W, Ho, Wo, stride, up); `temporal` = (F, S)."""
+    _need_gpu(A, "A")
+    d = GemmDesc()
+    d.A, d.A2, d.W, d.out = _p(A), _p(A2), _p(W), _p(out)
+    d.bias, d.R1, d.R2, d.V = _p(bias), _p(R1), _p(R2), _p(V)
+    d.M = out.shape[0] if M is None else M
+    d.N, d.Cin, d.taps = N, cin, taps
+    d.lda = A.stride(0)
+    d.lda2 = A2.stride(0) if A2 is not None else 0
+    d.c_split = c_split
+    d.mode = mode
+    if conv is not None:
+        d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
+    if temporal is not None:
+        d.F, d.S = temporal
+    d.ldo = out.stride(0)
+    d.n_store = out.shape[1] if n_store is None else n_store
+    d.ldr1 = R1.stride(0) if R1 is not None else 0
+    d.ldr2 = R2.stride(0) if R2 is not None else 0
+    d.s_acc, d.s1, d.s2 = s_acc, s1, s2
+    d.vmode = vmode if V is not None else 0
+    d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
+    d.ldv = V.stride(0) if V is not None else 0
+    d.act, d.geglu, d.out_f32, d.tile = act, geglu, 1 if out_f32 else 0, tile
+    check(_lib.load().ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
+    return out
+
+
+def groupnorm_chunks(n_img, S, C, imgs_per_stat):
+    rc = _lib.load().ctrlv_groupnorm_chunks(n_img, S, C, imgs_per_stat)
+    if rc < 0:
+        check(rc, "ctrlv_groupnorm_chunks")
+    return rc
+
+
+def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
+    """Two-pass GroupNorm(32)(+SiLU) over channels-last rows; (x | x2) is a channel concat when x2 is given."""
+    _need_gpu(x, "x")
+    lib = _lib.load()
+    c_split = x.shape[1] if x2 is not None else 0
+    st = _stream()
+    check(lib.ctrlv_groupnorm_stats(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), st),
+          "ctrlv_groupnorm_stats")
+    check(lib.ctrlv_groupnorm_apply(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), _p(gamma),
+                                    _p(beta), eps, 1 if silu else 0, _p(y), st), "ctrlv_groupnorm_apply")
+    return y
+
+
+def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30):
+    _need_gpu(x, "x")
+    M, C = x.shape
+    check(_lib.load().ctrlv_layernorm(_p(x), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
+                                      V.stride(0) if V is not None else 0, _p(y), _stream()), "ctrlv_layernorm")
+    return y
+
+
+def attention_spatial(qkv, out, n_img, S, C):
+    _need_gpu(qkv, "qkv")
+    check(_lib.load().ctrlv_attention_spatial(_p(qkv), _p(out), n_img, S, C, _stream()), "ctrlv_attention_spatial")
+    return out
+
+
+def attention_temporal(qkv, out, B, F, S, C):
+    _need_gpu(qkv, "qkv")
+    check(_lib.load().ctrlv_attention_temporal(_p(qkv), _p(out), B, F, S, C, _stream()), "ctrlv_attention_temporal")
+    return out
+
+
+def nchw_to_rows(src, dst, c_off=0):
+    """src: contiguous (n_img, C, H, W) fp32/fp16/bf16 -> dst rows [n_img*H*W, ldc] bf16, channels [c_off, c_off+C)."""
+    _need_gpu(src, "src")
+    n_img, C = src.shape[0], src.shape[1]
+    HW = src.shape[2] * src.shape[3]
+    check(_lib.load().ctrlv_nchw_to_rows(_p(src), _DT[src.dtype], n_img, C, HW, _p(dst), dst.stride(0), c_off,
+                                         _stream()), "ctrlv_nchw_to_rows")
+    return dst
+
+
+def rows_to_nchw(src, dst, C=None):
+    """src rows [n_img*H*W, ldc] bf16 -> dst contiguous (n_img, C, H, W) of dst.dtype."""
+    _need_gpu(src, "src")
+    n_img, Cd = dst.shape[0], dst.shape[1]
+    HW = dst.shape[2] * dst.shape[3]
+    check(_lib.load().ctrlv_rows_to_nchw(_p(src), src.stride(0), n_img, Cd if C is None else C, HW, _p(dst),
+                                         _DT[dst.dtype], _stream()), "ctrlv_rows_to_nchw")
+    return dst
+
+
+def im2col3x3(x, n_img, H, W, col):
+    _need_gpu(x, "x")
+    check(_lib.load().ctrlv_im2col3x3(_p(x), n_img, H, W, x.shape[1], _p(col), col.shape[1], _stream()),
+          "ctrlv_im2col3x3")
+    return col
+
+
+def axpby(x, r, a, b, y):
+    _need_gpu(x, "x")
+    check(_lib.load().ctrlv_axpby(_p(x), _p(r), a, b, _p(y), x.numel(), _stream()), "ctrlv_axpby")
+    return y
+
+
+def silu(x, y):
+    _need_gpu(x, "x")
+    check(_lib.load().ctrlv_silu(_p(x), _p(y), x.numel(), _stream()), "ctrlv_silu")
+    return y
+
+
+def timestep_embedding(t, dim, out):
+    """t: fp32 [n] -> out [n, dim] bf16 = [cos | sin] (Timesteps(dim, flip_sin_to_cos=True, shift 0))."""
+    _need_gpu(t, "t")
+    check(_lib.load().ctrlv_timestep_embedding(_p(t), t.numel(), dim, _p(out), _stream()),
+          "ctrlv_timestep_embedding")
+    return out
+
+
+def cfg_euler_step(latents, noise_pred, guidance, sigma, sigma_next, scaled_next=None):
+    """In-place fused CFG combine + Euler v-prediction update (pipeline_video_control.py:327-332)."""
+    _need_gpu(latents, "latents")
+    B, F = latents.shape[0], latents.shape[1]
+    chw = latents[0, 0].numel()
+    cfg = 1 if noise_pred.shape[0] == 2 * B else 0
+    check(_lib.load().ctrlv_cfg_euler_step(_p(latents), _p(noise_pred), _DT[noise_pred.dtype], cfg, _p(guidance), B,
+                                           F, chw, float(sigma), float(sigma_next), _p(scaled_next), _stream()),
+          "ctrlv_cfg_euler_step")
+    return latents

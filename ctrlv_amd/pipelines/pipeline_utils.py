@@ -1,0 +1,350 @@
+"""Host-side pipeline plumbing shared by the two sampling pipelines.
+
+Restates the helpers the reference inherits from diffusers' `StableVideoDiffusionPipeline` (the
+reference vendors copies of `_encode_image` / `_encode_vae_image` / `_resize_with_antialiasing` at
+src/ctrlv/bbox_generator_baseline/utils/image_encoder.py:111-291, which serve as the spec) and implements the
+denoising loop body of pipeline_video_control.py:298-343 / pipeline_video_diffusion.py:259-293 on top of the HIP
+models: the CFG combine + Euler update is one fused kernel, latents stay fp32 on the device, sigmas stay on the
+host, so a step is `ControlNet fwd + UNet fwd + 1 kernel + 2 small copies` with no host synchronisation.
+VAE and CLIP are caller-supplied PyTorch-ROCm modules (out of the hot path, once per clip).
+"""
+import math
+from dataclasses import dataclass
+from typing import Union
+
+import numpy as np
+import torch
+import torch.nn.functional as Fnn
+
+from .. import ops
+
+try:                                  # PIL is optional: tensors are the primary input type
+    import PIL.Image
+except Exception:                     # pragma: no cover
+    PIL = None
+
+
+@dataclass
+class StableVideoDiffusionPipelineOutput:
+    frames: Union[list, np.ndarray, torch.Tensor]
+
+
+def _append_dims(x, target_dims):
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * dims_to_append]
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """Generator-device aware randn (a CPU generator draws on the CPU and the sample is moved)."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != shape[0]:
+            raise ValueError(f"got {len(generator)} generators for batch size {shape[0]}")
+        return torch.cat([randn_tensor((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], 0)
+    gdev = generator.device if generator is not None else device
+    return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+
+
+def _gaussian_kernel1d(ks, sigma, device, dtype):
+    x = torch.arange(ks, device=device, dtype=dtype) - ks // 2
+    if ks % 2 == 0:
+        x = x + 0.5
+    g = torch.exp(-x.pow(2.0) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def _resize_with_antialiasing(image, size, interpolation="bicubic", align_corners=True):
+    """Gaussian pre-blur (sigma from the down-scale factor) followed by bicubic resize."""
+    h, w = image.shape[-2:]
+    factors = (h / size[0], w / size[1])
+    sigmas = (max((factors[0] - 1.0) / 2.0, 0.001), max((factors[1] - 1.0) / 2.0, 0.001))
+    ks = [int(max(2.0 * 2 * s, 3)) for s in sigmas]
+    ks = [k + 1 if k % 2 == 0 else k for k in ks]
+    ky = _gaussian_kernel1d(ks[0], sigmas[0], image.device, image.dtype)
+    kx = _gaussian_kernel1d(ks[1], sigmas[1], image.device, image.dtype)
+    c = image.shape[1]
+    x = Fnn.pad(image, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+    x = Fnn.conv2d(x, ky.view(1, 1, -1, 1).expand(c, 1, -1, 1), groups=c)
+    x = Fnn.conv2d(x, kx.view(1, 1, 1, -1).expand(c, 1, 1, -1), groups=c)
+    return Fnn.interpolate(x, size=size, mode=interpolation, align_corners=align_corners)
+
+
+class VaeImageProcessor:
+    """The subset of diffusers' VaeImageProcessor the SVD pipelines use."""
+
+    def __init__(self, vae_scale_factor=8):
+        self.vae_scale_factor = vae_scale_factor
+
+    @staticmethod
+    def pil_to_numpy(images):
+        if not isinstance(images, list):
+            images = [images]
+        return np.stack([np.array(im).astype(np.float32) / 255.0 for im in images], axis=0)
+
+    @staticmethod
+    def numpy_to_pt(images):
+        if images.ndim == 3:
+            images = images[..., None]
+        return torch.from_numpy(images.transpose(0, 3, 1, 2))
+
+    @staticmethod
+    def pt_to_numpy(images):
+        return images.cpu().permute(0, 2, 3, 1).float().numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        return [PIL.Image.fromarray(im.squeeze() if im.shape[-1] == 1 else im) for im in images]
+
+    def preprocess(self, image, height=None, width=None):
+        if torch.is_tensor(image):
+            x = image if image.ndim == 4 else image[None]
+            x = x.float()
+            if height is not None and tuple(x.shape[-2:]) != (height, width):
+                x = Fnn.interpolate(x, size=(height, width), mode="bilinear", align_corners=False)
+            return x if x.min() < 0 else 2.0 * x - 1.0      # tensors already in [-1, 1] are passed through
+        if not isinstance(image, list):
+            image = [image]
+        if height is not None:
+            image = [im.resize((width, height), resample=PIL.Image.LANCZOS) for im in image]
+        return 2.0 * self.numpy_to_pt(self.pil_to_numpy(image)) - 1.0
+
+    def postprocess(self, image, output_type="pil"):
+        image = (image / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return image
+        image = self.pt_to_numpy(image)
+        return image if output_type == "np" else self.numpy_to_pil(image)
+
+
+def tensor2vid(video, processor, output_type="np"):
+    """(B, C, F, H, W) in [-1, 1] -> per-clip list / array / tensor of frames."""
+    outputs = []
+    for b in range(video.shape[0]):
+        outputs.append(processor.postprocess(video[b].permute(1, 0, 2, 3), output_type))
+    if output_type == "np":
+        return np.stack(outputs)
+    if output_type == "pt":
+        return torch.stack(outputs)
+    if output_type != "pil":
+        raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil']")
+    return outputs
+
+
+class _ProgressBar:
+    def __init__(self, total, disable):
+        self.total, self.disable, self.n = total, disable, 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, n=1):
+        self.n += n
+
+
+class SVDPipelineBase:
+    """Component registry + the inherited helpers + the HIP denoising loop."""
+
+    _component_names = ("vae", "image_encoder", "unet", "controlnet", "scheduler", "feature_extractor")
+
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self._components = list(kw)
+
+    # ---- device / dtype plumbing -----------------------------------------------------------------------------
+    def to(self, *args, **kwargs):
+        for name in self._components:
+            m = getattr(self, name, None)
+            if isinstance(m, torch.nn.Module):
+                m.to(*args, **kwargs)
+        return self
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    @property
+    def dtype(self):
+        return self.unet.dtype
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
+
+    def progress_bar(self, total=None):
+        return _ProgressBar(total, getattr(self, "_progress_bar_config", {}).get("disable", False))
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    def save_pretrained(self, save_directory, safe_serialization=True, **kw):
+        """Writes the HIP models in diffusers layout (`unet/`, `controlnet/`), as pipeline.save_pretrained does
+        at tools/train_video_controlnet.py:553; VAE / CLIP are the caller's modules and keep their own savers."""
+        import os
+        for name in ("unet", "controlnet"):
+            m = getattr(self, name, None)
+            if m is not None:
+                m.save_pretrained(os.path.join(save_directory, name), safe_serialization=safe_serialization)
+        for name in ("vae", "image_encoder"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "save_pretrained"):
+                m.save_pretrained(os.path.join(save_directory, name))
+
+    # ---- guidance ------------------------------------------------------------------------------------------------
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        if isinstance(self.guidance_scale, (int, float)):
+            return self.guidance_scale > 1
+        return self.guidance_scale.max() > 1
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    # ---- encoders (once per clip; PyTorch-ROCm modules) ----------------------------------------------------------
+    def _encode_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        dtype = next(self.image_encoder.parameters()).dtype
+        if not isinstance(image, torch.Tensor):
+            image = self.image_processor.pil_to_numpy(image)
+            image = self.image_processor.numpy_to_pt(image)
+            # normalise before resizing, un-normalise after (matches the original implementation)
+            image = image * 2.0 - 1.0
+            image = _resize_with_antialiasing(image, (224, 224))
+            image = (image + 1.0) / 2.0
+        image = self.feature_extractor(images=image, do_normalize=True, do_center_crop=False, do_resize=False,
+                                       do_rescale=False, return_tensors="pt").pixel_values
+        image = image.to(device=device, dtype=dtype)
+        image_embeddings = self.image_encoder(image).image_embeds
+        image_embeddings = image_embeddings.unsqueeze(1)
+        bs_embed, seq_len, _ = image_embeddings.shape
+        image_embeddings = image_embeddings.repeat(1, num_videos_per_prompt, 1)
+        image_embeddings = image_embeddings.view(bs_embed * num_videos_per_prompt, seq_len, -1)
+        if do_classifier_free_guidance:
+            image_embeddings = torch.cat([torch.zeros_like(image_embeddings), image_embeddings])
+        return image_embeddings
+
+    def _encode_vae_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        image = image.to(device=device)
+        image_latents = self.vae.encode(image).latent_dist.mode()          # NOT multiplied by scaling_factor
+        if do_classifier_free_guidance:
+            image_latents = torch.cat([torch.zeros_like(image_latents), image_latents])
+        return image_latents.repeat(num_videos_per_prompt, 1, 1, 1)
+
+    def _encode_vae_condition(self, cond_image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        """pipeline_video_control.py:71-101: bbox frames (3 channels) go through the VAE, latents (4) pass through."""
+        video_length = cond_image.shape[1]
+        cond_image = cond_image.to(device=device).to(dtype=self.vae.dtype)
+        if cond_image.shape[2] == 3:
+            b = cond_image.shape[0]
+            cond_em = self.vae.encode(cond_image.flatten(0, 1)).latent_dist.mode()
+            cond_em = cond_em.reshape(b, video_length, *cond_em.shape[1:])
+        else:
+            assert cond_image.shape[2] == 4, \
+                "The input tensor should have 3 or 4 channels. 3 for frames and 4 for latents."
+            cond_em = cond_image
+        cond_em = cond_em.repeat(num_videos_per_prompt, 1, 1, 1, 1)
+        if do_classifier_free_guidance:
+            cond_em = torch.cat([torch.zeros_like(cond_em), cond_em])
+        return cond_em
+
+    def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, batch_size, num_videos_per_prompt,
+                          do_classifier_free_guidance):
+        add_time_ids = [fps, motion_bucket_id, noise_aug_strength]
+        passed_add_embed_dim = self.unet.config.addition_time_embed_dim * len(add_time_ids)
+        expected_add_embed_dim = self.unet.add_embedding.linear_1.in_features
+        if expected_add_embed_dim != passed_add_embed_dim:
+            raise ValueError(
+                f"Model expects an added time embedding vector of length {expected_add_embed_dim}, but a vector of "
+                f"{passed_add_embed_dim} was created. The model has an incorrect config. Please check "
+                "`unet.config.time_embedding_type` and `text_encoder_2.config.projection_dim`.")
+        add_time_ids = torch.tensor([add_time_ids], dtype=dtype)
+        add_time_ids = add_time_ids.repeat(batch_size * num_videos_per_prompt, 1)
+        if do_classifier_free_guidance:
+            add_time_ids = torch.cat([add_time_ids, add_time_ids])
+        return add_time_ids
+
+    def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_frames, num_channels_latents // 2, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
+                             "the generators.")
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    def decode_latents(self, latents, num_frames, decode_chunk_size=14):
+        latents = latents.flatten(0, 1)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        frames = []
+        for i in range(0, latents.shape[0], decode_chunk_size):
+            num_frames_in = latents[i:i + decode_chunk_size].shape[0]
+            frames.append(self.vae.decode(latents[i:i + decode_chunk_size], num_frames=num_frames_in).sample)
+        frames = torch.cat(frames, dim=0)
+        frames = frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
+        return frames.float()
+
+    # ---- the hot loop --------------------------------------------------------------------------------------------
+    def _denoise(self, latents, image_latents, image_embeddings, added_time_ids, cond_em, num_inference_steps,
+                 min_guidance_scale, max_guidance_scale, control_condition_scale, callback_on_step_end,
+                 callback_on_step_end_tensor_inputs, progress_bar):
+        """Loop body of pipeline_video_control.py:298-343.  `latents` (B, F, 4, h, w) any float dtype."""
+        device = latents.device
+        model_dtype = image_embeddings.dtype
+        timesteps = self.scheduler.timesteps
+        B, F = latents.shape[:2]
+        do_cfg = bool(self.do_classifier_free_guidance)
+        guidance = torch.linspace(min_guidance_scale, max_guidance_scale, F, dtype=torch.float32, device=device)
+        lat32 = latents.to(torch.float32).contiguous()
+        nb = 2 * B if do_cfg else B
+        c_lat = lat32.shape[2]
+        # scaled model input | image latents on the channel dim (pipeline_video_control.py:300-304)
+        lmi = torch.empty(nb, F, c_lat + image_latents.shape[2], *lat32.shape[3:], dtype=model_dtype, device=device)
+        lmi[:, :, c_lat:] = image_latents.to(model_dtype)
+        sig0 = self.scheduler.sigma_at(0)
+        scaled = (lat32 / math.sqrt(sig0 ** 2 + 1)).to(torch.bfloat16)
+        controlnet = getattr(self, "controlnet", None) if cond_em is not None else None
+        for i, t in enumerate(timesteps):
+            lmi[:B, :, :c_lat] = scaled
+            if do_cfg:
+                lmi[B:, :, :c_lat] = scaled
+            down = mid = None
+            if controlnet is not None:
+                down, mid = controlnet(lmi, timestep=t, encoder_hidden_states=image_embeddings,
+                                       added_time_ids=added_time_ids, control_cond=cond_em,
+                                       conditioning_scale=control_condition_scale, return_dict=False)
+            noise_pred = self.unet(sample=lmi, timestep=t, encoder_hidden_states=image_embeddings,
+                                   added_time_ids=added_time_ids, down_block_additional_residuals=down,
+                                   mid_block_additional_residuals=mid, return_dict=False)[0]
+            # CFG combine + Euler v-prediction update, fused (pipeline_video_control.py:327-332)
+            ops.cfg_euler_step(lat32, noise_pred.contiguous(), guidance, self.scheduler.sigma_at(i),
+                               self.scheduler.sigma_at(i + 1), scaled)
+            if callback_on_step_end is not None:
+                latents_cb = lat32.to(model_dtype)
+                local = {"latents": latents_cb, "noise_pred": noise_pred, "image_latents": image_latents}
+                callback_kwargs = {k: local[k] for k in callback_on_step_end_tensor_inputs}
+                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                new = callback_outputs.pop("latents", latents_cb)
+                if new is not latents_cb:
+                    lat32 = new.to(torch.float32).contiguous()
+                    s_next = self.scheduler.sigma_at(i + 1)
+                    scaled = (lat32 / math.sqrt(s_next ** 2 + 1)).to(torch.bfloat16)
+            progress_bar.update()
+        return lat32.to(model_dtype)

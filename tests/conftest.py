@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Builds (if stale) and loads libctrlv_hip.so; GPU tests fail loudly if the native library is missing."""
+    import __graft_entry__ as g
+    if not os.path.exists(g.LIB):
+        g.build()
+    from ctrlv_amd import _lib
+    return _lib.load()
