@@ -1,0 +1,171 @@
+"""CPU tests of the oracle itself: structural known-answers and the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ctrlv_ref as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+torch.set_grad_enabled(False)
+
+
+def test_param_counts_match_published_svd_sizes():
+    with torch.device("meta"):
+        u, c = R.UNetSpatioTemporalConditionModel(), R.ControlNetModel()
+    assert sum(p.numel() for p in u.parameters()) == 1_524_623_082
+    assert sum(p.numel() for p in c.parameters()) == 680_946_897
+
+
+def test_state_dict_key_layout():
+    with torch.device("meta"):
+        u, c = R.UNetSpatioTemporalConditionModel(), R.ControlNetModel()
+    uk, ck = set(u.state_dict()), set(c.state_dict())
+    for k in ["conv_in.weight", "time_embedding.linear_1.weight", "add_embedding.linear_2.bias",
+              "down_blocks.0.resnets.0.spatial_res_block.norm1.weight",
+              "down_blocks.0.resnets.1.temporal_res_block.conv1.weight",
+              "down_blocks.1.resnets.0.spatial_res_block.conv_shortcut.weight",
+              "down_blocks.0.resnets.0.time_mixer.mix_factor",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_out.0.bias",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "down_blocks.0.attentions.0.temporal_transformer_blocks.0.ff_in.net.2.weight",
+              "down_blocks.0.attentions.0.temporal_transformer_blocks.0.norm_in.weight",
+              "down_blocks.0.attentions.0.time_pos_embed.linear_1.weight",
+              "down_blocks.0.attentions.0.time_mixer.mix_factor",
+              "down_blocks.2.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_out.weight",
+              "mid_block.resnets.1.temporal_res_block.time_emb_proj.bias",
+              "up_blocks.0.resnets.2.spatial_res_block.conv1.weight", "up_blocks.2.upsamplers.0.conv.bias",
+              "up_blocks.3.attentions.2.norm.weight", "conv_norm_out.weight", "conv_out.bias"]:
+        assert k in uk, k
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in uk and "up_blocks.0.attentions.0.norm.weight" not in uk
+    assert u.state_dict()["down_blocks.0.resnets.0.temporal_res_block.conv1.weight"].shape == (320, 320, 3, 1, 1)
+    assert u.state_dict()["up_blocks.3.resnets.0.spatial_res_block.conv1.weight"].shape == (320, 960, 3, 3)
+    assert u.state_dict()["up_blocks.1.resnets.2.spatial_res_block.conv1.weight"].shape == (1280, 1920, 3, 3)
+    only_ctrl = {k.split(".")[0] for k in ck - uk}
+    assert only_ctrl == {"control_conv_in", "controlnet_down_blocks", "controlnet_mid_block"}
+    assert not any(k.startswith(("up_blocks", "conv_norm_out", "conv_out")) for k in ck)
+    assert len([k for k in ck if k.startswith("controlnet_down_blocks") and k.endswith("weight")]) == 12
+    chans = [c.state_dict()[f"controlnet_down_blocks.{i}.weight"].shape[0] for i in range(12)]
+    assert chans == [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+
+
+def _tiny_pair(order="sb", zero_std=0.02):
+    cfg = dict(R.TINY_CONFIG)
+    unet = R.UNetSpatioTemporalConditionModel(time_context_order=order, **cfg)
+    R.seeded_init_(unet, 0)
+    ctrl = R.ControlNetModel.from_unet(unet, time_context_order=order)
+    R.seeded_init_(ctrl, 1, zero_conv_std=zero_std)
+    return unet, ctrl
+
+
+def test_from_unet_copies_the_key_intersection_and_zero_convs_are_a_noop():
+    cfg = dict(R.TINY_CONFIG)
+    unet = R.UNetSpatioTemporalConditionModel(**cfg)
+    R.seeded_init_(unet, 0)
+    ctrl = R.ControlNetModel.from_unet(unet)
+    usd, csd = unet.state_dict(), ctrl.state_dict()
+    for k in set(usd) & set(csd):
+        assert torch.equal(usd[k], csd[k]), k
+    assert all(csd[k].abs().max() == 0 for k in csd if k.startswith(("controlnet_down_blocks", "controlnet_mid")))
+    g = torch.Generator().manual_seed(0)
+    x, e = torch.randn(1, 3, 8, 8, 8, generator=g), torch.randn(1, 1, 64, generator=g)
+    ids, cc = torch.tensor([[6.0, 127.0, 0.02]]), torch.randn(1, 3, 4, 8, 8, generator=g)
+    t = torch.tensor(0.7)
+    down, mid = ctrl(x, t, e, ids, control_cond=cc)
+    assert len(down) == 12 and all(d.abs().max() == 0 for d in down) and mid.abs().max() == 0
+    assert torch.equal(unet(x, t, e, ids)[0], unet(x, t, e, ids, down, mid)[0])
+
+
+def test_controlnet_config_validation():
+    with pytest.raises(ValueError):
+        R.ControlNetModel(block_out_channels=(64, 128))
+    with pytest.raises(ValueError):
+        R.ControlNetModel(**dict(R.TINY_CONFIG, num_attention_heads=(1, 2)))
+
+
+def test_golden_scheduler_tables_and_formulas():
+    gold = np.load(os.path.join(GOLD, "scheduler_tables.npz"))
+    for n in (25, 30, 50):
+        s = R.EulerDiscreteScheduler()
+        s.set_timesteps(n)
+        np.testing.assert_array_equal(s.sigmas.numpy(), gold[f"sigmas_{n}"])
+        np.testing.assert_array_equal(s.timesteps.numpy(), gold[f"timesteps_{n}"])
+        # closed forms of SURVEY A.8
+        i = np.arange(n)
+        karras = (700.0 ** (1 / 7) + i / (n - 1) * (0.002 ** (1 / 7) - 700.0 ** (1 / 7))) ** 7
+        np.testing.assert_allclose(s.sigmas[:-1].numpy(), karras, rtol=1e-6)
+        np.testing.assert_allclose(s.timesteps.numpy(), 0.25 * np.log(karras), rtol=1e-5, atol=1e-6)
+        assert float(s.sigmas[-1]) == 0.0
+        assert abs(float(s.init_noise_sigma) - (700.0 ** 2 + 1) ** 0.5) < 1e-3
+    np.testing.assert_array_equal(R.guidance_scale_tensor(1.0, 3.0, 25, 1).numpy(), gold["guidance_1_3_25"])
+
+
+def test_scheduler_step_matches_training_side_formulas():
+    """tools/train_video_controlnet.py:405-410,468-471: c_in = 1/sqrt(s^2+1), c_out = -s/sqrt(s^2+1), c_skip = 1/(s^2+1)."""
+    s = R.EulerDiscreteScheduler()
+    s.set_timesteps(25)
+    g = torch.Generator().manual_seed(0)
+    x, v = torch.randn(1, 2, 4, 4, 4, generator=g) * 10, torch.randn(1, 2, 4, 4, 4, generator=g)
+    t = s.timesteps[5]
+    sig, sig_n = float(s.sigmas[5]), float(s.sigmas[6])
+    np.testing.assert_allclose(s.scale_model_input(x, t).numpy(), (x / (sig ** 2 + 1) ** 0.5).numpy(), rtol=1e-6)
+    denoised = v * (-sig / (sig ** 2 + 1) ** 0.5) + x / (sig ** 2 + 1)
+    expect = x + (x - denoised) / sig * (sig_n - sig)
+    np.testing.assert_allclose(s.step(v, t, x).numpy(), expect.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_golden_block_vectors():
+    gold = np.load(os.path.join(GOLD, "block_vectors.npz"))
+    ind = torch.zeros(1, 2)
+    rb = R.SpatioTemporalResBlock(64, 128, 256, eps=1e-6)
+    R.seeded_init_(rb, 11)
+    y = rb(torch.from_numpy(gold["res_x"]), torch.from_numpy(gold["res_temb"]), ind)
+    np.testing.assert_allclose(y.numpy(), gold["res_y"], rtol=1e-4, atol=1e-5)
+    tr = R.TransformerSpatioTemporalModel(1, 64, 64, 64)
+    R.seeded_init_(tr, 12)
+    y = tr(torch.from_numpy(gold["tr_x"]), torch.from_numpy(gold["tr_ehs"]), ind)
+    np.testing.assert_allclose(y.numpy(), gold["tr_y"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("order", ["sb", "bs"])
+def test_golden_model_vectors(order):
+    gold = np.load(os.path.join(GOLD, "model_vectors.npz"))
+    unet, ctrl = _tiny_pair(order)
+    for B in (1, 2):
+        g = torch.Generator().manual_seed(100 + B)
+        sample = torch.randn(B, 3, 8, 8, 8, generator=g)
+        cond = torch.randn(B, 3, 4, 8, 8, generator=g)
+        ehs = torch.randn(B, 1, 64, generator=g)
+        ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+        t = torch.tensor(1.6377)
+        down, mid = ctrl(sample, t, ehs, ids, control_cond=cond)
+        k = f"{order}_b{B}"
+        np.testing.assert_allclose(unet(sample, t, ehs, ids)[0].numpy(), gold[k + "_unet"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(unet(sample, t, ehs, ids, down, mid)[0].numpy(), gold[k + "_unet_ctrl"], rtol=1e-3,
+                                   atol=1e-4)
+        np.testing.assert_allclose(mid.numpy(), gold[k + "_mid"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(down[11].numpy(), gold[k + "_down11"], rtol=1e-3, atol=1e-4)
+    # hard part H1: the two context orders agree at batch 1 and differ at batch 2 (CFG)
+    other = "bs" if order == "sb" else "sb"
+    np.testing.assert_allclose(gold[f"{order}_b1_unet"], gold[f"{other}_b1_unet"], rtol=1e-4, atol=1e-5)
+    assert np.abs(gold["sb_b2_unet"] - gold["bs_b2_unet"]).max() > 1e-4
+
+
+def test_golden_sampling_trajectory():
+    gold = np.load(os.path.join(GOLD, "model_vectors.npz"))
+    unet, ctrl = _tiny_pair("sb")
+    g = torch.Generator().manual_seed(1234)
+    sched = R.EulerDiscreteScheduler()
+    lat = torch.randn(1, 3, 4, 16, 16, generator=g) * sched.init_noise_sigma
+    np.testing.assert_array_equal(lat.numpy(), gold["traj_init"])
+    img = torch.randn(1, 4, 16, 16, generator=g)
+    image_latents = torch.cat([torch.zeros_like(img), img]).unsqueeze(1).repeat(1, 3, 1, 1, 1)
+    e = torch.randn(1, 1, 64, generator=g)
+    c = torch.randn(1, 3, 4, 16, 16, generator=g)
+    rec = []
+    R.sample_loop(unet, ctrl, sched, lat, image_latents, torch.cat([torch.zeros_like(e), e]),
+                  torch.tensor([[6.0, 127.0, 0.02]] * 2), torch.cat([torch.zeros_like(c), c]), 3, record=rec)
+    for i, r in enumerate(rec):
+        np.testing.assert_allclose(r.numpy(), gold[f"traj_step{i}"], rtol=1e-3, atol=1e-3)
