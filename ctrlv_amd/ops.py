@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, profiler as _prof
 from ._lib import GemmDesc, check
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -50,7 +50,12 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
     d.ldv = V.stride(0) if V is not None else 0
     d.act, d.geglu, d.out_f32, d.tile = act, geglu, 1 if out_f32 else 0, tile
+    ev = _prof.begin()
     check(_lib.load().ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
+    if ev is not None:
+        n_alg = d.N if geglu else min(d.N, d.n_store)
+        fam = "gemm_conv3x3" if mode == 1 else ("gemm_conv_temporal" if mode == 2 else "gemm_linear")
+        _prof.end(ev, fam, 2.0 * d.M * n_alg * taps * cin)
     return out
 
 
@@ -67,30 +72,38 @@ def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, part
     lib = _lib.load()
     c_split = x.shape[1] if x2 is not None else 0
     st = _stream()
+    ev = _prof.begin()
     check(lib.ctrlv_groupnorm_stats(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), st),
           "ctrlv_groupnorm_stats")
     check(lib.ctrlv_groupnorm_apply(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), _p(gamma),
                                     _p(beta), eps, 1 if silu else 0, _p(y), st), "ctrlv_groupnorm_apply")
+    _prof.end(ev, "groupnorm", 0.0, 2.0 * 2 * n_img * S * C)       # algorithmic: 1 read + 1 write, bf16
     return y
 
 
 def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30):
     _need_gpu(x, "x")
     M, C = x.shape
+    ev = _prof.begin()
     check(_lib.load().ctrlv_layernorm(_p(x), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
                                       V.stride(0) if V is not None else 0, _p(y), _stream()), "ctrlv_layernorm")
+    _prof.end(ev, "layernorm", 0.0, 2.0 * 2 * M * C)
     return y
 
 
 def attention_spatial(qkv, out, n_img, S, C):
     _need_gpu(qkv, "qkv")
+    ev = _prof.begin()
     check(_lib.load().ctrlv_attention_spatial(_p(qkv), _p(out), n_img, S, C, _stream()), "ctrlv_attention_spatial")
+    _prof.end(ev, "attention_spatial", 4.0 * n_img * (C // 64) * S * S * 64, 2.0 * 4 * n_img * S * C)
     return out
 
 
 def attention_temporal(qkv, out, B, F, S, C):
     _need_gpu(qkv, "qkv")
+    ev = _prof.begin()
     check(_lib.load().ctrlv_attention_temporal(_p(qkv), _p(out), B, F, S, C, _stream()), "ctrlv_attention_temporal")
+    _prof.end(ev, "attention_temporal", 4.0 * B * S * (C // 64) * F * F * 64, 2.0 * 4 * B * F * S * C)
     return out
 
 
@@ -123,7 +136,9 @@ def im2col3x3(x, n_img, H, W, col):
 
 def axpby(x, r, a, b, y):
     _need_gpu(x, "x")
+    ev = _prof.begin()
     check(_lib.load().ctrlv_axpby(_p(x), _p(r), a, b, _p(y), x.numel(), _stream()), "ctrlv_axpby")
+    _prof.end(ev, "residual_add", 0.0, 2.0 * 3 * x.numel())
     return y
 
 

@@ -305,46 +305,96 @@ class SVDPipelineBase:
     def _denoise(self, latents, image_latents, image_embeddings, added_time_ids, cond_em, num_inference_steps,
                  min_guidance_scale, max_guidance_scale, control_condition_scale, callback_on_step_end,
                  callback_on_step_end_tensor_inputs, progress_bar):
-        """Loop body of pipeline_video_control.py:298-343.  `latents` (B, F, 4, h, w) any float dtype."""
-        device = latents.device
+        """Loop of pipeline_video_control.py:298-343.  `latents` (B, F, 4, h, w) any float dtype."""
         model_dtype = image_embeddings.dtype
-        timesteps = self.scheduler.timesteps
-        B, F = latents.shape[:2]
-        do_cfg = bool(self.do_classifier_free_guidance)
-        guidance = torch.linspace(min_guidance_scale, max_guidance_scale, F, dtype=torch.float32, device=device)
-        lat32 = latents.to(torch.float32).contiguous()
-        nb = 2 * B if do_cfg else B
-        c_lat = lat32.shape[2]
-        # scaled model input | image latents on the channel dim (pipeline_video_control.py:300-304)
-        lmi = torch.empty(nb, F, c_lat + image_latents.shape[2], *lat32.shape[3:], dtype=model_dtype, device=device)
-        lmi[:, :, c_lat:] = image_latents.to(model_dtype)
-        sig0 = self.scheduler.sigma_at(0)
-        scaled = (lat32 / math.sqrt(sig0 ** 2 + 1)).to(torch.bfloat16)
         controlnet = getattr(self, "controlnet", None) if cond_em is not None else None
-        for i, t in enumerate(timesteps):
-            lmi[:B, :, :c_lat] = scaled
-            if do_cfg:
-                lmi[B:, :, :c_lat] = scaled
-            down = mid = None
-            if controlnet is not None:
-                down, mid = controlnet(lmi, timestep=t, encoder_hidden_states=image_embeddings,
-                                       added_time_ids=added_time_ids, control_cond=cond_em,
-                                       conditioning_scale=control_condition_scale, return_dict=False)
-            noise_pred = self.unet(sample=lmi, timestep=t, encoder_hidden_states=image_embeddings,
-                                   added_time_ids=added_time_ids, down_block_additional_residuals=down,
-                                   mid_block_additional_residuals=mid, return_dict=False)[0]
-            # CFG combine + Euler v-prediction update, fused (pipeline_video_control.py:327-332)
-            ops.cfg_euler_step(lat32, noise_pred.contiguous(), guidance, self.scheduler.sigma_at(i),
-                               self.scheduler.sigma_at(i + 1), scaled)
+        stepper = DenoiseStepper(self.unet, controlnet, self.scheduler, latents, image_latents, image_embeddings,
+                                 added_time_ids, cond_em, min_guidance_scale, max_guidance_scale,
+                                 control_condition_scale, do_cfg=bool(self.do_classifier_free_guidance),
+                                 use_hip_graph=getattr(self, "use_hip_graph", False))
+        for i, t in enumerate(self.scheduler.timesteps):
+            noise_pred = stepper.step(i)
             if callback_on_step_end is not None:
-                latents_cb = lat32.to(model_dtype)
+                latents_cb = stepper.latents.to(model_dtype)
                 local = {"latents": latents_cb, "noise_pred": noise_pred, "image_latents": image_latents}
                 callback_kwargs = {k: local[k] for k in callback_on_step_end_tensor_inputs}
                 callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
                 new = callback_outputs.pop("latents", latents_cb)
                 if new is not latents_cb:
-                    lat32 = new.to(torch.float32).contiguous()
-                    s_next = self.scheduler.sigma_at(i + 1)
-                    scaled = (lat32 / math.sqrt(s_next ** 2 + 1)).to(torch.bfloat16)
+                    stepper.set_latents(new, i + 1)
             progress_bar.update()
-        return lat32.to(model_dtype)
+        return stepper.latents.to(model_dtype)
+
+
+class DenoiseStepper:
+    """One scheduler iteration for a batch of clips = the unit of the headline metric ("denoising step"):
+    scale + concat (pipeline_video_control.py:300-304) -> ControlNet forward (:305-313) -> UNet forward (:316-324)
+    -> CFG combine + Euler update (:327-332, one fused kernel).  Latents stay fp32 on the device and sigmas on the
+    host, so a step never synchronises.  With `use_hip_graph` the two model forwards are captured once into a HIP
+    graph (static input buffers, timestep read from device memory) and replayed every step."""
+
+    def __init__(self, unet, controlnet, scheduler, latents, image_latents, image_embeddings, added_time_ids,
+                 cond_em, min_guidance_scale=1.0, max_guidance_scale=3.0, control_condition_scale=1.0, do_cfg=True,
+                 use_hip_graph=False):
+        self.unet, self.controlnet, self.scheduler = unet, controlnet, scheduler
+        device = latents.device
+        self.model_dtype = image_embeddings.dtype
+        B, F = latents.shape[:2]
+        self.B, self.F, self.do_cfg = B, F, do_cfg
+        self.guidance = torch.linspace(min_guidance_scale, max_guidance_scale, F, dtype=torch.float32, device=device)
+        self.latents = latents.to(torch.float32).contiguous().clone()
+        nb = 2 * B if do_cfg else B
+        self.c_lat = self.latents.shape[2]
+        # scaled model input | image latents on the channel dim (pipeline_video_control.py:300-304)
+        self.lmi = torch.empty(nb, F, self.c_lat + image_latents.shape[2], *self.latents.shape[3:],
+                               dtype=self.model_dtype, device=device)
+        self.lmi[:, :, self.c_lat:] = image_latents.to(self.model_dtype)
+        self.image_embeddings, self.added_time_ids, self.cond_em = image_embeddings, added_time_ids, cond_em
+        self.control_scale = control_condition_scale
+        self.scaled = torch.empty(B, F, *self.latents.shape[2:], dtype=torch.bfloat16, device=device)
+        self.set_latents(self.latents, 0)
+        self.t_dev = torch.zeros((), dtype=torch.float32, device=device)
+        self.use_hip_graph = use_hip_graph
+        self._graph = None
+        self._noise_pred = None
+        self._eager_runs = 0
+
+    def set_latents(self, latents, sigma_index):
+        self.latents = latents.to(torch.float32).contiguous()
+        s = self.scheduler.sigma_at(sigma_index)
+        self.scaled.copy_(self.latents / math.sqrt(s ** 2 + 1))
+
+    def _forward(self, t):
+        down = mid = None
+        if self.controlnet is not None:
+            down, mid = self.controlnet(self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
+                                        added_time_ids=self.added_time_ids, control_cond=self.cond_em,
+                                        conditioning_scale=self.control_scale, return_dict=False)
+        return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
+                         added_time_ids=self.added_time_ids, down_block_additional_residuals=down,
+                         mid_block_additional_residuals=mid, return_dict=False)[0]
+
+    def step(self, i):
+        B, c = self.B, self.c_lat
+        self.lmi[:B, :, :c] = self.scaled
+        if self.do_cfg:
+            self.lmi[B:, :, :c] = self.scaled
+        t = self.scheduler.timesteps[i]
+        if not self.use_hip_graph:
+            noise_pred = self._forward(t)
+        else:
+            self.t_dev.copy_(t)
+            if self._graph is None and self._eager_runs < 1:
+                noise_pred = self._forward(self.t_dev)        # warm-up: sizes workspaces, packs weights
+                self._eager_runs += 1
+            else:
+                if self._graph is None:
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._noise_pred = self._forward(self.t_dev)
+                self._graph.replay()
+                noise_pred = self._noise_pred
+        ops.cfg_euler_step(self.latents, noise_pred.contiguous(), self.guidance, self.scheduler.sigma_at(i),
+                           self.scheduler.sigma_at(i + 1), self.scaled)
+        return noise_pred

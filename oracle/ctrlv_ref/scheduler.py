@@ -57,7 +57,7 @@ class EulerDiscreteScheduler:
         step_ratio = c["num_train_timesteps"] // num_inference_steps          # "leading"
         timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32)
         timesteps += c["steps_offset"]
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)      # interpolation_type == "linear"
         sigmas = self._convert_to_karras(in_sigmas=sigmas, num_inference_steps=num_inference_steps)
         sigmas = torch.from_numpy(sigmas).to(dtype=torch.float32, device=device)
