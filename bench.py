@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--hip-graph", type=int, default=int(os.environ.get("CTRLV_HIP_GRAPH", "1")),
                     help="replay the two model forwards from a captured HIP graph (default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="debug: only time the CPU oracle sample")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-latent", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1234)
@@ -164,8 +165,15 @@ def cpu_baseline(args):
                       f"({tf / sec * 1e3:.0f} GFLOP/s); scaled to 218.52 TFLOP/step"}
 
 
+def log(*a):
+    print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
     from ctrlv_amd import distributed as D
     from ctrlv_amd import profiler
     rank, world, local = D.init("nccl" if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
@@ -176,11 +184,15 @@ def main():
     torch.cuda.set_device(device)
     unet, ctrl = build_models(device, args.workload, args.frames)
     st = make_stepper(unet, ctrl, device, args, clip_index=rank)       # one clip per rank (weak scaling)
+    log(f"rank {rank}/{world}: models built on {device}, hip_graph={args.hip_graph}")
 
     i = 0
     for _ in range(max(args.warmup, 2 if args.hip_graph else 1)):      # graph mode: 1 eager + 1 capture step
         run_step(st, i); i += 1
     torch.cuda.synchronize()
+    log(f"warm-up done; workspace peak {unet._ws.peak / 2**30:.1f} GiB (UNet)"
+        + (f" + {ctrl._ws.peak / 2**30:.1f} GiB (ControlNet)" if ctrl is not None else "")
+        + f"; torch allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -197,6 +209,7 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     finite = bool(torch.isfinite(st.latents).all())
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
     if rank == 0 and args.hip_graph:
         # per-kernel HIP-event timing needs eager launches: one extra identical step outside the timed region
@@ -249,6 +262,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         del st, unet, ctrl
         torch.cuda.empty_cache()
+        log("timing the CPU oracle baseline (bounded sample) ...")
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line))
 
