@@ -45,6 +45,7 @@ def parse():
                     help="replay the two model forwards from a captured HIP graph (default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="debug: only time the CPU oracle sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle (0 = min(cores, 32))")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-latent", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1234)
@@ -101,7 +102,7 @@ def cpu_baseline(args):
     steps/s-equivalent = (sample TFLOP / seconds) / (218.52 TFLOP per full step)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctrlv_ref as R
-    cores = os.cpu_count() or 1
+    cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     F, L = args.cpu_frames, args.cpu_latent
     with torch.no_grad():
@@ -163,6 +164,28 @@ def cpu_baseline(args):
             "sample": f"oracle (plain PyTorch fp32, {cores} threads, {model}) ControlNet+UNet forward, full SVD widths, "
                       f"B=1 no CFG, {F} frames, {L}x{L} latent = {tf:.3f} TFLOP in {sec:.2f} s "
                       f"({tf / sec * 1e3:.0f} GFLOP/s); scaled to 218.52 TFLOP/step"}
+
+
+def cpu_baseline_child(args):
+    """Runs the CPU-oracle timing in a child process (own thread pool, hard time limit) so that a pathological host
+    (e.g. 256 hardware threads oversubscribing small ops) cannot stall the benchmark; retries with fewer threads."""
+    import subprocess
+    total = os.cpu_count() or 1
+    for thr in ([args.cpu_threads] if args.cpu_threads else [min(total, 32), 8]):
+        env = dict(os.environ, OMP_NUM_THREADS=str(thr), MKL_NUM_THREADS=str(thr))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(thr),
+               "--cpu-frames", str(args.cpu_frames), "--cpu-latent", str(args.cpu_latent), "--workload", args.workload]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            for ln in reversed(r.stdout.strip().splitlines()):
+                if ln.startswith("{"):
+                    res = json.loads(ln)
+                    res["host_cores"] = total
+                    return res
+            log(f"cpu baseline child ({thr} threads) produced no result: {r.stderr[-300:]}")
+        except subprocess.TimeoutExpired:
+            log(f"cpu baseline child with {thr} threads exceeded 240 s")
+    return {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "CPU oracle timing failed on this host"}
 
 
 def log(*a):
@@ -263,7 +286,7 @@ def main():
         del st, unet, ctrl
         torch.cuda.empty_cache()
         log("timing the CPU oracle baseline (bounded sample) ...")
-        line["cpu_baseline"] = cpu_baseline(args)
+        line["cpu_baseline"] = cpu_baseline_child(args)
     print(json.dumps(line))
 
 

@@ -43,8 +43,21 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
   v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
   return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// silu(x) = x * sigmoid(x) with the raw v_exp_f32 / v_rcp_f32 (1 ulp each); x -> -inf gives x * 0.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+// exact-erf GELU, 0.5*x*(1+erf(x/sqrt2)), through erfc(z) = t*(a1+t*(a2+t*(a3+t*(a4+t*a5))))*exp(-z^2), t = 1/(1+p*z)
+// (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7).  Written as x*(1 - erfc/2) for x >= 0 and x*erfc/2 for x < 0,
+// so there is no cancellation on the negative tail.  13 VALU instructions, 2 of them transcendental (libm erff: ~30).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  const float q = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float hc = 0.5f * q * e;           // erfc(z)/2
+  return x * (x >= 0.f ? 1.0f - hc : hc);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -17,6 +17,10 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
+
+// ping-pong schedule (gemm_pp.hip): tile 5 = 256x256, tile 6 = 256x320
+int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
 
 namespace {
 
@@ -152,82 +156,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
     }
   }
 
-  // ---- epilogue: lane owns row m; accumulator quad q holds columns n0 + 8q + 4h + {0..3}
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = bm + wr * WTM + i * 32 + r32;
-    if (m >= d.M) continue;
-    const float* vrow = nullptr;
-    if (d.vmode == 1) {
-      vrow = d.V + (long)((m / d.vdiv) % d.vmod) * d.ldv;
-    } else if (d.vmode == 2) {
-      vrow = d.V + (long)(((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod) * d.ldv;
-    }
-    if (d.geglu) {
-#pragma unroll
-      for (int j = 0; j + 1 < TN; j += 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;  // "a" column in the interleaved weight order
-          if (ncol >= d.N) continue;
-          const int ocol = ((bn + wc * WTN + j * 32) >> 1) + 8 * q + 4 * hsel;
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a = acc[i][j][4 * q + e], g = acc[i][j + 1][4 * q + e];
-            if (d.bias) { a += d.bias[ncol + e]; g += d.bias[ncol + 32 + e]; }
-            o[e] = a * gelu_erf_f(g);
-          }
-          if (ocol < d.n_store) {
-            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-            *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pk;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;
-          if (ncol >= d.N || ncol >= d.n_store) continue;
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
-          if (d.bias) {
-            const float4 b = *(const float4*)(d.bias + ncol);
-            o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] *= d.s_acc;
-          if (d.R1) {
-            const uint2 rv = *(const uint2*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ncol);
-            o[0] += d.s1 * __uint_as_float(rv.x << 16); o[1] += d.s1 * __uint_as_float(rv.x & 0xffff0000u);
-            o[2] += d.s1 * __uint_as_float(rv.y << 16); o[3] += d.s1 * __uint_as_float(rv.y & 0xffff0000u);
-          }
-          if (d.R2) {
-            const uint2 rv = *(const uint2*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ncol);
-            o[0] += d.s2 * __uint_as_float(rv.x << 16); o[1] += d.s2 * __uint_as_float(rv.x & 0xffff0000u);
-            o[2] += d.s2 * __uint_as_float(rv.y << 16); o[3] += d.s2 * __uint_as_float(rv.y & 0xffff0000u);
-          }
-          if (vrow) {
-            const float4 vv = *(const float4*)(vrow + ncol);
-            o[0] += vv.x; o[1] += vv.y; o[2] += vv.z; o[3] += vv.w;
-          }
-          if (d.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
-          }
-          if (d.out_f32) {
-            *(float4*)((float*)d.out + (long)m * d.ldo + ncol) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-            *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ncol) = pk;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -311,6 +240,10 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 2: return launch<256, 256, 2, 4>(d, stream);
     case 3: return launch<256, 64, 4, 1>(d, stream);
     case 4: return launch<256, 128, 4, 2>(d, stream);
+    case 5: return ctrlv_gemm_launch_pp(d, 5, stream);
+    case 6:
+      CTRLV_CHECK_ARG(!d.geglu, "ctrlv_gemm: tile 6 (256x320) cannot pair GEGLU columns; use tile 5");
+      return ctrlv_gemm_launch_pp(d, 6, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

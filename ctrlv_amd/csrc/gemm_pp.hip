@@ -1,0 +1,244 @@
+// Ping-pong gather-GEMM for gfx950: 256 x BN x 32 half-steps, 8 waves, 4-slot LDS-DMA ring, counted vmcnt.
+//
+// Same contract as gemm.hip (ctrlv_gemm_desc), different schedule.  The 2-stage kernel of gemm.hip drains
+// `vmcnt(0)` and barriers once per K-step with both waves of every SIMD in the same phase, which caps it at
+// ~0.3 of the MFMA peak (profiles/r01_*).  Here:
+//   * the two waves that share a SIMD (wave w and w+4) are put in different GROUPS and group 1 runs one barrier
+//     slot behind group 0: while one group issues its 16-20 MFMAs from registers, the other does its LDS fragment
+//     reads, its LDS-DMA issue and its waits -- matrix pipe and memory path of a SIMD alternate between its two waves
+//     (MI355X_MICROARCH "Two waves per SIMD"; guide T3/T4).
+//   * K advances in half-steps of 32; a ring of 4 LDS slots (4 x (256+BN) x 64 B) keeps 3 half-steps of LDS-DMA in
+//     flight across the raw s_barriers; waits are COUNTED (`s_waitcnt vmcnt(2*per_wave)`), never 0 in steady state.
+//   * hazards: slot of half-step j is read in phase L_j (group 0: slot 2j, group 1: slot 2j+1), re-filled by the DMA
+//     of half-step j+4 issued in L_{j+1}; every wave retires its own DMA(j+1) before the barrier that ends its L_j and
+//     finishes its ds_reads (lgkmcnt(0)) before that same barrier -- RAW and WAR are each separated by >= 1 barrier
+//     that all 8 waves pass.
+//   * 64-B LDS rows (32 bf16): physical 16-B chunk = logical ^ ((row>>2)&3) keeps ds_read_b128 conflict-free; the
+//     swizzle is applied on the per-lane DMA source address.
+// Tiles: BN = 256 (waves 2x4, wave tile 128x64) and BN = 320 (waves 4x2, wave tile 64x160) -- the latter makes
+// N = 320 / 640 / 960 / 1920 exact multiples (the C = 320 / 640 levels of the UNet).
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_done_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
+  constexpr int BM = 256, NW = 8, NH = 4;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_SLOT = BM * 64, B_SLOT = BN * 64, SLOT = A_SLOT + B_SLOT;
+  constexpr int A_TOT = BM / 16, B_TOT = BN / 16;            // 1-KiB DMA pieces (16 rows x 64 B) per half-step
+  constexpr int A_Q = A_TOT / NW;                            // per wave (2)
+  constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave upper bound (2 or 3)
+  static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 2;                                  // waves w and w+4 share a SIMD -> different groups
+  const int wr = wid / WN, wc = wid % WN;
+  const int r32 = lane & 31, hsel = lane >> 5;
+
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int tiles_m = (d.M + BM - 1) / BM;
+  const int t_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int bm = (t_id / tiles_n) * BM, bn = (t_id % tiles_n) * BN;
+
+  const int J = d.taps * (d.Cin >> 5);                       // half-steps
+  const long ktot = (long)d.taps * d.Cin;
+
+  // ---- per-lane DMA row state
+  const int prow = lane >> 2, pslot = lane & 3;
+  const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
+  const char* a_ptr[A_Q];
+  const char* a2_ptr[A_Q];
+  unsigned a_mask[A_Q];
+  int a_par[A_Q];
+#pragma unroll
+  for (int q = 0; q < A_Q; ++q) {
+    const int rt = (q * NW + wid) * 16 + prow;
+    const int m = bm + rt;
+    const int coff = (pslot ^ ((rt >> 2) & 3)) * 16;         // logical chunk this lane fetches (bytes)
+    const bool ok = m < d.M;
+    long row = m;
+    unsigned mask = ok ? 1u : 0u;
+    a_par[q] = 0;
+    if (MODE == 1) {
+      const int hw = d.Ho * d.Wo;
+      const int n_img = m / hw, rem = m - n_img * hw;
+      const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
+      int cy, cx;
+      if (d.up) { cy = yo >> 1; cx = xo >> 1; a_par[q] = (yo & 1) | ((xo & 1) << 1); }
+      else { cy = yo * d.stride; cx = xo * d.stride; }
+      row = ((long)n_img * d.H + cy) * d.Wd + cx;
+      mask = 0;
+      const int hl = d.H << d.up, wl = d.Wd << d.up;
+      const int y0 = d.up ? yo : cy, x0 = d.up ? xo : cx;     // coordinates in the (upsampled) conv input grid
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yi = y0 + t / 3 - 1, xi = x0 + t % 3 - 1;
+        if (ok && (unsigned)yi < (unsigned)hl && (unsigned)xi < (unsigned)wl) mask |= 1u << t;
+      }
+    } else if (MODE == 2) {
+      const int f = (m / d.S) % d.F;
+      mask = ok ? ((f > 0 ? 1u : 0u) | 2u | (f < d.F - 1 ? 4u : 0u)) : 0u;
+    }
+    a_ptr[q] = (const char*)d.A + row * d.lda * 2 + coff;
+    a2_ptr[q] = d.A2 ? (const char*)d.A2 + row * d.lda2 * 2 + coff : nullptr;
+    a_mask[q] = mask;
+  }
+  const char* b_ptr[B_Q];
+  bool b_ok[B_Q];
+#pragma unroll
+  for (int q = 0; q < B_Q; ++q) {
+    const int ib = q * NW + wid;
+    const int rt = ib * 16 + prow;
+    const int n = bn + rt;
+    b_ok[q] = ib < B_TOT && n < d.N;
+    b_ptr[q] = (const char*)d.W + ((long)n * ktot) * 2 + (pslot ^ ((rt >> 2) & 3)) * 16;
+  }
+
+  // issue stream state (half-step about to be issued)
+  int is_tap = 0, is_cc = 0;
+  auto issue = [&](int j) {
+    char* sa = smem + (j & (NH - 1)) * SLOT;
+    char* sb = sa + A_SLOT;
+    const bool second = d.A2 != nullptr && is_cc >= d.c_split;
+    const int ld = second ? d.lda2 : d.lda;
+    const int ch = second ? is_cc - d.c_split : is_cc;
+    long delta = (long)ch * 2;
+    int dyo = 0, dxo = 0;
+    if (MODE == 1) {
+      dyo = is_tap / 3 - 1; dxo = is_tap % 3 - 1;
+      if (!d.up) delta += ((long)dyo * d.Wd + dxo) * ld * 2;
+    } else if (MODE == 2) {
+      delta += (long)(is_tap - 1) * d.S * ld * 2;
+    }
+#pragma unroll
+    for (int q = 0; q < A_Q; ++q) {
+      const char* p = (second ? a2_ptr[q] : a_ptr[q]) + delta;
+      if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
+        const int oy = ((a_par[q] & 1) + dyo) >> 1, ox = ((a_par[q] >> 1) + dxo) >> 1;
+        p += ((long)oy * d.Wd + ox) * ld * 2;
+      }
+      const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ok ? p : zsrc), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
+    }
+    const long koff = (long)j * 64;   // 32 bf16 per half-step
+#pragma unroll
+    for (int q = 0; q < B_Q; ++q) {
+      if (q * NW + wid < B_TOT)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(b_ok[q] ? b_ptr[q] + koff : zsrc), LDS_PTR(sb + (q * NW + wid) * 1024),
+                                         16, 0, 0);
+    }
+    is_cc += 32;
+    if (is_cc == d.Cin) { is_cc = 0; ++is_tap; }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int sw = (r32 >> 2) & 3;
+  const int a_frag = (wr * WTM + r32) * 64;
+  const int b_frag = A_SLOT + (wc * WTN + r32) * 64;
+  // DMA pieces this wave issues per half-step (uniform per wave): A_Q + (B pieces)
+  const bool b_extra = (B_Q - 1) * NW + wid < B_TOT;         // true for all waves when B_TOT % 8 == 0
+  constexpr bool UNEVEN = (B_TOT % NW) != 0;
+
+  // ---- prologue: 3 half-steps in flight
+  issue(0);
+  if (J > 1) issue(1);
+  if (J > 2) issue(2);
+  if (J > 2) { if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>(); }
+  else if (J > 1) { if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>(); }
+  else wait_vmcnt<0>();
+  raw_barrier();
+  if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
+
+  for (int j = 0; j < J; ++j) {
+    // ---------------- L phase: fragments of half-step j -> registers; DMA for j+3; retire own DMA(j+1)
+    const char* st = smem + (j & (NH - 1)) * SLOT;
+    bf16x8 af[TM][2], wf[TN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 2 + hsel) ^ sw) * 16;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
+    }
+    if (j + 3 < J) {
+      issue(j + 3);
+      if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>();
+    } else if (j + 2 < J) {
+      if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    lds_done_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- C phase: MFMAs from registers
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < J) raw_barrier();                            // no barrier after the last C phase (counts match)
+  }
+  if (grp == 0) raw_barrier();                               // pairs with group 1's barrier before its last C phase
+
+  gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
+}
+
+template <int BN, int WM, int WN, int MODE>
+int launch_one(const ctrlv_gemm_desc& d, hipStream_t stream) {
+  constexpr int smem = 4 * (256 + BN) * 64;
+  static bool attr_set = false;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE>;
+  if (!attr_set) {
+    CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), smem, stream, d);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+template <int BN, int WM, int WN>
+int launch_mode(const ctrlv_gemm_desc& d, hipStream_t stream) {
+  switch (d.mode) {
+    case 0: return launch_one<BN, WM, WN, 0>(d, stream);
+    case 1: return launch_one<BN, WM, WN, 1>(d, stream);
+    default: return launch_one<BN, WM, WN, 2>(d, stream);
+  }
+}
+
+}  // namespace
+
+// tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2)
+int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
+  if (tile == 5) return launch_mode<256, 2, 4>(d, stream);
+  return launch_mode<320, 4, 2>(d, stream);
+}

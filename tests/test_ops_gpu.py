@@ -45,8 +45,8 @@ def g(seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ gather-GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64)])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
     from ctrlv_amd import packing
     A = bf(torch.randn(M, K, generator=g(1)))
@@ -73,7 +73,7 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
     assert rel_l2(out32, ref2) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("tile", [1, 2, 4, 5])
 def test_gemm_geglu(ops, tile):
     from ctrlv_amd import packing
     M, C = 333, 64
@@ -89,7 +89,7 @@ def test_gemm_geglu(ops, tile):
     assert rel_l2(out, ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
 def test_gemm_conv3x3(ops, tile, stride, up):
     from ctrlv_amd import packing
@@ -109,7 +109,7 @@ def test_gemm_conv3x3(ops, tile, stride, up):
     assert rel_l2(nchw_from_rows(out.cpu(), n, Ho, Wo), ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 4])
+@pytest.mark.parametrize("tile", [1, 4, 5, 6])
 def test_gemm_temporal_conv(ops, tile):
     from ctrlv_amd import packing
     B, Fr, C, H, W = 2, 5, 64, 4, 6
@@ -125,14 +125,15 @@ def test_gemm_temporal_conv(ops, tile):
     assert rel_l2(got, ref) < 3e-3
 
 
-def test_gemm_concat_split(ops):
+@pytest.mark.parametrize("tile", [0, 5, 6])
+def test_gemm_concat_split(ops, tile):
     from ctrlv_amd import packing
     M, C1, C2, N = 500, 128, 64, 128
     a1, a2 = bf(torch.randn(M, C1, generator=g(1))), bf(torch.randn(M, C2, generator=g(2)))
     wt = torch.randn(N, C1 + C2, generator=g(3)) / math.sqrt(C1 + C2)
     ref = torch.cat([a1, a2], 1).float() @ bf(wt).float().T
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm(a1.to(DEV), packing.pack_linear(wt).to(DEV), out, N=N, cin=C1 + C2, A2=a2.to(DEV), c_split=C1)
+    ops.gemm(a1.to(DEV), packing.pack_linear(wt).to(DEV), out, N=N, cin=C1 + C2, A2=a2.to(DEV), c_split=C1, tile=tile)
     assert rel_l2(out, ref) < 3e-3
     # 3x3 conv over a channel concat (the up-block skip-concat path reads both tensors in place)
     n, H, W = 2, 6, 8
@@ -141,7 +142,7 @@ def test_gemm_concat_split(ops):
     refc = F.conv2d(torch.cat([x1, x2], 1).float(), bf(wc).float(), None, padding=1)
     outc = torch.empty(n * H * W, N, dtype=torch.bfloat16, device=DEV)
     ops.gemm(rows_from_nchw(x1).to(DEV), packing.pack_conv3x3(wc).to(DEV), outc, N=N, cin=C1 + C2, taps=9, mode=1,
-             conv=(H, W, H, W, 1, 0), A2=rows_from_nchw(x2).to(DEV), c_split=C1)
+             conv=(H, W, H, W, 1, 0), A2=rows_from_nchw(x2).to(DEV), c_split=C1, tile=tile)
     assert rel_l2(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
