@@ -228,12 +228,14 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   }
   int tile = d.tile;
   if (tile == 0) {
-    const long big_m = d.M >= 8192;
-    if (d.geglu) tile = (big_m && d.N % 256 == 0) ? 2 : 1;
-    else if (big_m && d.N % 256 == 0) tile = 2;
-    else if (big_m && d.N % 128 == 0) tile = 4;
-    else if (big_m && d.N % 64 == 0 && d.N % 128 != 0) tile = 3;
-    else tile = 1;
+    // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): the persistent ping-pong tiles win on
+    // every layer shape of the UNet; 256x320 where N is a multiple of 320 (C = 320 / 640 levels, conv / FF-out at
+    // 1280), 256x256 otherwise and for GEGLU (needs 64-column wave tiles); tiny-M per-clip GEMMs stay on 128x128.
+    const bool big = d.M >= 1024 && d.N >= 128;
+    if (!big) tile = 1;
+    else if (d.geglu) tile = 5;
+    else if (d.N % 320 == 0 && d.N < 3840 && d.M >= 16384) tile = 6;
+    else tile = 5;
   }
   switch (tile) {
     case 1: return launch<128, 128, 2, 2>(d, stream);

@@ -15,6 +15,10 @@
 //     that all 8 waves pass.
 //   * 64-B LDS rows (32 bf16): physical 16-B chunk = logical ^ ((row>>2)&3) keeps ds_read_b128 conflict-free; the
 //     swizzle is applied on the per-lane DMA source address.
+//   * PERSISTENT: one workgroup per CU walks its tiles (XCD-contiguous windows) and the DMA ring runs straight
+//     through tile boundaries -- the first three half-steps of tile T+1 are already in flight while tile T finishes and
+//     its epilogue (stores, GEGLU) runs, so short-K layers (K = 320: only 10 half-steps) no longer pay an exposed
+//     prologue per tile.  Group 1 stays one barrier slot behind group 0 across tiles.
 // Tiles: BN = 256 (waves 2x4, wave tile 128x64) and BN = 320 (waves 4x2, wave tile 64x160) -- the latter makes
 // N = 320 / 640 / 960 / 1920 exact multiples (the C = 320 / 640 levels of the UNet).
 #include "common.h"
@@ -52,107 +56,106 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
   const int tiles_n = (d.N + BN - 1) / BN;
   const int tiles_m = (d.M + BM - 1) / BM;
-  const int t_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int bm = (t_id / tiles_n) * BM, bn = (t_id % tiles_n) * BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  // tile of round r for this block: XCD-contiguous inside every window of G tiles
+  const int my_first = xcd_remap(blockIdx.x, G);
+  const int my_ntiles = (ntiles - my_first + G - 1) / G;       // >= 1 (grid <= ntiles)
 
-  const int J = d.taps * (d.Cin >> 5);                       // half-steps
+  const int J = d.taps * (d.Cin >> 5);                       // half-steps per tile
   const long ktot = (long)d.taps * d.Cin;
+  const int total = my_ntiles * J;                           // half-steps this block executes
 
-  // ---- per-lane DMA row state
+  // ---- per-lane DMA row state of the tile the ISSUE stream is in (kept small: row indices, not pointers)
   const int prow = lane >> 2, pslot = lane & 3;
   const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
-  const char* a_ptr[A_Q];
-  const char* a2_ptr[A_Q];
-  unsigned a_mask[A_Q];
-  int a_par[A_Q];
+  const int coff = (pslot ^ ((prow >> 2) & 3)) * 16;         // logical chunk this lane fetches (bytes); the piece
+                                                             // base row is a multiple of 16, so (row>>2)&3 == (prow>>2)&3
+  int a_row[A_Q];                                            // source row index of the tap centre (0 if invalid)
+  unsigned a_mask[A_Q];                                      // bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
+  int b_n[B_Q];                                              // weight row, -1 if out of range
+  auto setup = [&](int tile) {
+    const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
 #pragma unroll
-  for (int q = 0; q < A_Q; ++q) {
-    const int rt = (q * NW + wid) * 16 + prow;
-    const int m = bm + rt;
-    const int coff = (pslot ^ ((rt >> 2) & 3)) * 16;         // logical chunk this lane fetches (bytes)
-    const bool ok = m < d.M;
-    long row = m;
-    unsigned mask = ok ? 1u : 0u;
-    a_par[q] = 0;
-    if (MODE == 1) {
-      const int hw = d.Ho * d.Wo;
-      const int n_img = m / hw, rem = m - n_img * hw;
-      const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
-      int cy, cx;
-      if (d.up) { cy = yo >> 1; cx = xo >> 1; a_par[q] = (yo & 1) | ((xo & 1) << 1); }
-      else { cy = yo * d.stride; cx = xo * d.stride; }
-      row = ((long)n_img * d.H + cy) * d.Wd + cx;
-      mask = 0;
-      const int hl = d.H << d.up, wl = d.Wd << d.up;
-      const int y0 = d.up ? yo : cy, x0 = d.up ? xo : cx;     // coordinates in the (upsampled) conv input grid
+    for (int q = 0; q < A_Q; ++q) {
+      const int m = bm + (q * NW + wid) * 16 + prow;
+      const bool ok = m < d.M;
+      int row = m;
+      unsigned mask = ok ? 1u : 0u;
+      if (MODE == 1) {
+        const int hw = d.Ho * d.Wo;
+        const int n_img = m / hw, rem = m - n_img * hw;
+        const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
+        int cy, cx;
+        mask = 0;
+        if (d.up) { cy = yo >> 1; cx = xo >> 1; mask = ((unsigned)(yo & 1) << 16) | ((unsigned)(xo & 1) << 17); }
+        else { cy = yo * d.stride; cx = xo * d.stride; }
+        row = (n_img * d.H + cy) * d.Wd + cx;
+        const int hl = d.H << d.up, wl = d.Wd << d.up;
+        const int y0 = d.up ? yo : cy, x0 = d.up ? xo : cx;   // coordinates in the (upsampled) conv input grid
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int yi = y0 + t / 3 - 1, xi = x0 + t % 3 - 1;
-        if (ok && (unsigned)yi < (unsigned)hl && (unsigned)xi < (unsigned)wl) mask |= 1u << t;
+        for (int t = 0; t < 9; ++t) {
+          const int yi = y0 + t / 3 - 1, xi = x0 + t % 3 - 1;
+          if (ok && (unsigned)yi < (unsigned)hl && (unsigned)xi < (unsigned)wl) mask |= 1u << t;
+        }
+      } else if (MODE == 2) {
+        const int f = (m / d.S) % d.F;
+        mask = ok ? ((f > 0 ? 1u : 0u) | 2u | (f < d.F - 1 ? 4u : 0u)) : 0u;
       }
-    } else if (MODE == 2) {
-      const int f = (m / d.S) % d.F;
-      mask = ok ? ((f > 0 ? 1u : 0u) | 2u | (f < d.F - 1 ? 4u : 0u)) : 0u;
+      a_row[q] = ok ? row : 0;
+      a_mask[q] = mask;
     }
-    a_ptr[q] = (const char*)d.A + row * d.lda * 2 + coff;
-    a2_ptr[q] = d.A2 ? (const char*)d.A2 + row * d.lda2 * 2 + coff : nullptr;
-    a_mask[q] = mask;
-  }
-  const char* b_ptr[B_Q];
-  bool b_ok[B_Q];
 #pragma unroll
-  for (int q = 0; q < B_Q; ++q) {
-    const int ib = q * NW + wid;
-    const int rt = ib * 16 + prow;
-    const int n = bn + rt;
-    b_ok[q] = ib < B_TOT && n < d.N;
-    b_ptr[q] = (const char*)d.W + ((long)n * ktot) * 2 + (pslot ^ ((rt >> 2) & 3)) * 16;
-  }
+    for (int q = 0; q < B_Q; ++q) {
+      const int ib = q * NW + wid;
+      const int n = bn + ib * 16 + prow;
+      b_n[q] = (ib < B_TOT && n < d.N) ? n : -1;
+    }
+  };
 
-  // issue stream state (half-step about to be issued)
-  int is_tap = 0, is_cc = 0;
-  auto issue = [&](int j) {
-    char* sa = smem + (j & (NH - 1)) * SLOT;
+  // issue stream state (global half-step g about to be issued; its tile-local index, tap and channel offset)
+  int is_tile = my_first, is_j = 0, is_tap = 0, is_cc = 0;
+  setup(is_tile);
+  auto issue = [&](int g) {
+    if (is_j == J) {                                         // the stream crosses into this block's next tile
+      is_tile += G; is_j = 0; is_tap = 0; is_cc = 0;
+      setup(is_tile);
+    }
+    char* sa = smem + (g & (NH - 1)) * SLOT;
     char* sb = sa + A_SLOT;
     const bool second = d.A2 != nullptr && is_cc >= d.c_split;
-    const int ld = second ? d.lda2 : d.lda;
-    const int ch = second ? is_cc - d.c_split : is_cc;
-    long delta = (long)ch * 2;
-    int dyo = 0, dxo = 0;
+    const char* abase = (const char*)(second ? d.A2 : d.A) + ((second ? is_cc - d.c_split : is_cc) * 2 + coff);
+    const long ld2 = (long)(second ? d.lda2 : d.lda) * 2;     // row pitch in bytes
+    int dyo = 0, dxo = 0, roff = 0;
     if (MODE == 1) {
       dyo = is_tap / 3 - 1; dxo = is_tap % 3 - 1;
-      if (!d.up) delta += ((long)dyo * d.Wd + dxo) * ld * 2;
+      if (!d.up) roff = dyo * d.Wd + dxo;
     } else if (MODE == 2) {
-      delta += (long)(is_tap - 1) * d.S * ld * 2;
+      roff = (is_tap - 1) * d.S;
     }
 #pragma unroll
     for (int q = 0; q < A_Q; ++q) {
-      const char* p = (second ? a2_ptr[q] : a_ptr[q]) + delta;
+      int row = a_row[q] + roff;
       if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
-        const int oy = ((a_par[q] & 1) + dyo) >> 1, ox = ((a_par[q] >> 1) + dxo) >> 1;
-        p += ((long)oy * d.Wd + ox) * ld * 2;
+        const int oy = ((int)((a_mask[q] >> 16) & 1) + dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + dxo) >> 1;
+        row += oy * d.Wd + ox;
       }
       const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ok ? p : zsrc), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
+      const char* p = ok ? abase + (long)row * ld2 : zsrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
     }
-    const long koff = (long)j * 64;   // 32 bf16 per half-step
+    const char* wbase = (const char*)d.W + ((long)is_tap * d.Cin + is_cc) * 2 + coff;   // == is_j * 64 + coff
 #pragma unroll
     for (int q = 0; q < B_Q; ++q) {
-      if (q * NW + wid < B_TOT)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(b_ok[q] ? b_ptr[q] + koff : zsrc), LDS_PTR(sb + (q * NW + wid) * 1024),
-                                         16, 0, 0);
+      if (q * NW + wid < B_TOT) {
+        const char* p = b_n[q] >= 0 ? wbase + (long)b_n[q] * (ktot * 2) : zsrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (q * NW + wid) * 1024), 16, 0, 0);
+      }
     }
+    ++is_j;
     is_cc += 32;
     if (is_cc == d.Cin) { is_cc = 0; ++is_tap; }
   };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int sw = (r32 >> 2) & 3;
   const int a_frag = (wr * WTM + r32) * 64;
@@ -161,54 +164,74 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   const bool b_extra = (B_Q - 1) * NW + wid < B_TOT;         // true for all waves when B_TOT % 8 == 0
   constexpr bool UNEVEN = (B_TOT % NW) != 0;
 
-  // ---- prologue: 3 half-steps in flight
+  // ---- prologue: 3 half-steps in flight (total >= 2 always: Cin >= 64)
   issue(0);
-  if (J > 1) issue(1);
-  if (J > 2) issue(2);
-  if (J > 2) { if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>(); }
-  else if (J > 1) { if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>(); }
-  else wait_vmcnt<0>();
+  issue(1);
+  if (total > 2) issue(2);
+  if (total > 2) { if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>(); }
+  else { if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>(); }
   raw_barrier();
   if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
 
-  for (int j = 0; j < J; ++j) {
-    // ---------------- L phase: fragments of half-step j -> registers; DMA for j+3; retire own DMA(j+1)
-    const char* st = smem + (j & (NH - 1)) * SLOT;
-    bf16x8 af[TM][2], wf[TN][2];
+  f32x16 acc[TM][TN];
+  int g = 0;
+  for (int tr = 0; tr < my_ntiles; ++tr) {
+    const int tile = my_first + tr * G;
+    const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
+    for (int j = 0; j < J; ++j, ++g) {
+      // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
+      const char* st = smem + (g & (NH - 1)) * SLOT;
+      bf16x8 af[TM][2], wf[TN][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 2 + hsel) ^ sw) * 16;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 2 + hsel) ^ sw) * 16;
 #pragma unroll
-      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff);
+        for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
+        for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
+      }
+      if (g + 3 < total) {
+        issue(g + 3);
+        if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>();
+      } else if (g + 2 < total) {
+        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      lds_done_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- C phase: MFMAs from registers (first half-step of a tile starts from a literal-zero C)
+      __builtin_amdgcn_s_setprio(1);
+      if (j == 0) {
+        f32x16 zero;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][1], af[i][1], acc[i][n], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < total) raw_barrier();                      // no barrier after the very last C phase (counts match)
     }
-    if (j + 3 < J) {
-      issue(j + 3);
-      if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>();
-    } else if (j + 2 < J) {
-      if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    lds_done_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- C phase: MFMAs from registers
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < J) raw_barrier();                            // no barrier after the last C phase (counts match)
+    gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
   }
   if (grp == 0) raw_barrier();                               // pairs with group 1's barrier before its last C phase
-
-  gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
 }
 
 template <int BN, int WM, int WN, int MODE>
@@ -220,8 +243,16 @@ int launch_one(const ctrlv_gemm_desc& d, hipStream_t stream) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    CTRLV_HIP_TRY(hipGetDevice(&dev));
+    CTRLV_HIP_TRY(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (num_cu <= 0) num_cu = 256;
+  }
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), smem, stream, d);
+  const int grid = tiles < num_cu ? tiles : num_cu;          // persistent: one 512-thread workgroup per CU
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -146,6 +146,30 @@ def test_gemm_concat_split(ops, tile):
     assert rel_l2(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
+@pytest.mark.parametrize("tile", [5, 6])
+def test_gemm_persistent_many_tiles(ops, tile):
+    """More output tiles than CUs: every persistent workgroup walks several tiles and the LDS-DMA ring runs through the
+    tile boundaries (ragged last M tile, conv halo rows, 2 N tiles for the 256-wide tile)."""
+    from ctrlv_amd import packing
+    n, cin, cout, H, W = 9, 64, 320, 96, 100          # M = 86400 -> 338 M-tiles
+    x = bf(torch.randn(n, cin, H, W, generator=g(1)))
+    wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g(3))
+    ref = F.conv2d(x.float(), bf(wt).float(), b, padding=1)
+    out = torch.empty(n * H * W, cout, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(rows_from_nchw(x).to(DEV), packing.pack_conv3x3(wt).to(DEV), out, N=cout, cin=cin, taps=9, mode=1,
+             conv=(H, W, H, W, 1, 0), bias=b.to(DEV), tile=tile)
+    assert rel_l2(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
+    # short-K linear (2 half-steps per tile: the ring holds pieces of two tiles at once)
+    M = 86400
+    A = bf(torch.randn(M, 64, generator=g(4)))
+    wl = torch.randn(640, 64, generator=g(5)) / 8
+    R1 = bf(torch.randn(M, 640, generator=g(6)))
+    outl = torch.empty(M, 640, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A.to(DEV), packing.pack_linear(wl).to(DEV), outl, N=640, cin=64, R1=R1.to(DEV), tile=tile)
+    assert rel_l2(outl, A.float() @ bf(wl).float().T + R1.float()) < 3e-3
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs) into per-kernel HBM traffic.
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports
+exactly 1/2 of the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B) -> doubled here;
+WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Other access widths are uncalibrated (flagged in the output).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    if "gemm_pp_kernel" in name:
+        return "gemm_pp_kernel"
+    for k in ("gemm_kernel", "attn_spatial_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_apply_kernel",
+              "ln_kernel", "axpby_kernel", "im2col3x3_kernel", "cfg_euler_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+def load(path, counter):
+    per = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            fam = family(r["Kernel_Name"])
+            if fam is None:
+                continue
+            per[fam][0] += 1
+            per[fam][1] += float(r["Counter_Value"])
+    return per
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    fe, wr = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    res = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches; FETCH doubled per the gfx950 "
+                    "calibration for wide coalesced reads; includes Infinity-Cache hits (fabric-side counters)"}
+    for fam in sorted(set(fe) | set(wr)):
+        nf, vf = fe.get(fam, [0, 0.0])
+        nw, vw = wr.get(fam, [0, 0.0])
+        res[fam] = {
+            "launches_fetch_pass": nf, "launches_write_pass": nw,
+            "fetch_bytes_per_launch": 2.0 * vf * 1024 / max(nf, 1),
+            "write_bytes_per_launch": vw * 1024 / max(nw, 1),
+        }
+        res[fam]["traffic_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch"] + res[fam]["write_bytes_per_launch"]
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for k, v in res.items():
+        if k != "_note":
+            print(f"{k:24s} launches {v['launches_fetch_pass']:5d}  fetch {v['fetch_bytes_per_launch'] / 1e6:10.1f} MB  "
+                  f"write {v['write_bytes_per_launch'] / 1e6:10.1f} MB per launch")
+
+
+if __name__ == "__main__":
+    main()
