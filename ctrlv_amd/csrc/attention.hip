@@ -10,6 +10,8 @@
 //   spatial : 128 queries x 64-key tiles per workgroup (4 waves x 32 rows), 2-stage K/V ring, S up to 9216.
 //   temporal: one wave per (clip, pixel, head): 25 frames padded to one 32x32 tile; the (b f) s c <-> (b s) f c
 //             permutes of TemporalBasicTransformerBlock are row-stride arithmetic (stride S*3C between frames).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -50,7 +52,9 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 }
 
 // ---------------------------------------------------------------------------------------------- spatial
-__global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// launch_bounds(256, 2): a 256-register budget makes hipcc keep the score / output accumulators in arch VGPRs; with the
+// default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB)
   const int lane = threadIdx.x & 63;
@@ -102,15 +106,11 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
   const int vkey = 4 * hsel + (i16 >> 2);
   const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
 
-  const int nt = (S + 63) / 64;
-  issue(0, 0);
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+  constexpr float kDeferLog2 = 6.0f;   // T13: keep the running max while a tile's max exceeds it by < 2^6 (P <= 64)
+  auto tile = [&](int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const char* kst = smem + (t & 1) * 16384;
     const char* vst = kst + 8192;
-
     f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
       }
     }
-    if (t == nt - 1 && (S & 63)) {  // key masking on a ragged last tile
+    if (MASKED) {  // key masking on the ragged last tile only (separate instantiation: no selects in the main loop)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -137,24 +137,28 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
     mx = half_max(mx) * kScaleLog2;
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // deferred rescale: only when some row's max grew by more than 2^kDeferLog2 (always on the first tile: m_run = -inf).
+    // P of this tile is exponentiated AFTER the decision against the max that is kept, and O / l are scaled exactly once.
+    if (!__all(mx - m_run <= kDeferLog2)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kt][e] * kScaleLog2 - m_new);
+        const float p = __builtin_amdgcn_exp2f(sacc[kt][e] * kScaleLog2 - m_run);
         sacc[kt][e] = p;
         rs += p;
       }
-    l_run = l_run * alpha + rs;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
-
+    l_run += rs;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -168,6 +172,21 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         }
       }
     }
+  };
+
+  const int nt = (S + 63) / 64;
+  const int nt_full = S / 64;
+  issue(0, 0);
+  for (int t = 0; t < nt_full; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    tile(t, std::false_type{});
+  }
+  if (nt_full < nt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile(nt_full, std::true_type{});
   }
 
   const float l_tot = half_sum(l_run);
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- temporal
-__global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             int B, int F, int S, int C) {
   __shared__ __attribute__((aligned(1024))) char smem[4 * 4096];  // one 32x64 V tile per wave
   const int lane = threadIdx.x & 63;

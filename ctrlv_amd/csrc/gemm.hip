@@ -242,10 +242,12 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 2: return launch<256, 256, 2, 4>(d, stream);
     case 3: return launch<256, 64, 4, 1>(d, stream);
     case 4: return launch<256, 128, 4, 2>(d, stream);
-    case 5: return ctrlv_gemm_launch_pp(d, 5, stream);
+    case 5:
+    case 7: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 6:
-      CTRLV_CHECK_ARG(!d.geglu, "ctrlv_gemm: tile 6 (256x320) cannot pair GEGLU columns; use tile 5");
-      return ctrlv_gemm_launch_pp(d, 6, stream);
+    case 8:
+      CTRLV_CHECK_ARG(!d.geglu, "ctrlv_gemm: the 256x320 tile cannot pair GEGLU columns; use the 256x256 tile");
+      return ctrlv_gemm_launch_pp(d, tile, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

@@ -66,14 +66,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   const long ktot = (long)d.taps * d.Cin;
   const int total = my_ntiles * J;                           // half-steps this block executes
 
-  // ---- per-lane DMA row state of the tile the ISSUE stream is in (kept small: row indices, not pointers)
+  // ---- per-lane DMA row state of the tile the ISSUE stream is in.  Sources are addressed through buffer descriptors
+  // (buffer_load ... lds): a 32-bit byte offset per lane, and every invalid row (conv halo, frame edge, tile overhang)
+  // simply gets an out-of-range offset -- the hardware range check returns zeros, no zero page, no 64-bit pointer math.
   const int prow = lane >> 2, pslot = lane & 3;
-  const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
-  const int coff = (pslot ^ ((prow >> 2) & 3)) * 16;         // logical chunk this lane fetches (bytes); the piece
+  const unsigned coff = (pslot ^ ((prow >> 2) & 3)) * 16;    // logical chunk this lane fetches (bytes); the piece
                                                              // base row is a multiple of 16, so (row>>2)&3 == (prow>>2)&3
-  int a_row[A_Q];                                            // source row index of the tap centre (0 if invalid)
+  const unsigned kOOB = 0xFFFFFFFFu;
+  const long a_rows = MODE == 1 ? (long)(d.M / (d.Ho * d.Wo)) * d.H * d.Wd : (long)d.M;
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(a_rows * d.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(d.A2 ? d.A2 : d.A), 0, (int)(d.A2 ? a_rows * d.lda2 * 2 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.W, 0, (int)((long)d.N * ktot * 2), 0x00020000);
+  int a_row[A_Q];                                            // source row index of the tap centre
   unsigned a_mask[A_Q];                                      // bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
-  int b_n[B_Q];                                              // weight row, -1 if out of range
+  unsigned b_voff[B_Q];                                      // byte offset of the weight row (+chunk), kOOB if out of range
   auto setup = [&](int tile) {
     const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
 #pragma unroll
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     for (int q = 0; q < B_Q; ++q) {
       const int ib = q * NW + wid;
       const int n = bn + ib * 16 + prow;
-      b_n[q] = (ib < B_TOT && n < d.N) ? n : -1;
+      b_voff[q] = (ib < B_TOT && n < d.N) ? (unsigned)n * (unsigned)(ktot * 2) + coff : kOOB;
     }
   };
 
@@ -124,8 +133,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     char* sa = smem + (g & (NH - 1)) * SLOT;
     char* sb = sa + A_SLOT;
     const bool second = d.A2 != nullptr && is_cc >= d.c_split;
-    const char* abase = (const char*)(second ? d.A2 : d.A) + ((second ? is_cc - d.c_split : is_cc) * 2 + coff);
-    const long ld2 = (long)(second ? d.lda2 : d.lda) * 2;     // row pitch in bytes
+    const int ld2 = (second ? d.lda2 : d.lda) * 2;           // row pitch in bytes
     int dyo = 0, dxo = 0, roff = 0;
     if (MODE == 1) {
       dyo = is_tap / 3 - 1; dxo = is_tap % 3 - 1;
@@ -133,24 +141,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     } else if (MODE == 2) {
       roff = (is_tap - 1) * d.S;
     }
+    // uniform part of the byte offset (may be "negative": 32-bit modular arithmetic, the per-lane sum is in range)
+    const unsigned uni = (unsigned)(roff * ld2) + (unsigned)((second ? is_cc - d.c_split : is_cc) * 2) + 0u;
 #pragma unroll
     for (int q = 0; q < A_Q; ++q) {
-      int row = a_row[q] + roff;
+      int row = a_row[q];
       if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
         const int oy = ((int)((a_mask[q] >> 16) & 1) + dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + dxo) >> 1;
         row += oy * d.Wd + ox;
       }
       const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
-      const char* p = ok ? abase + (long)row * ld2 : zsrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
+      const unsigned voff = ok ? (unsigned)row * (unsigned)ld2 + coff + uni : kOOB;
+      if (second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
     }
-    const char* wbase = (const char*)d.W + ((long)is_tap * d.Cin + is_cc) * 2 + coff;   // == is_j * 64 + coff
+    const int wsoff = (is_tap * d.Cin + is_cc) * 2;            // == is_j * 64: K offset of this half-step (scalar)
 #pragma unroll
     for (int q = 0; q < B_Q; ++q) {
-      if (q * NW + wid < B_TOT) {
-        const char* p = b_n[q] >= 0 ? wbase + (long)b_n[q] * (ktot * 2) : zsrc;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (q * NW + wid) * 1024), 16, 0, 0);
-      }
+      if (q * NW + wid < B_TOT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(sb + (q * NW + wid) * 1024), 16, b_voff[q], wsoff, 0, 0);
     }
     ++is_j;
     is_cc += 32;
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 }
 
 template <int BN, int WM, int WN, int MODE>
-int launch_one(const ctrlv_gemm_desc& d, hipStream_t stream) {
+int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   constexpr int smem = 4 * (256 + BN) * 64;
   static bool attr_set = false;
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE>;
@@ -251,25 +262,27 @@ int launch_one(const ctrlv_gemm_desc& d, hipStream_t stream) {
     if (num_cu <= 0) num_cu = 256;
   }
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
-  const int grid = tiles < num_cu ? tiles : num_cu;          // persistent: one 512-thread workgroup per CU
+  const int grid = (persistent && tiles > num_cu) ? num_cu : tiles;   // persistent: one 512-thread workgroup per CU
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
 
 template <int BN, int WM, int WN>
-int launch_mode(const ctrlv_gemm_desc& d, hipStream_t stream) {
+int launch_mode(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   switch (d.mode) {
-    case 0: return launch_one<BN, WM, WN, 0>(d, stream);
-    case 1: return launch_one<BN, WM, WN, 1>(d, stream);
-    default: return launch_one<BN, WM, WN, 2>(d, stream);
+    case 0: return launch_one<BN, WM, WN, 0>(d, persistent, stream);
+    case 1: return launch_one<BN, WM, WN, 1>(d, persistent, stream);
+    default: return launch_one<BN, WM, WN, 2>(d, persistent, stream);
   }
 }
 
 }  // namespace
 
-// tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2)
+// tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
+// workgroup per output tile instead of one persistent workgroup per CU.
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
-  if (tile == 5) return launch_mode<256, 2, 4>(d, stream);
-  return launch_mode<320, 4, 2>(d, stream);
+  const bool persistent = tile <= 6;
+  if (tile == 5 || tile == 7) return launch_mode<256, 2, 4>(d, persistent, stream);
+  return launch_mode<320, 4, 2>(d, persistent, stream);
 }

@@ -45,7 +45,7 @@ def g(seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ gather-GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
     from ctrlv_amd import packing
@@ -146,7 +146,7 @@ def test_gemm_concat_split(ops, tile):
     assert rel_l2(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("tile", [5, 6, 7, 8])
 def test_gemm_persistent_many_tiles(ops, tile):
     """More output tiles than CUs: every persistent workgroup walks several tiles and the LDS-DMA ring runs through the
     tile boundaries (ragged last M tile, conv halo rows, 2 N tiles for the 256-wide tile)."""
