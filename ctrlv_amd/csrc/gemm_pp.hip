@@ -37,6 +37,7 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "me
 
 template <int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
   }
   if (grp == 0) raw_barrier();                               // pairs with group 1's barrier before its last C phase
+#endif
 }
 
 template <int BN, int WM, int WN, int MODE>
