@@ -26,6 +26,16 @@
 
 namespace {
 
+// Diagnostic build only (-DCTRLV_PP_STAMP, tools/gemm_stamp.py): per-wave cycle sums of the phases of the schedule,
+// written to the buffer passed in d.V with vmode == 0 (unused by the profiled launch).  The shipped library contains no stamp.
+#ifdef CTRLV_PP_STAMP
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -126,47 +136,69 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // issue stream state (global half-step g about to be issued; its tile-local index, tap and channel offset)
   int is_tile = my_first, is_j = 0, is_tap = 0, is_cc = 0;
   setup(is_tile);
-  auto issue = [&](int g) {
+  const bool dbg_nodma = (d.out_f32 & 4) != 0;   // profiling aid (tools/gemm_sweep.py)
+  // One half-step's DMA is issued piece by piece (issue_begin, issue_a(q)..., issue_b(q)..., issue_end) so that the
+  // pieces can sit in the gaps of an MFMA cluster: an LDS-DMA piece costs 100-200 cycles of issue when four waves
+  // of a CU issue together (measured with tools/gemm_stamp.py: 934 cycles per half-step in the load phase), ~60
+  // among MFMAs (MI355X_MICROARCH cycle constants).
+  char* is_sa = nullptr;
+  char* is_sb = nullptr;
+  bool is_second = false;
+  int is_ld2 = 0, is_dyo = 0, is_dxo = 0, is_wsoff = 0;
+  unsigned is_uni = 0;
+  auto issue_begin = [&](int g) {
     if (is_j == J) {                                         // the stream crosses into this block's next tile
       is_tile += G; is_j = 0; is_tap = 0; is_cc = 0;
       setup(is_tile);
     }
-    char* sa = smem + (g & (NH - 1)) * SLOT;
-    char* sb = sa + A_SLOT;
-    const bool second = d.A2 != nullptr && is_cc >= d.c_split;
-    const int ld2 = (second ? d.lda2 : d.lda) * 2;           // row pitch in bytes
-    int dyo = 0, dxo = 0, roff = 0;
+    is_sa = smem + (g & (NH - 1)) * SLOT;
+    is_sb = is_sa + A_SLOT;
+    is_second = d.A2 != nullptr && is_cc >= d.c_split;
+    is_ld2 = (is_second ? d.lda2 : d.lda) * 2;               // row pitch in bytes
+    int roff = 0;
+    is_dyo = 0; is_dxo = 0;
     if (MODE == 1) {
-      dyo = is_tap / 3 - 1; dxo = is_tap % 3 - 1;
-      if (!d.up) roff = dyo * d.Wd + dxo;
+      is_dyo = is_tap / 3 - 1; is_dxo = is_tap % 3 - 1;
+      if (!d.up) roff = is_dyo * d.Wd + is_dxo;
     } else if (MODE == 2) {
       roff = (is_tap - 1) * d.S;
     }
     // uniform part of the byte offset (may be "negative": 32-bit modular arithmetic, the per-lane sum is in range)
-    const unsigned uni = (unsigned)(roff * ld2) + (unsigned)((second ? is_cc - d.c_split : is_cc) * 2) + 0u;
-#pragma unroll
-    for (int q = 0; q < A_Q; ++q) {
-      int row = a_row[q];
-      if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
-        const int oy = ((int)((a_mask[q] >> 16) & 1) + dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + dxo) >> 1;
-        row += oy * d.Wd + ox;
-      }
-      const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
-      const unsigned voff = ok ? (unsigned)row * (unsigned)ld2 + coff + uni : kOOB;
-      if (second)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+    is_uni = (unsigned)(roff * is_ld2) + (unsigned)((is_second ? is_cc - d.c_split : is_cc) * 2);
+    is_wsoff = (is_tap * d.Cin + is_cc) * 2;                 // == is_j * 64: K offset of this half-step (scalar)
+  };
+  auto issue_a = [&](int q) {
+    if (dbg_nodma) return;
+    int row = a_row[q];
+    if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
+      const int oy = ((int)((a_mask[q] >> 16) & 1) + is_dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + is_dxo) >> 1;
+      row += oy * d.Wd + ox;
     }
-    const int wsoff = (is_tap * d.Cin + is_cc) * 2;            // == is_j * 64: K offset of this half-step (scalar)
-#pragma unroll
-    for (int q = 0; q < B_Q; ++q) {
-      if (q * NW + wid < B_TOT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(sb + (q * NW + wid) * 1024), 16, b_voff[q], wsoff, 0, 0);
-    }
+    const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
+    const unsigned voff = ok ? (unsigned)row * (unsigned)is_ld2 + coff + is_uni : kOOB;
+    if (is_second)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+  };
+  auto issue_b = [&](int q) {
+    if (dbg_nodma) return;
+    if (q * NW + wid < B_TOT)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(is_sb + (q * NW + wid) * 1024), 16, b_voff[q], is_wsoff,
+                                               0, 0);
+  };
+  auto issue_end = [&]() {
     ++is_j;
     is_cc += 32;
     if (is_cc == d.Cin) { is_cc = 0; ++is_tap; }
+  };
+  auto issue = [&](int g) {                                  // whole half-step at once (prologue)
+    issue_begin(g);
+#pragma unroll
+    for (int q = 0; q < A_Q; ++q) issue_a(q);
+#pragma unroll
+    for (int q = 0; q < B_Q; ++q) issue_b(q);
+    issue_end();
   };
 
   const int sw = (r32 >> 2) & 3;
@@ -187,6 +219,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
   f32x16 acc[TM][TN];
   int g = 0;
+#ifdef CTRLV_PP_STAMP
+  unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
+  STAMP(t_begin);
+#endif
   for (int tr = 0; tr < my_ntiles; ++tr) {
     const int tile = my_first + tr * G;
     const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
@@ -194,6 +230,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
       const char* st = smem + (g & (NH - 1)) * SLOT;
       bf16x8 af[TM][2], wf[TN][2];
+      STAMP(t0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int coff = ((ks * 2 + hsel) ^ sw) * 16;
@@ -202,47 +239,81 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
       }
-      if (g + 3 < total) {
-        issue(g + 3);
-        if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>();
-      } else if (g + 2 < total) {
+      STAMP(t1);
+      // own DMA(g+1) must have landed; DMA(g+2) (issued in the previous C phase) may stay in flight
+      if (g + 2 < total) {
         if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
       } else {
         wait_vmcnt<0>();
       }
+      STAMP(t2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(t2b);
       lds_done_barrier();
+      STAMP(t3);
+      STAMP_ADD(c_lread, t0, t1);
+      STAMP_ADD(c_lwait, t1, t2b);
+      STAMP_ADD(c_lbar, t2b, t3);
       __builtin_amdgcn_sched_barrier(0);
-      // ---------------- C phase: MFMAs from registers (first half-step of a tile starts from a literal-zero C)
-      __builtin_amdgcn_s_setprio(1);
-      if (j == 0) {
-        f32x16 zero;
+      // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
+      // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
+      const bool do_issue = g + 3 < total;
+      if (do_issue) issue_begin(g + 3);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+      for (int grpi = 0; grpi < 4; ++grpi) {
+        constexpr int HM = TM / 2;
+        const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
+        __builtin_amdgcn_s_setprio(1);
+        if (j == 0 && ks == 0) {
+          f32x16 zero;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int e = 0; e < 16; ++e) zero[e] = 0.f;
 #pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
+          for (int i = i0; i < i0 + HM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int n = 0; n < TN; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][1], af[i][1], acc[i][n], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
+          for (int i = i0; i < i0 + HM; ++i)
 #pragma unroll
             for (int n = 0; n < TN; ++n)
               acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_issue) {
+          if (grpi == 0) issue_a(0);
+          if (grpi == 1) { if (A_Q > 1) issue_a(1); }
+          if (grpi == 2) issue_b(0);
+          if (grpi == 3) {
+            if (B_Q > 1) issue_b(1);
+            if (B_Q > 2) issue_b(2);
+            issue_end();
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+      STAMP(t4);
       if (g + 1 < total) raw_barrier();                      // no barrier after the very last C phase (counts match)
+      STAMP(t5);
+      STAMP_ADD(c_mfma, t3, t4);
+      STAMP_ADD(c_cbar, t4, t5);
     }
+    STAMP(t6);
     gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
+    STAMP(t7);
+    STAMP_ADD(c_epi, t6, t7);
   }
+#ifdef CTRLV_PP_STAMP
+  STAMP(t_end);
+  if (lane == 0 && d.V != nullptr && d.vmode == 0) {
+    unsigned long long* o = (unsigned long long*)d.V + ((long)blockIdx.x * 8 + wid) * 10;
+    o[0] = t_end - t_begin; o[1] = c_lread; o[2] = c_lissue; o[3] = c_lwait; o[4] = c_lbar; o[5] = c_mfma;
+    o[6] = c_cbar; o[7] = c_epi; o[8] = (unsigned long long)total; o[9] = (unsigned long long)my_ntiles;
+  }
+#endif
   if (grp == 0) raw_barrier();                               // pairs with group 1's barrier before its last C phase
 #endif
 }

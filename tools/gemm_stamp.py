@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Diagnostic: builds a STAMPED copy of the ping-pong GEMM (-DCTRLV_PP_STAMP, s_memtime around every phase) into a
+scratch library and prints where a persistent workgroup's cycles go, per layer shape.  Never part of the product."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "ctrlv_amd", "csrc")
+OUT = os.path.join(ROOT, "gpurun_out", "libctrlv_stamp.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    for s in ("gemm.hip", "gemm_pp.hip"):
+        o = os.path.join(ROOT, "gpurun_out", s + ".stamp.o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                               "-DCTRLV_PP_STAMP", "-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+
+
+def main():
+    build()
+    from ctrlv_amd import _lib
+    lib = ctypes.CDLL(OUT)
+    lib.ctrlv_gemm.restype = ctypes.c_int
+    lib.ctrlv_gemm.argtypes = [ctypes.POINTER(_lib.GemmDesc), ctypes.c_void_p]
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    N0, N1 = 50 * 9216, 50 * 2304
+    shapes = [("L0 qkv 320->960", N0, 960, 320, 1, 0, None, 6, 0),
+              ("L0 proj 320->320 +R1", N0, 320, 320, 1, 0, None, 6, 1),
+              ("L0 ff.out 1280->320 +R1", N0, 320, 1280, 1, 0, None, 6, 1),
+              ("L0 geglu 320->2560", N0, 2560, 320, 1, 0, None, 5, 0),
+              ("L0 conv3x3 320->320", N0, 320, 320, 9, 1, (72, 128, 72, 128, 1, 0), 6, 0),
+              ("L1 conv3x3 1920->640", N1, 640, 1920, 9, 1, (36, 64, 36, 64, 1, 0), 6, 0),
+              ("L1 geglu 640->5120", N1, 5120, 640, 1, 0, None, 5, 0)]
+    names = ["total", "L:ds_read issue", "L:dma issue", "L:vmcnt wait", "L:lgkm+barrier", "C:mfma", "C:barrier",
+             "epilogue"]
+    for name, M, N, K, taps, mode, geo, tile, r1 in shapes:
+        A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+        W = (torch.randn(N, taps * K, generator=g, device=dev) / (taps * K) ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g, device=dev)
+        geglu = 1 if "geglu" in name else 0
+        out = torch.empty(M, N // 2 if geglu else N, dtype=torch.bfloat16, device=dev)
+        R1 = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if r1 else None
+        stamps = torch.zeros(256 * 8 * 10, dtype=torch.int64, device=dev)
+        d = _lib.GemmDesc()
+        d.A, d.W, d.out, d.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr()
+        d.R1 = R1.data_ptr() if r1 else None
+        d.V = stamps.data_ptr()           # stamp buffer: V is ignored by the epilogue when vmode == 0
+        d.M, d.N, d.Cin, d.taps, d.lda, d.mode = M, N, K, taps, K, mode
+        if geo:
+            d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = geo
+        d.ldo, d.n_store, d.ldr1, d.ldr2 = out.shape[1], out.shape[1], N, N
+        d.s_acc, d.s1, d.s2 = 1.0, 1.0, 0.0
+        d.geglu, d.tile = geglu, tile
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            rc = lib.ctrlv_gemm(ctypes.byref(d), st)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        s = stamps.view(-1, 10).double()
+        s = s[s[:, 8] > 0]
+        tot = s[:, 0].mean().item()
+        print(f"{name:28s} half-steps/wg {int(s[0, 8]):5d} tiles/wg {int(s[0, 9]):3d}  cycles/wave {tot:10.0f}")
+        for i in range(1, 8):
+            v = s[:, i].mean().item()
+            print(f"      {names[i]:18s} {v:10.0f}  {100 * v / tot:5.1f}%   per half-step {v / s[0, 8].item():7.0f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tiles", type=str, default="5,6,7,8")
+    ap.add_argument("--dbg", type=int, default=0, help="profiling aid bits: 2 skip stores, 4 skip DMA, 8 skip MFMA")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -52,7 +53,7 @@ def main():
         W = (torch.randn(N, taps * K, generator=g, device=DEV, dtype=torch.float32) / (taps * K) ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, generator=g, device=DEV, dtype=torch.float32)
         out = torch.empty(M, N // 2 if geglu else N, dtype=torch.bfloat16, device=DEV)
-        kw = dict(N=N, cin=K, taps=taps, mode=mode, bias=bias, geglu=geglu)
+        kw = dict(N=N, cin=K, taps=taps, mode=mode, bias=bias, geglu=geglu, _dbg=args.dbg)
         if mode == 1:
             kw["conv"] = geo
         if mode == 2:
