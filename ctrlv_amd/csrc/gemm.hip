@@ -224,7 +224,8 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   if (d.vmode) CTRLV_CHECK_ARG(d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv % 4 == 0 && (d.vmode == 1 || d.vS > 0), "ctrlv_gemm: bad row-vector table");
   if (d.geglu) {
     CTRLV_CHECK_SHAPE(d.N % 64 == 0, "ctrlv_gemm: GEGLU needs N %% 64 == 0");
-    CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !d.out_f32, "ctrlv_gemm: GEGLU epilogue takes bias only");
+    CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !(d.out_f32 & 1) && d.mode == 0,
+                    "ctrlv_gemm: GEGLU epilogue takes bias only (mode 0)");
   }
   int tile = d.tile;
   if (tile == 0) {
@@ -236,6 +237,15 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     else if (d.geglu) tile = 5;
     else if (d.N % 320 == 0 && d.N < 3840 && d.M >= 16384) tile = 6;
     else tile = 5;
+  }
+  if (tile >= 5) {
+    // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
+    const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&
+                         (!d.R2 || d.ldr2 % 8 == 0) && (!d.vmode || d.ldv % 8 == 0);
+    if (!wide_ok) {
+      CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8");
+      tile = 1;
+    }
   }
   switch (tile) {
     case 1: return launch<128, 128, 2, 2>(d, stream);

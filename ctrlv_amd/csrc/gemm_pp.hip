@@ -45,7 +45,167 @@ __device__ __forceinline__ void lds_done_barrier() {
 }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int BN, int WM, int WN, int MODE>
+// Epilogue through a per-wave LDS transpose.  In the MFMA result layout a lane owns one output ROW of a 32x32
+// sub-tile, so direct stores are 8 bytes per lane at a row stride: every store / residual-load instruction touches
+// 32 cache lines and the epilogue of a short-K tile cost more than its main loop (tools/gemm_stamp.py: 37 % of the
+// qkv GEMM, plus the same again waiting on the other wave group).  Here each 32x32 fp32 sub-tile goes through 4 KiB of
+// wave-private LDS (the four 1-KiB ring pieces of the just-consumed slot that only THIS wave's next DMA refills) and
+// comes back with 8 consecutive columns per lane: bias / residual / row-vector reads and the bf16 store are 16-32 B
+// per lane and row-contiguous (4x fewer cache lines per instruction, half the instructions).
+// Operands of one 32x32 sub-tile in the transposed (row-contiguous) layout: lane -> rows {lane>>2, 16 + lane>>2},
+// 8 columns (lane&3)*8.  Bias and the R1 residual are loaded one sub-tile AHEAD of their use (issued back-to-back,
+// consumed after the previous sub-tile's LDS round trip); R2 and the row-vector table (rarer, L2-resident) are issued
+// at the start of their own sub-tile, ahead of its LDS round trip.  (Stamps: an un-prefetched epilogue spent ~1800
+// cycles per sub-tile on two dependent load rounds.)
+struct EpiOperands {
+  float4 b0, b1;        // bias[ocol .. ocol+7]
+  uint4 r1[2];          // R1 rows (bf16 x 8) of the two passes
+};
+
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
+                                                  int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
+                                                  char* p2, char* p3) {
+  const int r32 = lane & 31, hsel = lane >> 5;
+  // staging image: row r (0..31) lives in piece r>>3 at (r&7)*128 B; 16-B chunk c of a row is stored at c ^ (r&7)
+  char* const wpiece = (r32 < 8) ? p0 : (r32 < 16) ? p1 : (r32 < 24) ? p2 : p3;
+  char* const wrow = wpiece + (r32 & 7) * 128;
+  const int rrow0 = lane >> 2;                       // row read in pass 0 (pass 1: +16)
+  const int rc = (lane & 3) * 2;                     // first of the two 16-B chunks this lane reads
+  const int row_a = rrow0, row_b = 16 + rrow0;
+  const char* const rp_a = (row_a < 8 ? p0 : p1) + (row_a & 7) * 128;
+  const char* const rp_b = (row_b < 24 ? p2 : p3) + (row_b & 7) * 128;
+  const int wbase_n = bn + wc * WTN;                 // first column of this wave's tile (weight-row order)
+  constexpr int NSUB = TM * TN;
+
+  auto sub_valid = [&](int s) {      // uniform: does sub-tile s produce output?
+    const int j = s % TN;
+    if (GEGLU && ((j & 1) || j + 1 >= TN)) return false;
+    return wbase_n + j * 32 < d.N;
+  };
+  auto out_col = [&](int j) { return (GEGLU ? ((wbase_n + j * 32) >> 1) : wbase_n + j * 32) + (lane & 3) * 8; };
+  auto load_ops = [&](int s, EpiOperands& o) {
+    if (GEGLU) return;
+    const int i = s / TN, j = s % TN;
+    const int ocol = out_col(j);
+    if (ocol >= d.n_store) return;
+    if (d.bias) { o.b0 = *(const float4*)(d.bias + ocol); o.b1 = *(const float4*)(d.bias + ocol + 4); }
+    if (d.R1) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int m = bm + wr * WTM + i * 32 + pass * 16 + rrow0;
+        if (m < d.M) o.r1[pass] = *(const uint4*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ocol);
+      }
+    }
+  };
+
+  EpiOperands cur, nxt;
+  {
+    int s_first = 0;
+    while (s_first < NSUB && !sub_valid(s_first)) ++s_first;
+    if (s_first < NSUB) load_ops(s_first, cur);
+  }
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    if (!sub_valid(s)) continue;
+    const int i = s / TN, j = s % TN;
+    {  // prefetch the operands of the next producing sub-tile
+      int sn = s + 1;
+      while (sn < NSUB && !sub_valid(sn)) ++sn;
+      if (sn < NSUB) load_ops(sn, nxt);
+    }
+    const int ocol = out_col(j);
+    // ---- stage through the wave-private LDS image (GEGLU: value * gelu(gate) computed in the MFMA layout first;
+    //      its bias is a per-column broadcast read straight from L1/L2, 2 x 16 B per quad)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o[4];
+      if (GEGLU) {
+        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+        if (d.bias) {
+          ba = *(const float4*)(d.bias + wbase_n + j * 32 + 8 * q + 4 * hsel);
+          bg = *(const float4*)(d.bias + wbase_n + j * 32 + 32 + 8 * q + 4 * hsel);
+        }
+        constexpr int jg = 1;    // GEGLU runs with TN == 2: value sub-tile 0, gate sub-tile 1
+        o[0] = (acc[i][0][4 * q] + ba.x) * gelu_erf_f(acc[i][jg][4 * q] + bg.x);
+        o[1] = (acc[i][0][4 * q + 1] + ba.y) * gelu_erf_f(acc[i][jg][4 * q + 1] + bg.y);
+        o[2] = (acc[i][0][4 * q + 2] + ba.z) * gelu_erf_f(acc[i][jg][4 * q + 2] + bg.z);
+        o[3] = (acc[i][0][4 * q + 3] + ba.w) * gelu_erf_f(acc[i][jg][4 * q + 3] + bg.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
+      }
+      const int c = (2 * q + hsel) ^ (r32 & 7);
+      *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass ? row_b : row_a;
+      const char* rp = pass ? rp_b : rp_a;
+      const float4 v0 = *(const float4*)(rp + ((rc ^ (row & 7)) * 16));
+      const float4 v1 = *(const float4*)(rp + (((rc + 1) ^ (row & 7)) * 16));
+      float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int m = bm + wr * WTM + i * 32 + row;
+      if (m < d.M && ocol < d.n_store) {
+        // R2 / row-vector operands (rarer, L2-resident tables): issued here, consumed after the bias / R1 math
+        uint4 r2v = make_uint4(0, 0, 0, 0);
+        float4 vv0 = make_float4(0.f, 0.f, 0.f, 0.f), vv1 = vv0;
+        if (!GEGLU) {
+          if (d.R2) r2v = *(const uint4*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ocol);
+          if (d.vmode) {
+            const long vi = d.vmode == 1 ? (long)((m / d.vdiv) % d.vmod)
+                                         : (((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod);
+            const float* vrow = d.V + vi * d.ldv + ocol;
+            vv0 = *(const float4*)vrow;
+            vv1 = *(const float4*)(vrow + 4);
+          }
+        }
+        if (!GEGLU) {
+          if (d.bias) {
+            o[0] += cur.b0.x; o[1] += cur.b0.y; o[2] += cur.b0.z; o[3] += cur.b0.w;
+            o[4] += cur.b1.x; o[5] += cur.b1.y; o[6] += cur.b1.z; o[7] += cur.b1.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= d.s_acc;
+          if (d.R1) {
+            float f[8];
+            unpack_bf16x8(cur.r1[pass], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
+          }
+          if (d.R2) {
+            float f[8];
+            unpack_bf16x8(r2v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
+          }
+          if (d.vmode) {
+            o[0] += vv0.x; o[1] += vv0.y; o[2] += vv0.z; o[3] += vv0.w;
+            o[4] += vv1.x; o[5] += vv1.y; o[6] += vv1.z; o[7] += vv1.w;
+          }
+          if (d.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
+          }
+        }
+        if (d.out_f32 & 2) {
+          asm volatile("" ::"v"(o[0]), "v"(o[7]));          // profiling aid: compute, do not store
+        } else if (d.out_f32 & 1) {
+          float* op = (float*)d.out + (long)m * d.ldo + ocol;
+          *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+          *(uint4*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pack_bf16x8(o);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the image
+    cur = nxt;
+  }
+}
+
+template <int BN, int WM, int WN, int MODE, bool GEGLU>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -296,13 +456,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         __builtin_amdgcn_sched_barrier(0);
       }
       STAMP(t4);
-      if (g + 1 < total) raw_barrier();                      // no barrier after the very last C phase (counts match)
+      // post-C barrier; after the block's very last C phase only group 0 executes one (it pairs with group 1's
+      // barrier before its last C phase) -- and it must come BEFORE group 0's epilogue, which reuses ring pieces
+      // that group 1 may still be reading in its last load phase
+      if (g + 1 < total || grp == 0) raw_barrier();
       STAMP(t5);
       STAMP_ADD(c_mfma, t3, t4);
       STAMP_ADD(c_cbar, t4, t5);
     }
     STAMP(t6);
-    gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
+    {
+      // wave-private staging: this wave's own four DMA pieces of the slot consumed last (refilled only by this
+      // wave's DMA of half-step g+3, which it issues in ITS next compute phase, after this epilogue)
+      char* s0 = smem + ((g - 1) & (NH - 1)) * SLOT;
+      gemm_epilogue_lds<TM, TN, GEGLU>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
+                                s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024);
+    }
     STAMP(t7);
     STAMP_ADD(c_epi, t6, t7);
   }
@@ -314,15 +483,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     o[6] = c_cbar; o[7] = c_epi; o[8] = (unsigned long long)total; o[9] = (unsigned long long)my_ntiles;
   }
 #endif
-  if (grp == 0) raw_barrier();                               // pairs with group 1's barrier before its last C phase
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE>
+template <int BN, int WM, int WN, int MODE, bool GEGLU = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   constexpr int smem = 4 * (256 + BN) * 64;
   static bool attr_set = false;
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU>;
   if (!attr_set) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -356,6 +524,7 @@ int launch_mode(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
 // workgroup per output tile instead of one persistent workgroup per CU.
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
   const bool persistent = tile <= 6;
+  if (d.geglu) return launch_one<256, 2, 4, 0, true>(d, persistent, stream);    // host checks: mode 0, 256-wide tile
   if (tile == 5 || tile == 7) return launch_mode<256, 2, 4>(d, persistent, stream);
   return launch_mode<320, 4, 2>(d, persistent, stream);
 }

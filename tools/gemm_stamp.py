@@ -26,6 +26,7 @@ def build():
 
 
 def main():
+    dbg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     build()
     from ctrlv_amd import _lib
     lib = ctypes.CDLL(OUT)
@@ -61,6 +62,7 @@ def main():
         d.ldo, d.n_store, d.ldr1, d.ldr2 = out.shape[1], out.shape[1], N, N
         d.s_acc, d.s1, d.s2 = 1.0, 1.0, 0.0
         d.geglu, d.tile = geglu, tile
+        d.out_f32 = dbg
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(2):
             rc = lib.ctrlv_gemm(ctypes.byref(d), st)
