@@ -19,8 +19,9 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
-// ping-pong schedule (gemm_pp.hip): tile 5 = 256x256, tile 6 = 256x320
+// ping-pong schedule (gemm_pp_kernel.h, gemm_pp_m*.hip): tile 5 = 256x256, tile 6 = 256x320 (7 / 8: non-persistent)
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
+bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);
 
 namespace {
 
@@ -242,8 +243,9 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
     const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&
                          (!d.R2 || d.ldr2 % 8 == 0) && (!d.vmode || d.ldv % 8 == 0);
-    if (!wide_ok) {
-      CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8");
+    if (!wide_ok || !ctrlv_gemm_pp_supports(d)) {
+      CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8 and an "
+                                     "epilogue of {bias, V, R1, R1+V, R1+R2} without SiLU / fp32 output");
       tile = 1;
     }
   }

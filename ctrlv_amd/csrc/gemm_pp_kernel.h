@@ -21,8 +21,8 @@
 //     prologue per tile.  Group 1 stays one barrier slot behind group 0 across tiles.
 // Tiles: BN = 256 (waves 2x4, wave tile 128x64) and BN = 320 (waves 4x2, wave tile 64x160) -- the latter makes
 // N = 320 / 640 / 960 / 1920 exact multiples (the C = 320 / 640 levels of the UNet).
+#pragma once
 #include "common.h"
-#include "gemm_epilogue.h"
 
 namespace {
 
@@ -62,7 +62,9 @@ struct EpiOperands {
   uint4 r1[2];          // R1 rows (bf16 x 8) of the two passes
 };
 
-template <int TM, int TN, bool GEGLU>
+// EPI: compile-time operand set of the epilogue -- bit 0: row-vector table V, bit 1: residual R1, bit 2: residual R2
+// (bias and s_acc are always honoured).  SiLU / fp32 output are served by the 128x128 kernel of gemm.hip only.
+template <int TM, int TN, bool GEGLU, int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     const int ocol = out_col(j);
     if (ocol >= d.n_store) return;
     if (d.bias) { o.b0 = *(const float4*)(d.bias + ocol); o.b1 = *(const float4*)(d.bias + ocol + 4); }
-    if (d.R1) {
+    if (EPI & 2) {
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const int m = bm + wr * WTM + i * 32 + pass * 16 + rrow0;
@@ -152,8 +154,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         uint4 r2v = make_uint4(0, 0, 0, 0);
         float4 vv0 = make_float4(0.f, 0.f, 0.f, 0.f), vv1 = vv0;
         if (!GEGLU) {
-          if (d.R2) r2v = *(const uint4*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ocol);
-          if (d.vmode) {
+          if (EPI & 4) r2v = *(const uint4*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ocol);
+          if (EPI & 1) {
             const long vi = d.vmode == 1 ? (long)((m / d.vdiv) % d.vmod)
                                          : (((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod);
             const float* vrow = d.V + vi * d.ldv + ocol;
@@ -168,33 +170,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] *= d.s_acc;
-          if (d.R1) {
+          if (EPI & 2) {
             float f[8];
             unpack_bf16x8(cur.r1[pass], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
           }
-          if (d.R2) {
+          if (EPI & 4) {
             float f[8];
             unpack_bf16x8(r2v, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
           }
-          if (d.vmode) {
+          if (EPI & 1) {
             o[0] += vv0.x; o[1] += vv0.y; o[2] += vv0.z; o[3] += vv0.w;
             o[4] += vv1.x; o[5] += vv1.y; o[6] += vv1.z; o[7] += vv1.w;
-          }
-          if (d.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
           }
         }
         if (d.out_f32 & 2) {
           asm volatile("" ::"v"(o[0]), "v"(o[7]));          // profiling aid: compute, do not store
-        } else if (d.out_f32 & 1) {
-          float* op = (float*)d.out + (long)m * d.ldo + ocol;
-          *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
-          *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
         } else {
           *(uint4*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pack_bf16x8(o);
         }
@@ -205,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
   }
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -400,8 +394,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
       }
       STAMP(t1);
-      // own DMA(g+1) must have landed; DMA(g+2) (issued in the previous C phase) may stay in flight
-      if (g + 2 < total) {
+      // DMA of half-step g+3: the A pieces are issued here (load phase), the B pieces in the gaps of the MFMA cluster
+      // below -- an LDS-DMA piece holds the issuing wave for 100-200 cycles (stamps), so the issue work is split
+      // between the two phases to balance them.  Then retire own DMA(g+1): pieces of g+2 and the A pieces just issued
+      // may stay in flight.
+      const bool do_issue = g + 3 < total;
+      if (do_issue) {
+        issue_begin(g + 3);
+#pragma unroll
+        for (int q = 0; q < A_Q; ++q) issue_a(q);
+        STAMP(t1b);
+        STAMP_ADD(c_lissue, t1, t1b);
+        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1 + A_Q>(); else wait_vmcnt<A_Q + B_Q + A_Q>();
+      } else if (g + 2 < total) {
         if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
       } else {
         wait_vmcnt<0>();
@@ -417,9 +422,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
       // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
-      const bool do_issue = g + 3 < total;
-      if (do_issue) issue_begin(g + 3);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int grpi = 0; grpi < 4; ++grpi) {
         constexpr int HM = TM / 2;
@@ -444,14 +446,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (do_issue) {
-          if (grpi == 0) issue_a(0);
-          if (grpi == 1) { if (A_Q > 1) issue_a(1); }
-          if (grpi == 2) issue_b(0);
-          if (grpi == 3) {
-            if (B_Q > 1) issue_b(1);
-            if (B_Q > 2) issue_b(2);
-            issue_end();
-          }
+          if (grpi == 0) issue_b(0);
+          if (grpi == 1) { if (B_Q > 1) issue_b(1); }
+          if (grpi == 2) { if (B_Q > 2) issue_b(2); }
+          if (grpi == 3) issue_end();
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -469,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (refilled only by this
       // wave's DMA of half-step g+3, which it issues in ITS next compute phase, after this epilogue)
       char* s0 = smem + ((g - 1) & (NH - 1)) * SLOT;
-      gemm_epilogue_lds<TM, TN, GEGLU>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024);
     }
     STAMP(t7);
@@ -486,11 +484,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   constexpr int smem = 4 * (256 + BN) * 64;
   static bool attr_set = false;
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI>;
   if (!attr_set) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -509,22 +507,30 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   return CTRLV_OK;
 }
 
-template <int BN, int WM, int WN>
-int launch_mode(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
-  switch (d.mode) {
-    case 0: return launch_one<BN, WM, WN, 0>(d, persistent, stream);
-    case 1: return launch_one<BN, WM, WN, 1>(d, persistent, stream);
-    default: return launch_one<BN, WM, WN, 2>(d, persistent, stream);
+// epilogue operand set of a descriptor (see EPI above); -1 if the ping-pong kernels do not serve it
+inline int pp_epi_of(const ctrlv_gemm_desc& d) {
+  if (d.act || (d.out_f32 & 1)) return -1;
+  const int e = (d.vmode ? 1 : 0) | (d.R1 ? 2 : 0) | (d.R2 ? 4 : 0);
+  if (e == 0 || e == 1 || e == 2 || e == 3 || e == 6) return e;
+  return -1;
+}
+
+template <int BN, int WM, int WN, int MODE>
+int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
+  switch (pp_epi_of(d)) {
+    case 0: return launch_one<BN, WM, WN, MODE, false, 0>(d, persistent, stream);
+    case 1: return launch_one<BN, WM, WN, MODE, false, 1>(d, persistent, stream);
+    case 2: return launch_one<BN, WM, WN, MODE, false, 2>(d, persistent, stream);
+    case 3:
+      if constexpr (MODE == 0) return launch_one<BN, WM, WN, MODE, false, 3>(d, persistent, stream);
+      break;
+    case 6:
+      if constexpr (MODE == 0) return launch_one<BN, WM, WN, MODE, false, 6>(d, persistent, stream);
+      break;
+    default: break;
   }
+  ctrlv_set_error("ctrlv_gemm: epilogue operand combination not served by the ping-pong kernels");
+  return CTRLV_E_BAD_ARG;
 }
 
 }  // namespace
-
-// tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
-// workgroup per output tile instead of one persistent workgroup per CU.
-int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
-  const bool persistent = tile <= 6;
-  if (d.geglu) return launch_one<256, 2, 4, 0, true>(d, persistent, stream);    // host checks: mode 0, 256-wide tile
-  if (tile == 5 || tile == 7) return launch_mode<256, 2, 4>(d, persistent, stream);
-  return launch_mode<320, 4, 2>(d, persistent, stream);
-}

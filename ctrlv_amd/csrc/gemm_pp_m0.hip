@@ -1,0 +1,24 @@
+// Ping-pong gather-GEMM instantiations: mode 0 (nn.Linear / 1x1 conv), incl. the GEGLU variant, and the dispatcher.
+#include "gemm_pp_kernel.h"
+
+int ctrlv_gemm_launch_pp_conv(const ctrlv_gemm_desc& d, int tile, bool persistent, hipStream_t stream);      // gemm_pp_m1.hip
+int ctrlv_gemm_launch_pp_temporal(const ctrlv_gemm_desc& d, int tile, bool persistent, hipStream_t stream);  // gemm_pp_m2.hip
+
+// does the ping-pong family serve this descriptor's epilogue? (gemm.hip falls back to the 128x128 kernel otherwise)
+bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
+  if (d.geglu) return d.mode == 0;
+  const int e = pp_epi_of(d);
+  if (e < 0) return false;
+  return d.mode == 0 || e <= 2;
+}
+
+// tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
+// workgroup per output tile instead of one persistent workgroup per CU.
+int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
+  const bool persistent = tile <= 6;
+  if (d.mode == 1) return ctrlv_gemm_launch_pp_conv(d, tile, persistent, stream);
+  if (d.mode == 2) return ctrlv_gemm_launch_pp_temporal(d, tile, persistent, stream);
+  if (d.geglu) return launch_one<256, 2, 4, 0, true, 0>(d, persistent, stream);
+  if (tile == 5 || tile == 7) return launch_epi<256, 2, 4, 0>(d, persistent, stream);
+  return launch_epi<320, 4, 2, 0>(d, persistent, stream);
+}

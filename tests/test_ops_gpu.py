@@ -48,6 +48,8 @@ def g(seed=0):
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
+    """Every epilogue operand combination the models use.  Tiles 1-4 (2-stage kernels) take any combination incl. SiLU
+    and fp32 output; the ping-pong tiles 5-8 serve {bias, V, R1, R1+V, R1+R2} (the rest is routed to tile 1)."""
     from ctrlv_amd import packing
     A = bf(torch.randn(M, K, generator=g(1)))
     Wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
@@ -56,21 +58,36 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
     R2 = bf(torch.randn(M, N, generator=g(5)))
     V = torch.randn(7, N, generator=g(6))
     Wp = packing.pack_linear(Wt)
-    ref = 0.7 * (A.float() @ Wp[:N].float().T + bias) + 0.5 * R1.float() - 0.25 * R2.float()
-    vidx = (torch.arange(M) // 13) % 7
-    ref = ref + V[vidx]
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm(A.to(DEV), Wp.to(DEV), out, N=N, cin=K, bias=bias.to(DEV), R1=R1.to(DEV), s1=0.5, R2=R2.to(DEV), s2=-0.25,
-             s_acc=0.7, V=V.to(DEV), vmode=1, vdiv=13, vmod=7, tile=tile)
-    assert rel_l2(out, ref) < 3e-3
-    # silu + fp32 output + quirk row-vector indexing (vmode 2)
-    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm(A.to(DEV), Wp.to(DEV), out32, N=N, cin=K, bias=bias.to(DEV), V=V.to(DEV), vmode=2, vdiv=50, vS=10, vmod=7,
-             act=1, out_f32=True, tile=tile)
+    lin = A.float() @ Wp[:N].float().T + bias
     m = torch.arange(M)
+    vidx = (m // 13) % 7
     vidx2 = ((m // 50) * 10 + (m % 10)) % 7
-    ref2 = F.silu(A.float() @ Wp[:N].float().T + bias + V[vidx2])
-    assert rel_l2(out32, ref2) < 1e-4
+    Ad, Wd, bd, R1d, R2d, Vd = (t.to(DEV) for t in (A, Wp, bias, R1, R2, V))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    # bias + scale + R1 + R2  (AlphaBlender-folded FF output)
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7, tile=tile)
+    assert rel_l2(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float()) < 3e-3
+    # bias + R1 + V (vmode 1), and the diffusers-0.27.2 context-order quirk map (vmode 2)
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, V=Vd, vmode=1, vdiv=13, vmod=7, tile=tile)
+    assert rel_l2(out, lin + R1.float() + V[vidx]) < 3e-3
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, V=Vd, vmode=2, vdiv=50, vS=10, vmod=7, tile=tile)
+    assert rel_l2(out, lin + R1.float() + V[vidx2]) < 3e-3
+    # bias + V only, bias only, nothing
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, V=Vd, vmode=1, vdiv=13, vmod=7, tile=tile)
+    assert rel_l2(out, lin + V[vidx]) < 3e-3
+    ops.gemm(Ad, Wd, out, N=N, cin=K, tile=tile)
+    assert rel_l2(out, lin - bias) < 3e-3
+    if tile <= 4:
+        # all operands at once, SiLU, fp32 output
+        ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7, V=Vd, vmode=1, vdiv=13,
+                 vmod=7, tile=tile)
+        assert rel_l2(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float() + V[vidx]) < 3e-3
+        out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(Ad, Wd, out32, N=N, cin=K, bias=bd, V=Vd, vmode=2, vdiv=50, vS=10, vmod=7, act=1, out_f32=True, tile=tile)
+        assert rel_l2(out32, F.silu(lin + V[vidx2])) < 1e-4
+    else:
+        with pytest.raises(ValueError):      # explicit ping-pong tile with an operand set it does not serve
+            ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
 
 
 @pytest.mark.parametrize("tile", [1, 2, 4, 5])
