@@ -224,7 +224,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   CTRLV_CHECK_ARG(d.vmode >= 0 && d.vmode <= 2, "ctrlv_gemm: bad vmode");
   if (d.vmode) CTRLV_CHECK_ARG(d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv % 4 == 0 && (d.vmode == 1 || d.vS > 0), "ctrlv_gemm: bad row-vector table");
   if (d.geglu) {
-    CTRLV_CHECK_SHAPE(d.N % 64 == 0, "ctrlv_gemm: GEGLU needs N %% 64 == 0");
+    CTRLV_CHECK_SHAPE(d.N % 32 == 0, "ctrlv_gemm: GEGLU needs N %% 32 == 0 (16 value + 16 gate columns per sub-tile)");
     CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !(d.out_f32 & 1) && d.mode == 0,
                     "ctrlv_gemm: GEGLU epilogue takes bias only (mode 0)");
   }
@@ -235,8 +235,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // 1280), 256x256 otherwise and for GEGLU (needs 64-column wave tiles); tiny-M per-clip GEMMs stay on 128x128.
     const bool big = d.M >= 1024 && d.N >= 128;
     if (!big) tile = 1;
-    else if (d.geglu) tile = 5;
-    else if (d.N % 320 == 0 && d.N < 3840 && d.M >= 16384) tile = 6;
+    else if (d.N % 320 == 0 && (d.N < 3840 || d.geglu) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
   if (tile >= 5) {
@@ -257,9 +256,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 5:
     case 7: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 6:
-    case 8:
-      CTRLV_CHECK_ARG(!d.geglu, "ctrlv_gemm: the 256x320 tile cannot pair GEGLU columns; use the 256x256 tile");
-      return ctrlv_gemm_launch_pp(d, tile, stream);
+    case 8: return ctrlv_gemm_launch_pp(d, tile, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

@@ -19,18 +19,19 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
       vrow = d.V + (long)(((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod) * d.ldv;
     }
     if (d.geglu) {
+      // weight rows are interleaved in 16-row (value, gate) blocks: quads 0,1 of a sub-tile are values, quads 2,3 gates
 #pragma unroll
-      for (int j = 0; j + 1 < TN; j += 2) {
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;  // "a" column in the interleaved weight order
+        for (int q = 0; q < 2; ++q) {
+          const int ncol = bn + wc * WTN + j * 32 + 8 * q + 4 * hsel;  // value column in the interleaved weight order
           if (ncol >= d.N) continue;
           const int ocol = ((bn + wc * WTN + j * 32) >> 1) + 8 * q + 4 * hsel;
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float a = acc[i][j][4 * q + e], g = acc[i][j + 1][4 * q + e];
-            if (d.bias) { a += d.bias[ncol + e]; g += d.bias[ncol + 32 + e]; }
+            float a = acc[i][j][4 * q + e], g = acc[i][j][4 * (q + 2) + e];
+            if (d.bias) { a += d.bias[ncol + e]; g += d.bias[ncol + 16 + e]; }
             o[e] = a * gelu_erf_f(g);
           }
           if (ocol < d.n_store) {

@@ -80,9 +80,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
   const int wbase_n = bn + wc * WTN;                 // first column of this wave's tile (weight-row order)
   constexpr int NSUB = TM * TN;
 
-  auto sub_valid = [&](int s) {      // uniform: does sub-tile s produce output?
+  // GEGLU: two adjacent sub-tiles (16 outputs each) share one staged 32-column image; the image is emitted at the
+  // even sub-tile of the pair (a lone last sub-tile fills only the left half).
+  auto sub_valid = [&](int s) {      // uniform: does sub-tile s emit an image?
     const int j = s % TN;
-    if (GEGLU && ((j & 1) || j + 1 >= TN)) return false;
+    if (GEGLU && (j & 1)) return false;
     return wbase_n + j * 32 < d.N;
   };
   auto out_col = [&](int j) { return (GEGLU ? ((wbase_n + j * 32) >> 1) : wbase_n + j * 32) + (lane & 3) * 8; };
@@ -117,28 +119,36 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       if (sn < NSUB) load_ops(sn, nxt);
     }
     const int ocol = out_col(j);
-    // ---- stage through the wave-private LDS image (GEGLU: value * gelu(gate) computed in the MFMA layout first;
-    //      its bias is a per-column broadcast read straight from L1/L2, 2 x 16 B per quad)
+    // ---- stage through the wave-private LDS image (GEGLU: value * gelu(gate) computed in the MFMA layout first --
+    //      quads 0,1 of a sub-tile are values, quads 2,3 their gates; its bias is a per-column broadcast from L1/L2)
+    if (GEGLU) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float o[4];
-      if (GEGLU) {
-        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-        if (d.bias) {
-          ba = *(const float4*)(d.bias + wbase_n + j * 32 + 8 * q + 4 * hsel);
-          bg = *(const float4*)(d.bias + wbase_n + j * 32 + 32 + 8 * q + 4 * hsel);
+      for (int half = 0; half < 2; ++half) {
+        const int js = j + half;
+        if (js >= TN || wbase_n + js * 32 >= d.N) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+          if (d.bias) {
+            ba = *(const float4*)(d.bias + wbase_n + js * 32 + 8 * q + 4 * hsel);
+            bg = *(const float4*)(d.bias + wbase_n + js * 32 + 16 + 8 * q + 4 * hsel);
+          }
+          float o[4];
+          o[0] = (acc[i][js < TN ? js : 0][4 * q] + ba.x) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2)] + bg.x);
+          o[1] = (acc[i][js < TN ? js : 0][4 * q + 1] + ba.y) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 1] + bg.y);
+          o[2] = (acc[i][js < TN ? js : 0][4 * q + 2] + ba.z) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 2] + bg.z);
+          o[3] = (acc[i][js < TN ? js : 0][4 * q + 3] + ba.w) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 3] + bg.w);
+          const int c = (half * 4 + 2 * q + hsel) ^ (r32 & 7);
+          *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        constexpr int jg = 1;    // GEGLU runs with TN == 2: value sub-tile 0, gate sub-tile 1
-        o[0] = (acc[i][0][4 * q] + ba.x) * gelu_erf_f(acc[i][jg][4 * q] + bg.x);
-        o[1] = (acc[i][0][4 * q + 1] + ba.y) * gelu_erf_f(acc[i][jg][4 * q + 1] + bg.y);
-        o[2] = (acc[i][0][4 * q + 2] + ba.z) * gelu_erf_f(acc[i][jg][4 * q + 2] + bg.z);
-        o[3] = (acc[i][0][4 * q + 3] + ba.w) * gelu_erf_f(acc[i][jg][4 * q + 3] + bg.w);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
       }
-      const int c = (2 * q + hsel) ^ (r32 & 7);
-      *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = (2 * q + hsel) ^ (r32 & 7);
+        *(float4*)(wrow + c * 16) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -149,7 +159,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       const float4 v1 = *(const float4*)(rp + (((rc + 1) ^ (row & 7)) * 16));
       float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       const int m = bm + wr * WTM + i * 32 + row;
-      if (m < d.M && ocol < d.n_store) {
+      const bool col_ok = !GEGLU || (lane & 3) < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N);
+      if (m < d.M && ocol < d.n_store && col_ok) {
         // R2 / row-vector operands (rarer, L2-resident tables): issued here, consumed after the bias / R1 math
         uint4 r2v = make_uint4(0, 0, 0, 0);
         float4 vv0 = make_float4(0.f, 0.f, 0.f, 0.f), vv1 = vv0;

@@ -18,7 +18,10 @@ int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream)
   const bool persistent = tile <= 6;
   if (d.mode == 1) return ctrlv_gemm_launch_pp_conv(d, tile, persistent, stream);
   if (d.mode == 2) return ctrlv_gemm_launch_pp_temporal(d, tile, persistent, stream);
-  if (d.geglu) return launch_one<256, 2, 4, 0, true, 0>(d, persistent, stream);
+  if (d.geglu) {
+    if (tile == 5 || tile == 7) return launch_one<256, 2, 4, 0, true, 0>(d, persistent, stream);
+    return launch_one<320, 4, 2, 0, true, 0>(d, persistent, stream);
+  }
   if (tile == 5 || tile == 7) return launch_epi<256, 2, 4, 0>(d, persistent, stream);
   return launch_epi<320, 4, 2, 0>(d, persistent, stream);
 }

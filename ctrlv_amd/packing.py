@@ -57,13 +57,19 @@ def pack_conv_in(weights, cp=16, kp=192):
     return _pad_cols(_pad_rows(w), kp).to(torch.bfloat16).contiguous()
 
 
+GEGLU_BLOCK = 16
+
+
 def geglu_interleave(t):
-    """Rows [a_0..a_{I-1} | g_0..g_{I-1}] -> 32-row blocks (a-block, gate-block) alternating (GEGLU epilogue layout)."""
+    """Rows [a_0..a_{I-1} | g_0..g_{I-1}] -> alternating 16-row blocks (value block, gate block): every 32-column MFMA
+    sub-tile of the GEMM then holds 16 values (accumulator quads 0,1) and their 16 gates (quads 2,3) in the same lane,
+    so the GEGLU product needs no cross-lane or cross-sub-tile traffic and works for any tile width."""
     inner = t.shape[0] // 2
-    assert inner % 32 == 0, "GEGLU inner dim must be a multiple of 32"
+    assert inner % GEGLU_BLOCK == 0, "GEGLU inner dim must be a multiple of 16"
     a, g = t[:inner], t[inner:]
     rest = t.shape[1:]
-    st = torch.stack([a.reshape(inner // 32, 32, *rest), g.reshape(inner // 32, 32, *rest)], 1)
+    st = torch.stack([a.reshape(inner // GEGLU_BLOCK, GEGLU_BLOCK, *rest),
+                      g.reshape(inner // GEGLU_BLOCK, GEGLU_BLOCK, *rest)], 1)
     return st.reshape(2 * inner, *rest)
 
 

@@ -38,7 +38,7 @@ def test_pack_geglu_interleave_matches_chunk_semantics():
     wp, bp = packing.pack_geglu(w, b)
     x = torch.randn(5, k)
     proj = x @ wp.float().T + bp
-    blocks = proj.reshape(5, inner // 32, 2, 32)
+    blocks = proj.reshape(5, inner // 16, 2, 16)
     a, gt = blocks[:, :, 0].reshape(5, inner), blocks[:, :, 1].reshape(5, inner)
     ref = x @ w.to(torch.bfloat16).float().T + b
     torch.testing.assert_close(a, ref[:, :inner], rtol=1e-4, atol=1e-4)

@@ -90,10 +90,10 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_geglu(ops, tile):
     from ctrlv_amd import packing
-    M, C = 333, 64
+    M, C = 333, 320       # 8C = 2560: 8 tiles of 320 / 10 of 256; the ragged 333 rows span two 256-row tiles
     A = bf(torch.randn(M, C, generator=g(1)))
     Wt = torch.randn(8 * C, C, generator=g(2)) / math.sqrt(C)
     b = torch.randn(8 * C, generator=g(3))

@@ -60,7 +60,7 @@ def main():
             kw["temporal"] = geo
         res = []
         for t in tiles:
-            if geglu and (N % 64 or t in (6, 8)):
+            if geglu and N % 32:
                 res.append(float("nan")); continue
             try:
                 ops.gemm(A, W, out, tile=t, **kw)
