@@ -7,9 +7,11 @@
 // V^T fragments come from a row-major V tile in LDS through ds_read_b64_tr_b16 (hardware transpose).
 // K/V tiles are staged by LDS-DMA (global_load_lds_dwordx4) with the bank-conflict swizzle on the source address.
 //
-//   spatial : 128 queries x 64-key tiles per workgroup (4 waves x 32 rows), 2-stage K/V ring, S up to 9216.
+//   spatial : 128 queries x 64-key tiles per workgroup (4 waves x 32 rows), 2- or 3-slot K/V ring, S up to 9216.
 //   temporal: one wave per (clip, pixel, head): 25 frames padded to one 32x32 tile; the (b f) s c <-> (b s) f c
 //             permutes of TemporalBasicTransformerBlock are row-stride arithmetic (stride S*3C between frames).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -54,9 +56,10 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 // ---------------------------------------------------------------------------------------------- spatial
 // launch_bounds(256, 2): a 256-register budget makes hipcc keep the score / output accumulators in arch VGPRs; with the
 // default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
+template <int NSLOT>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int S, int C) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 3 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
   constexpr float kDeferLog2 = 6.0f;   // T13: keep the running max while a tile's max exceeds it by < 2^6 (P <= 64)
   auto tile = [&](int t, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const char* kst = smem + (t & 1) * 16384;
+    const char* kst = smem + (t % NSLOT) * 16384;
     const char* vst = kst + 8192;
     f32x16 sacc[2];
 #pragma unroll
@@ -174,18 +177,23 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
     }
   };
 
+  // 3-slot K/V ring, two tiles of LDS-DMA in flight: every wave retires its own pieces of tile t with a COUNTED
+  // vmcnt (the 4 pieces of tile t+1 may stay outstanding), a raw s_barrier (no implicit vmcnt(0) drain) makes all
+  // waves' pieces visible and proves slot (t+2)%3 == (t-1)%3 is no longer being read, then tile t+2 is issued.
   const int nt = (S + 63) / 64;
   const int nt_full = S / 64;
   issue(0, 0);
+  if (NSLOT == 3 && nt > 1) issue(1, 1);
   for (int t = 0; t < nt_full; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    if (NSLOT == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + NSLOT - 1 < nt) issue(t + NSLOT - 1, (t + NSLOT - 1) % NSLOT);
     tile(t, std::false_type{});
   }
-  if (nt_full < nt) {
+  if (nt_full < nt) {      // ragged last tile: separate instantiation with key masking
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_barrier" ::: "memory");
     tile(nt_full, std::true_type{});
   }
 
@@ -308,8 +316,19 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
   CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
   dim3 grid((S + 127) / 128, C / 64, n_img);
-  hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                     (bf16_t*)out, S, C);
+  // K/V ring depth: 2 slots (32 KiB LDS, 4 waves/SIMD) measured 883 TFLOP/s at S = 9216 against 810 for 3 slots (two
+  // tiles of LDS-DMA in flight but 3 waves/SIMD): occupancy beats prefetch depth for this VALU-heavy d = 64 kernel.
+  static int nslot = 0;
+  if (nslot == 0) {
+    const char* e = getenv("CTRLV_ATTN_SLOTS");
+    nslot = (e && e[0] == '3') ? 3 : 2;
+  }
+  if (nslot == 3)
+    hipLaunchKernelGGL((attn_spatial_kernel<3>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)out, S, C);
+  else
+    hipLaunchKernelGGL((attn_spatial_kernel<2>), grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)out, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
