@@ -245,19 +245,38 @@ def main():
     if rank != 0:
         return
     fams = timer.summary() if timer is not None else {}
+    # HBM traffic per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections
+    # applied by tools/pmc_summary.py) committed under profiles/; null when no summary is present
+    pmc = {}
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_summary.json")))
+        if cands and args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25):
+            raw = json.load(open(cands[-1]))
+            alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
+                     "groupnorm": ["gn_stats_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
+                     "residual_add": ["axpby_kernel"], "gemm_linear": ["gemm_linear"],
+                     "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"]}
+            for fam, keys in alias.items():
+                if all(k in raw for k in keys):
+                    pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
+            pmc["_source"] = os.path.relpath(cands[-1], ROOT)
+    except Exception as ex:       # noqa: BLE001
+        log(f"no PMC traffic summary: {ex}")
     rooflines = {}
     for fam, d in fams.items():
         sec = d["ms"] * 1e-3
         if d["flops"] > 0 and fam.startswith(("gemm", "attention_spatial")):
             ach = d["flops"] / sec / 1e12
             rooflines[fam] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_BF16_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                              "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
+                              "traffic": pmc.get(fam),
                               "ms_per_step": round(d["ms"], 3), "launches": d["calls"],
                               "avg_launch_ms": round(d["ms"] / d["calls"], 4)}
         else:
             ach = d["bytes"] / sec / 1e9
             rooflines[fam] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc.get(fam),
                               "ms_per_step": round(d["ms"], 3), "launches": d["calls"],
                               "avg_launch_ms": round(d["ms"] / d["calls"], 4)}
     dominant = max(rooflines, key=lambda f: rooflines[f]["ms_per_step"]) if rooflines else None
@@ -281,6 +300,7 @@ def main():
         "kernel_ms_per_step": round(sum(d["ms"] for d in fams.values()), 2),
         "finite": finite,
         "roofline": roofline, "rooflines": rooflines,
+        "traffic_source": pmc.get("_source"),
     }
     if world == 1 and not args.no_cpu_baseline:
         del st, unet, ctrl
