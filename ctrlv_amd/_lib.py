@@ -61,11 +61,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CTRLV_HIP_LIB", LIB_PATH)      # developer override: A/B builds of the same ABI (tools/)
+    if not os.path.exists(path):
         raise CtrlvHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  ctrlv_amd has no CPU / eager fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header / library out of sync
         fn.restype, fn.argtypes = res, args

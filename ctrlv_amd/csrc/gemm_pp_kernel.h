@@ -218,9 +218,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int A_SLOT = BM * 64, B_SLOT = BN * 64, SLOT = A_SLOT + B_SLOT;
   constexpr int A_TOT = BM / 16, B_TOT = BN / 16;            // 1-KiB DMA pieces (16 rows x 64 B) per half-step
+  // B pieces issued in the LOAD phase next to the A pieces (the rest go into the MFMA gaps); must stay below B_Q so
+  // that the ragged last piece of the 320-wide tile is always issued in the compute phase.  A/B on one device
+  // (tools/ab_build.py): 1 is +8-12 % on the 256-wide tile (16 MFMAs per phase), 0 is best on the 320-wide one (20).
+#ifdef CTRLV_PP_BL
+  constexpr int BL = CTRLV_PP_BL;
+#else
+  constexpr int BL = BN == 256 ? 1 : 0;
+#endif
   constexpr int A_Q = A_TOT / NW;                            // per wave (2)
   constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave upper bound (2 or 3)
   static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
+  static_assert(BL >= 0 && BL < B_Q, "CTRLV_PP_BL must be smaller than the B pieces per wave");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -414,9 +423,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         issue_begin(g + 3);
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) issue_a(q);
+#pragma unroll
+        for (int q = 0; q < BL; ++q) issue_b(q);          // every wave owns B pieces 0 .. B_Q-2 (only the last is ragged)
         STAMP(t1b);
         STAMP_ADD(c_lissue, t1, t1b);
-        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1 + A_Q>(); else wait_vmcnt<A_Q + B_Q + A_Q>();
+        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1 + A_Q + BL>(); else wait_vmcnt<A_Q + B_Q + A_Q + BL>();
       } else if (g + 2 < total) {
         if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
       } else {
@@ -457,9 +468,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (do_issue) {
-          if (grpi == 0) issue_b(0);
-          if (grpi == 1) { if (B_Q > 1) issue_b(1); }
-          if (grpi == 2) { if (B_Q > 2) issue_b(2); }
+          if (grpi == 0) { if (BL < 1) issue_b(0); }
+          if (grpi == 1) { if (BL < 2 && B_Q > 1) issue_b(1); }
+          if (grpi == 2) { if (BL < 3 && B_Q > 2) issue_b(2); }
           if (grpi == 3) issue_end();
         }
         __builtin_amdgcn_sched_barrier(0);
