@@ -47,166 +47,224 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "me
 
 // Epilogue through a per-wave LDS transpose.  In the MFMA result layout a lane owns one output ROW of a 32x32
 // sub-tile, so direct stores are 8 bytes per lane at a row stride: every store / residual-load instruction touches
-// 32 cache lines and the epilogue of a short-K tile cost more than its main loop (tools/gemm_stamp.py: 37 % of the
-// qkv GEMM, plus the same again waiting on the other wave group).  Here each 32x32 fp32 sub-tile goes through 4 KiB of
-// wave-private LDS (the four 1-KiB ring pieces of the just-consumed slot that only THIS wave's next DMA refills) and
-// comes back with 8 consecutive columns per lane: bias / residual / row-vector reads and the bf16 store are 16-32 B
-// per lane and row-contiguous (4x fewer cache lines per instruction, half the instructions).
-// Operands of one 32x32 sub-tile in the transposed (row-contiguous) layout: lane -> rows {lane>>2, 16 + lane>>2},
-// 8 columns (lane&3)*8.  Bias and the R1 residual are loaded one sub-tile AHEAD of their use (issued back-to-back,
-// consumed after the previous sub-tile's LDS round trip); R2 and the row-vector table (rarer, L2-resident) are issued
-// at the start of their own sub-tile, ahead of its LDS round trip.  (Stamps: an un-prefetched epilogue spent ~1800
-// cycles per sub-tile on two dependent load rounds.)
-struct EpiOperands {
-  float4 b0, b1;        // bias[ocol .. ocol+7]
-  uint4 r1[2];          // R1 rows (bf16 x 8) of the two passes
-};
+// 32 cache lines and the epilogue of a short-K tile cost more than its main loop (tools/gemm_stamp.py).  Here each
+// 32x32 fp32 sub-tile goes through 4 KiB of wave-private LDS (the four 1-KiB ring pieces of the just-consumed slot that
+// only THIS wave's next DMA refills) and comes back with 8 consecutive columns per lane: bias / residual / row-vector
+// reads and the bf16 store are 16-32 B per lane and row-contiguous.
+//
+// The whole epilogue is STRAIGHT-LINE code: every global access is a buffer_load / buffer_store whose per-lane offset
+// is forced out of range for rows >= M and columns >= n_store (the hardware range check drops the store / returns
+// zeros), so there is no divergent control flow.  That matters because on gfx9 `vmcnt` counts loads AND stores in
+// order: with exec-masked branches around the stores the compiler could only wait `vmcnt(0)` for a prefetched
+// operand, i.e. for the write acknowledgement of the previous sub-tile's stores (~1300 cycles per sub-tile in the
+// stamps).  Branch-free, its counted waits let stores drain in the background while operands for sub-tile s+PF are
+// loaded PF sub-tiles ahead.  LDS accesses of one wave execute in order, so the staging write -> read -> next write
+// sequence needs no explicit waits either.
+// EPI: compile-time operand set -- bit 0: row-vector table V, bit 1: residual R1, bit 2: residual R2 (bias and s_acc
+// are always honoured).  SiLU / fp32 output are served by the 128x128 kernel of gemm.hip only.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-// EPI: compile-time operand set of the epilogue -- bit 0: row-vector table V, bit 1: residual R1, bit 2: residual R2
-// (bias and s_acc are always honoured).  SiLU / fp32 output are served by the 128x128 kernel of gemm.hip only.
+// rows of the row-vector table V that rows [0, M) can address (vmod may be "no modulus" = 1 << 30)
+__host__ __device__ inline long pp_vtable_rows(const ctrlv_gemm_desc& d) {
+  const long groups = (long)(d.M - 1) / d.vdiv + 1;
+  const long reach = d.vmode == 1 ? groups : groups * d.vS;
+  return reach < d.vmod ? reach : (long)d.vmod;
+}
+
 template <int TM, int TN, bool GEGLU, int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3) {
-  const int r32 = lane & 31, hsel = lane >> 5;
+  constexpr unsigned kOOB = 0xFFFFFFFFu;
+  constexpr int kFlags = 0x00020000;
+  const int r32 = lane & 31, hsel = lane >> 5, l4 = lane & 3;
   // staging image: row r (0..31) lives in piece r>>3 at (r&7)*128 B; 16-B chunk c of a row is stored at c ^ (r&7)
   char* const wpiece = (r32 < 8) ? p0 : (r32 < 16) ? p1 : (r32 < 24) ? p2 : p3;
   char* const wrow = wpiece + (r32 & 7) * 128;
-  const int rrow0 = lane >> 2;                       // row read in pass 0 (pass 1: +16)
-  const int rc = (lane & 3) * 2;                     // first of the two 16-B chunks this lane reads
-  const int row_a = rrow0, row_b = 16 + rrow0;
+  const int row_a = lane >> 2, row_b = 16 + row_a;   // rows read back in pass 0 / pass 1 (same r&7)
   const char* const rp_a = (row_a < 8 ? p0 : p1) + (row_a & 7) * 128;
   const char* const rp_b = (row_b < 24 ? p2 : p3) + (row_b & 7) * 128;
+  const int rx0 = ((l4 * 2) ^ (row_a & 7)) * 16, rx1 = ((l4 * 2 + 1) ^ (row_a & 7)) * 16;
   const int wbase_n = bn + wc * WTN;                 // first column of this wave's tile (weight-row order)
+  const int m0 = bm + wr * WTM + row_a;              // + i*32 + pass*16
   constexpr int NSUB = TM * TN;
 
-  // GEGLU: two adjacent sub-tiles (16 outputs each) share one staged 32-column image; the image is emitted at the
-  // even sub-tile of the pair (a lone last sub-tile fills only the left half).
-  auto sub_valid = [&](int s) {      // uniform: does sub-tile s emit an image?
-    const int j = s % TN;
-    if (GEGLU && (j & 1)) return false;
-    return wbase_n + j * 32 < d.N;
-  };
-  auto out_col = [&](int j) { return (GEGLU ? ((wbase_n + j * 32) >> 1) : wbase_n + j * 32) + (lane & 3) * 8; };
-  auto load_ops = [&](int s, EpiOperands& o) {
-    if (GEGLU) return;
-    const int i = s / TN, j = s % TN;
-    const int ocol = out_col(j);
-    if (ocol >= d.n_store) return;
-    if (d.bias) { o.b0 = *(const float4*)(d.bias + ocol); o.b1 = *(const float4*)(d.bias + ocol + 4); }
-    if (EPI & 2) {
+  const __amdgpu_buffer_rsrc_t rsO =
+      __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)((long)d.M * d.ldo * 2), kFlags);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(d.bias ? (const void*)d.bias : d.W), 0, d.bias ? d.N * 4 : 0, kFlags);   // no bias: every load reads 0
+  const __amdgpu_buffer_rsrc_t rsR1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((EPI & 2) ? d.R1 : d.W), 0, (EPI & 2) ? (int)((long)d.M * d.ldr1 * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsR2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((EPI & 4) ? d.R2 : d.W), 0, (EPI & 4) ? (int)((long)d.M * d.ldr2 * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((EPI & 1) ? (const void*)d.V : d.W), 0, (EPI & 1) ? (int)(pp_vtable_rows(d) * d.ldv * 4) : 0, kFlags);
+
+  // byte offset of the row-vector table row of (i, pass): two integer divisions per row, hoisted out of the sub-tiles
+  unsigned v_row[TM][2];
+  if (EPI & 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        const int m = bm + wr * WTM + i * 32 + pass * 16 + rrow0;
-        if (m < d.M) o.r1[pass] = *(const uint4*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ocol);
+        const int m = m0 + i * 32 + pass * 16;
+        const int mc = m < d.M ? m : 0;
+        const unsigned vi = d.vmode == 1 ? (unsigned)((mc / d.vdiv) % d.vmod)
+                                         : (unsigned)((((long)(mc / d.vdiv) * d.vS + (mc % d.vS)) % d.vmod));
+        v_row[i][pass] = vi * (unsigned)(d.ldv * 4);
       }
-    }
-  };
-
-  EpiOperands cur, nxt;
-  {
-    int s_first = 0;
-    while (s_first < NSUB && !sub_valid(s_first)) ++s_first;
-    if (s_first < NSUB) load_ops(s_first, cur);
   }
+
+  if constexpr (!GEGLU) {
+    struct Ops { u32x4_t b0, b1, r1[2], r2[2]; };
+    // operand prefetch distance in sub-tiles, bounded by the register budget of the 320-wide tile (252+ VGPRs)
+    constexpr int PF = (TN > 2 && (EPI == 3 || EPI == 6)) ? 0 : ((EPI & 4) || (TN > 2 && (EPI & 2))) ? 1 : 2;
+    Ops q[PF + 1];
+    const int ocol0 = wbase_n + l4 * 8;
+    auto load_ops = [&](int s, Ops& o) {
+      const int i = s / TN, j = s % TN;
+      const int ocol = ocol0 + j * 32;
+      o.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, ocol * 4, 0, 0);
+      o.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, ocol * 4 + 16, 0, 0);
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) {
-    if (!sub_valid(s)) continue;
-    const int i = s / TN, j = s % TN;
-    {  // prefetch the operands of the next producing sub-tile
-      int sn = s + 1;
-      while (sn < NSUB && !sub_valid(sn)) ++sn;
-      if (sn < NSUB) load_ops(sn, nxt);
-    }
-    const int ocol = out_col(j);
-    // ---- stage through the wave-private LDS image (GEGLU: value * gelu(gate) computed in the MFMA layout first --
-    //      quads 0,1 of a sub-tile are values, quads 2,3 their gates; its bias is a per-column broadcast from L1/L2)
-    if (GEGLU) {
+      for (int pass = 0; pass < 2; ++pass) {
+        const int m = m0 + i * 32 + pass * 16;
+        const bool ok = m < d.M && ocol < d.n_store;
+        if (EPI & 2)
+          o.r1[pass] = __builtin_amdgcn_raw_buffer_load_b128(
+              rsR1, ok ? (unsigned)m * (unsigned)(d.ldr1 * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+        if (EPI & 4)
+          o.r2[pass] = __builtin_amdgcn_raw_buffer_load_b128(
+              rsR2, ok ? (unsigned)m * (unsigned)(d.ldr2 * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+      }
+    };
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int js = j + half;
-        if (js >= TN || wbase_n + js * 32 >= d.N) continue;
+    for (int s = 0; s < PF && s < NSUB; ++s) load_ops(s, q[s % (PF + 1)]);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-          if (d.bias) {
-            ba = *(const float4*)(d.bias + wbase_n + js * 32 + 8 * q + 4 * hsel);
-            bg = *(const float4*)(d.bias + wbase_n + js * 32 + 16 + 8 * q + 4 * hsel);
-          }
-          float o[4];
-          o[0] = (acc[i][js < TN ? js : 0][4 * q] + ba.x) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2)] + bg.x);
-          o[1] = (acc[i][js < TN ? js : 0][4 * q + 1] + ba.y) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 1] + bg.y);
-          o[2] = (acc[i][js < TN ? js : 0][4 * q + 2] + ba.z) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 2] + bg.z);
-          o[3] = (acc[i][js < TN ? js : 0][4 * q + 3] + ba.w) * gelu_erf_f(acc[i][js < TN ? js : 0][4 * (q + 2) + 3] + bg.w);
-          const int c = (half * 4 + 2 * q + hsel) ^ (r32 & 7);
-          *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int s = 0; s < NSUB; ++s) {
+      const int i = s / TN, j = s % TN;
+      if (s + PF < NSUB) load_ops(s + PF, q[(s + PF) % (PF + 1)]);
+      const Ops& cur = q[s % (PF + 1)];
+      const int ocol = ocol0 + j * 32;
+      // row-vector operands (L2-resident tables): issued ahead of this sub-tile's LDS round trip
+      u32x4_t vv[2][2] = {};
+      if (EPI & 1) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const bool okv = m0 + i * 32 + pass * 16 < d.M && ocol < d.n_store;
+          vv[pass][0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, okv ? v_row[i][pass] + (unsigned)(ocol * 4) : kOOB, 0, 0);
+          vv[pass][1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, okv ? v_row[i][pass] + (unsigned)(ocol * 4 + 16) : kOOB, 0, 0);
         }
       }
-    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = (2 * q + hsel) ^ (r32 & 7);
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c = (2 * qd + hsel) ^ (r32 & 7);
         *(float4*)(wrow + c * 16) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();     // compiler-only: the image is exchanged between lanes of this wave
+      float4 img[2][2];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const char* rp = pass ? rp_b : rp_a;
+        img[pass][0] = *(const float4*)(rp + rx0);
+        img[pass][1] = *(const float4*)(rp + rx1);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const float4 v0 = img[pass][0], v1 = img[pass][1];
+        float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const int m = m0 + i * 32 + pass * 16;
+        const bool ok = m < d.M && ocol < d.n_store;
+        const u32x4_t vv0 = vv[pass][0], vv1 = vv[pass][1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (o[e] + __uint_as_float(cur.b0[e])) * d.s_acc;
+          o[4 + e] = (o[4 + e] + __uint_as_float(cur.b1[e])) * d.s_acc;
+        }
+        if (EPI & 2) {
+          float f[8];
+          unpack_bf16x8(make_uint4(cur.r1[pass].x, cur.r1[pass].y, cur.r1[pass].z, cur.r1[pass].w), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
+        }
+        if (EPI & 4) {
+          float f[8];
+          unpack_bf16x8(make_uint4(cur.r2[pass].x, cur.r2[pass].y, cur.r2[pass].z, cur.r2[pass].w), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
+        }
+        if (EPI & 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] += __uint_as_float(vv0[e]);
+            o[4 + e] += __uint_as_float(vv1[e]);
+          }
+        }
+        const uint4 pk = pack_bf16x8(o);
+        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+        __builtin_amdgcn_raw_buffer_store_b128(
+            pv, rsO, ok ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    // GEGLU: weight rows come in 16-row (value, gate) blocks, so quads 0,1 of a 32x32 sub-tile are 16 values and
+    // quads 2,3 their gates, in the same lane: out = (a + ba) * gelu(g + bg) is computed in the MFMA layout (its bias
+    // is a per-column broadcast, L2-resident) and two adjacent sub-tiles (16 outputs each) share one staged 32-column
+    // image; a lone last sub-tile fills only the left half.
+    constexpr int NP = (TN + 1) / 2;
+    const int gcol0 = wbase_n + 4 * hsel;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass ? row_b : row_a;
-      const char* rp = pass ? rp_b : rp_a;
-      const float4 v0 = *(const float4*)(rp + ((rc ^ (row & 7)) * 16));
-      const float4 v1 = *(const float4*)(rp + (((rc + 1) ^ (row & 7)) * 16));
-      float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const int m = bm + wr * WTM + i * 32 + row;
-      const bool col_ok = !GEGLU || (lane & 3) < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N);
-      if (m < d.M && ocol < d.n_store && col_ok) {
-        // R2 / row-vector operands (rarer, L2-resident tables): issued here, consumed after the bias / R1 math
-        uint4 r2v = make_uint4(0, 0, 0, 0);
-        float4 vv0 = make_float4(0.f, 0.f, 0.f, 0.f), vv1 = vv0;
-        if (!GEGLU) {
-          if (EPI & 4) r2v = *(const uint4*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ocol);
-          if (EPI & 1) {
-            const long vi = d.vmode == 1 ? (long)((m / d.vdiv) % d.vmod)
-                                         : (((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod);
-            const float* vrow = d.V + vi * d.ldv + ocol;
-            vv0 = *(const float4*)vrow;
-            vv1 = *(const float4*)(vrow + 4);
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const int j = jp * 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int js = j + half;
+          if (js >= TN) continue;                          // compile time
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) {
+            const int n = gcol0 + js * 32 + 8 * qd;
+            const u32x4_t ba = __builtin_amdgcn_raw_buffer_load_b128(rsB, n * 4, 0, 0);
+            const u32x4_t bg = __builtin_amdgcn_raw_buffer_load_b128(rsB, (n + 16) * 4, 0, 0);
+            const f32x4_t g = {acc[i][js][4 * (qd + 2)] + __uint_as_float(bg[0]),
+                               acc[i][js][4 * (qd + 2) + 1] + __uint_as_float(bg[1]),
+                               acc[i][js][4 * (qd + 2) + 2] + __uint_as_float(bg[2]),
+                               acc[i][js][4 * (qd + 2) + 3] + __uint_as_float(bg[3])};
+            const f32x4_t a = {acc[i][js][4 * qd] + __uint_as_float(ba[0]), acc[i][js][4 * qd + 1] + __uint_as_float(ba[1]),
+                               acc[i][js][4 * qd + 2] + __uint_as_float(ba[2]),
+                               acc[i][js][4 * qd + 3] + __uint_as_float(ba[3])};
+            const f32x4_t o = a * gelu_erf4(g);
+            const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
+            *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
           }
         }
-        if (!GEGLU) {
-          if (d.bias) {
-            o[0] += cur.b0.x; o[1] += cur.b0.y; o[2] += cur.b0.z; o[3] += cur.b0.w;
-            o[4] += cur.b1.x; o[5] += cur.b1.y; o[6] += cur.b1.z; o[7] += cur.b1.w;
-          }
+        const int ocol = ((wbase_n + j * 32) >> 1) + l4 * 8;
+        // columns of the right half exist only if sub-tile j+1 does (inside the wave tile and inside N)
+        const bool col_ok = ocol < d.n_store && (l4 < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N));
+        __builtin_amdgcn_wave_barrier();   // compiler-only: the image is exchanged between lanes of this wave
+        float4 img[2][2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] *= d.s_acc;
-          if (EPI & 2) {
-            float f[8];
-            unpack_bf16x8(cur.r1[pass], f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
-          }
-          if (EPI & 4) {
-            float f[8];
-            unpack_bf16x8(r2v, f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
-          }
-          if (EPI & 1) {
-            o[0] += vv0.x; o[1] += vv0.y; o[2] += vv0.z; o[3] += vv0.w;
-            o[4] += vv1.x; o[5] += vv1.y; o[6] += vv1.z; o[7] += vv1.w;
-          }
+        for (int pass = 0; pass < 2; ++pass) {
+          const char* rp = pass ? rp_b : rp_a;
+          img[pass][0] = *(const float4*)(rp + rx0);
+          img[pass][1] = *(const float4*)(rp + rx1);
         }
-        if (d.out_f32 & 2) {
-          asm volatile("" ::"v"(o[0]), "v"(o[7]));          // profiling aid: compute, do not store
-        } else {
-          *(uint4*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pack_bf16x8(o);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const float4 v0 = img[pass][0], v1 = img[pass][1];
+          const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const int m = m0 + i * 32 + pass * 16;
+          const uint4 pk = pack_bf16x8(o);
+          const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+          __builtin_amdgcn_raw_buffer_store_b128(
+              pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the image
-    cur = nxt;
   }
 }
 
@@ -476,14 +534,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         __builtin_amdgcn_sched_barrier(0);
       }
       STAMP(t4);
-      // post-C barrier; after the block's very last C phase only group 0 executes one (it pairs with group 1's
-      // barrier before its last C phase) -- and it must come BEFORE group 0's epilogue, which reuses ring pieces
-      // that group 1 may still be reading in its last load phase
-      if (g + 1 < total || grp == 0) raw_barrier();
+      // post-C barrier (pairs with the other group's post-L barrier)
+      raw_barrier();
       STAMP(t5);
       STAMP_ADD(c_mfma, t3, t4);
       STAMP_ADD(c_cbar, t4, t5);
     }
+    // Tile boundary.  Group 0 takes one EXTRA barrier before its epilogue (it pairs with group 1's last post-C
+    // barrier) and group 1 one after its epilogue (pairing with group 0's first post-L barrier of the next tile), so
+    // that the two epilogues run CONCURRENTLY instead of each group stalling at a barrier for the whole epilogue of
+    // the other (stamps: "C:barrier" was 1.3-2.5x the epilogue itself on the K = 320 layers).  The extra barrier also
+    // orders group 0's staging writes after group 1's last load phase, which still reads those ring pieces.
+    if (grp == 0) raw_barrier();
     STAMP(t6);
     {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (refilled only by this
@@ -494,6 +556,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     }
     STAMP(t7);
     STAMP_ADD(c_epi, t6, t7);
+    if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
   }
 #ifdef CTRLV_PP_STAMP
   STAMP(t_end);

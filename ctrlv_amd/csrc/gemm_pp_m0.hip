@@ -6,6 +6,12 @@ int ctrlv_gemm_launch_pp_temporal(const ctrlv_gemm_desc& d, int tile, bool persi
 
 // does the ping-pong family serve this descriptor's epilogue? (gemm.hip falls back to the 128x128 kernel otherwise)
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
+  // the epilogue addresses out / R1 / R2 / V through buffer descriptors: 32-bit byte offsets
+  const long lim = 0xFFFFFFF0L;
+  if ((long)d.M * d.ldo * 2 > lim) return false;
+  if (d.R1 && (long)d.M * d.ldr1 * 2 > lim) return false;
+  if (d.R2 && (long)d.M * d.ldr2 * 2 > lim) return false;
+  if (d.vmode && pp_vtable_rows(d) * d.ldv * 4 > lim) return false;
   if (d.geglu) return d.mode == 0;
   const int e = pp_epi_of(d);
   if (e < 0) return false;

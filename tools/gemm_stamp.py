@@ -15,13 +15,17 @@ OUT = os.path.join(ROOT, "gpurun_out", "libctrlv_stamp.so")
 
 
 def build():
+    import __graft_entry__ as ge
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    objs = []
-    for s in ("gemm.hip", "gemm_pp.hip"):
+    objs, procs = [], []
+    for s in ge.HIP_SOURCES:
+        if not s.startswith("gemm"):
+            continue
         o = os.path.join(ROOT, "gpurun_out", s + ".stamp.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                               "-DCTRLV_PP_STAMP", "-c", os.path.join(CSRC, s), "-o", o])
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                                       "-DCTRLV_PP_STAMP", "-c", os.path.join(CSRC, s), "-o", o]))
         objs.append(o)
+    assert all(p.wait() == 0 for p in procs)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
 
 

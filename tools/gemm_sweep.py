@@ -44,11 +44,15 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tiles", type=str, default="5,6,7,8")
     ap.add_argument("--dbg", type=int, default=0, help="profiling aid bits: 2 skip stores, 4 skip DMA, 8 skip MFMA")
+    ap.add_argument("--epi", type=int, default=0, help="epilogue operands: bit 0 row-vector table, bit 1 R1, bit 2 R2")
+    ap.add_argument("--only", type=str, default="", help="substring filter on the shape name")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     g = torch.Generator(device=DEV).manual_seed(0)
     print(f"{'shape':34s} " + " ".join(f"tile{t:>2d}" for t in tiles) + "   (TFLOP/s)")
     for name, M, N, K, taps, mode, geo, geglu in SHAPES:
+        if args.only and args.only not in name:
+            continue
         A = torch.randn(M, K, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
         W = (torch.randn(N, taps * K, generator=g, device=DEV, dtype=torch.float32) / (taps * K) ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, generator=g, device=DEV, dtype=torch.float32)
@@ -58,6 +62,14 @@ def main():
             kw["conv"] = geo
         if mode == 2:
             kw["temporal"] = geo
+        if args.epi and not geglu:
+            if args.epi & 1:      # one row per image of 9216 / 2304 / ... pixels (the temb broadcast add)
+                pix = M // 50
+                kw.update(V=torch.randn(50, N, generator=g, device=DEV, dtype=torch.float32), vmode=1, vdiv=pix, vmod=50)
+            if args.epi & 2:
+                kw.update(R1=torch.randn(M, N, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16), s1=1.0)
+            if args.epi & 4:
+                kw.update(R2=torch.randn(M, N, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16), s2=0.5)
         res = []
         for t in tiles:
             if geglu and N % 32:
