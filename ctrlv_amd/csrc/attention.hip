@@ -57,7 +57,7 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 // launch_bounds(256, 2): a 256-register budget makes hipcc keep the score / output accumulators in arch VGPRs; with the
 // default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
 template <int NSLOT>
-__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 3 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
@@ -79,21 +79,27 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
     qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
 
+  // K/V tiles are gathered by LDS-DMA through a buffer descriptor over THIS image's rows: the per-lane byte offsets
+  // are computed once, a tile only adds a scalar offset, and keys >= S fall outside num_records (the hardware range
+  // check returns zeros) -- no per-tile address arithmetic or bounds selects on the VALU, which is this kernel's
+  // critical resource (softmax: ~2 VALU slots per MFMA cycle at head_dim 64).
   const int prow = lane >> 3, pslot = lane & 7;
-  const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
+  const __amdgpu_buffer_rsrc_t rs_kv =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + row0 * ld), 0, (int)((long)S * ld * 2), 0x00020000);
+  // piece q of a wave covers tile rows (q*4 + wid)*8 + prow: q only adds 32 rows (a scalar offset; the swizzle terms
+  // depend on (row >> 1) & 7 and are unchanged), so one K and one V offset per lane serve the whole kernel
+  const int rt0 = wid * 8 + prow;
+  const unsigned koff = (unsigned)(rt0 * ld + C + head * 64 + (pslot ^ ((rt0 >> 1) & 7)) * 8) * 2u;
+  const unsigned voff = (unsigned)(rt0 * ld + 2 * C + head * 64 + (pslot ^ (((rt0 >> 1) & 1) << 2)) * 8) * 2u;
+  const int tile_bytes = 64 * ld * 2;
   auto issue = [&](int t, int stage) {
     char* ks_ = smem + stage * 16384;
     char* vs_ = ks_ + 8192;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int rt = (q * 4 + wid) * 8 + prow;
-      const int key = t * 64 + rt;
-      const bool ok = key < S;
-      const long roff = (row0 + key) * ld;
-      const char* pk = ok ? (const char*)(kp + roff + (pslot ^ ((rt >> 1) & 7)) * 8) : zsrc;
-      const char* pv = ok ? (const char*)(vp + roff + (pslot ^ (((rt >> 1) & 1) << 2)) * 8) : zsrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, 0, 0);
+      const int so = t * tile_bytes + q * (tile_bytes >> 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, koff, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, voff, so, 0, 0);
     }
   };
 
@@ -109,12 +115,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
   const int vkey = 4 * hsel + (i16 >> 2);
   const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
 
-  constexpr float kDeferLog2 = 6.0f;   // T13: keep the running max while a tile's max exceeds it by < 2^6 (P <= 64)
-  auto tile = [&](int t, auto masked_tag) {
+  // Online softmax without a per-element running-max pass.  A tile is exponentiated against the max KEPT from
+  // earlier tiles (packed fma + v_exp_f32) and summed; only if some lane's partial row sum exceeds 2^12 (or is
+  // inf / NaN: always on the first tile, m_run = -inf) the tile takes the slow path: scores are recomputed from the
+  // K tile still in LDS, the true row max is folded into m_run, O and l are rescaled once, and the tile is
+  // exponentiated again.  P stays <= 2^12 (exact in bf16's fp32 exponent range, fp32 accumulation), and the common
+  // path drops the 24 v_max3/v_max and the compare of the classic deferred-rescale scheme (T13) from a loop that is
+  // VALU-bound: measured on MI355X v_exp_f32 costs two VALU issue slots, the kernel spends ~1.6 slots per MFMA cycle.
+  constexpr float kSumLimit = 4096.0f;
+  auto scores = [&](const char* kst, f32x16 (&sacc)[2], int t, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const char* kst = smem + (t % NSLOT) * 16384;
-    const char* vst = kst + 8192;
-    f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -124,6 +134,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
         const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
       }
+      // keep the four K fragments of the second 32-key half out of flight until the first half is consumed: the
+      // kernel has to fit 128 VGPRs (4 waves per SIMD), and hoisting all eight costs 16 registers
+      if (kt == 0) asm volatile("" ::: "memory");
     }
     if (MASKED) {  // key masking on the ragged last tile only (separate instantiation: no selects in the main loop)
 #pragma unroll
@@ -134,15 +147,37 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
           if (key >= S) sacc[kt][e] = -INFINITY;
         }
     }
-    float mx = sacc[0][0];
+  };
+  auto exp_sum = [&](f32x16 (&sacc)[2]) -> float {
+    f32x2_t rs2 = {0.f, 0.f};
+    const f32x2_t nm = {-m_run, -m_run};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
-    mx = half_max(mx) * kScaleLog2;
-    // deferred rescale: only when some row's max grew by more than 2^kDeferLog2 (always on the first tile: m_run = -inf).
-    // P of this tile is exponentiated AFTER the decision against the max that is kept, and O / l are scaled exactly once.
-    if (!__all(mx - m_run <= kDeferLog2)) {
+      for (int e = 0; e < 16; e += 2) {
+        f32x2_t x = {sacc[kt][e], sacc[kt][e + 1]};
+        x = x * kScaleLog2 + nm;
+        f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+        sacc[kt][e] = pe.x;
+        sacc[kt][e + 1] = pe.y;
+        rs2 += pe;
+      }
+    return rs2.x + rs2.y;
+  };
+  auto tile = [&](int t, auto masked_tag) {
+    const char* kst = smem + (t % NSLOT) * 16384;
+    const char* vst = kst + 8192;
+    f32x16 sacc[2];
+    scores(kst, sacc, t, masked_tag);
+    float rs = exp_sum(sacc);
+    if (!__all(rs <= kSumLimit)) {
+      scores(kst, sacc, t, masked_tag);
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+      mx = half_max(mx) * kScaleLog2;
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -151,16 +186,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+      rs = exp_sum(sacc);
     }
-    float rs = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kt][e] * kScaleLog2 - m_run);
-        sacc[kt][e] = p;
-        rs += p;
-      }
     l_run += rs;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ float silu_f(float x) {
 // rounding.  All FMAs, written on float vectors so that the compiler emits v_pk_fma_f32 (2 elements per instruction).
 // (Four elements per call: two independent Horner chains interleave, which also fills the 1-wait-state hazard
 // between dependent packed-fp32 instructions that the compiler otherwise pads with s_nop.)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t gelu_phi4(f32x4_t x) {
   f32x4_t xc;

@@ -276,18 +276,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int A_SLOT = BM * 64, B_SLOT = BN * 64, SLOT = A_SLOT + B_SLOT;
   constexpr int A_TOT = BM / 16, B_TOT = BN / 16;            // 1-KiB DMA pieces (16 rows x 64 B) per half-step
-  // B pieces issued in the LOAD phase next to the A pieces (the rest go into the MFMA gaps); must stay below B_Q so
-  // that the ragged last piece of the 320-wide tile is always issued in the compute phase.  A/B on one device
-  // (tools/ab_build.py): 1 is +8-12 % on the 256-wide tile (16 MFMAs per phase), 0 is best on the 320-wide one (20).
-#ifdef CTRLV_PP_BL
-  constexpr int BL = CTRLV_PP_BL;
-#else
-  constexpr int BL = BN == 256 ? 1 : 0;
-#endif
   constexpr int A_Q = A_TOT / NW;                            // per wave (2)
   constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave upper bound (2 or 3)
   static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
-  static_assert(BL >= 0 && BL < B_Q, "CTRLV_PP_BL must be smaller than the B pieces per wave");
+  // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
+  // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue costs ~60 cycles instead of
+  // 200-450: it overlaps the matrix pipe).  Whichever phase is longer sets the slot time, so NL balances them: A/B on one
+  // device (tools/ab_build.py -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 1-2 of 5 for the
+  // 320-wide one (20 MFMAs; the 3x3 gather's address arithmetic makes its load phase longer).  The ragged last B piece of the 320-wide tile must stay in the compute phase (NL < NPIECE).
+  constexpr int NPIECE = A_Q + B_Q;
+#ifdef CTRLV_PP_NL
+  constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
+#else
+  constexpr int NL = BN == 256 ? A_Q + 1 : (MODE == 1 ? A_Q - 1 : A_Q);   // 320-wide: conv 1 (+3 %), linear / temporal 2
+#endif
+  constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
+  static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -419,6 +423,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(is_sb + (q * NW + wid) * 1024), 16, b_voff[q], is_wsoff,
                                                0, 0);
   };
+  auto issue_piece = [&](int pc) {
+    if (pc < A_Q) issue_a(pc); else issue_b(pc - A_Q);
+  };
   auto issue_end = [&]() {
     ++is_j;
     is_cc += 32;
@@ -472,20 +479,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
       }
       STAMP(t1);
-      // DMA of half-step g+3: the A pieces are issued here (load phase), the B pieces in the gaps of the MFMA cluster
-      // below -- an LDS-DMA piece holds the issuing wave for 100-200 cycles (stamps), so the issue work is split
-      // between the two phases to balance them.  Then retire own DMA(g+1): pieces of g+2 and the A pieces just issued
-      // may stay in flight.
+      // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
+      // cluster below.  Then retire own DMA(g+1): the pieces of g+2 and the NL pieces just issued may stay in flight.
       const bool do_issue = g + 3 < total;
       if (do_issue) {
         issue_begin(g + 3);
 #pragma unroll
-        for (int q = 0; q < A_Q; ++q) issue_a(q);
-#pragma unroll
-        for (int q = 0; q < BL; ++q) issue_b(q);          // every wave owns B pieces 0 .. B_Q-2 (only the last is ragged)
+        for (int pc = 0; pc < NL; ++pc) issue_piece(pc);
         STAMP(t1b);
         STAMP_ADD(c_lissue, t1, t1b);
-        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1 + A_Q + BL>(); else wait_vmcnt<A_Q + B_Q + A_Q + BL>();
+        if (UNEVEN && !b_extra) wait_vmcnt<NPIECE - 1 + NL>(); else wait_vmcnt<NPIECE + NL>();
       } else if (g + 2 < total) {
         if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
       } else {
@@ -526,9 +529,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (do_issue) {
-          if (grpi == 0) { if (BL < 1) issue_b(0); }
-          if (grpi == 1) { if (BL < 2 && B_Q > 1) issue_b(1); }
-          if (grpi == 2) { if (BL < 3 && B_Q > 2) issue_b(2); }
+#pragma unroll
+          for (int k = 0; k < NC; ++k)
+            if (k * 4 / NC == grpi) issue_piece(NL + k);
           if (grpi == 3) issue_end();
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -1,8 +1,11 @@
 """Register-budget regression guard for the ping-pong GEMM (CPU only: hipcc cross-compiles gfx950).
 
 The 256x320 tile runs at 252-256 VGPRs; a careless edit pushes hundreds of registers to scratch and every layer shape
-drops ~20x (seen during development).  This test compiles the three instantiation units with
--Rpass-analysis=kernel-resource-usage and bounds spills / scratch for every kernel."""
+drops ~20x (seen during development).  This test compiles the three instantiation units to assembly with
+-Rpass-analysis=kernel-resource-usage and checks, for every kernel: <= 256 VGPRs, two waves per SIMD, a bounded number
+of spills, and -- what actually matters for speed -- that (almost) no scratch access sits inside the K loop: the
+epilogue of the widest tile may park a few tile-invariant values in scratch once per output tile, the half-step
+loop must not."""
 import os
 import re
 import subprocess
@@ -16,11 +19,12 @@ def test_pingpong_gemm_register_budget():
     procs = []
     with tempfile.TemporaryDirectory() as td:
         for unit in ("gemm_pp_m0.hip", "gemm_pp_m1.hip", "gemm_pp_m2.hip"):
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "--cuda-device-only",
-                   "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, unit), "-o", os.path.join(td, unit + ".o")]
-            procs.append((unit, subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)))
+            asm = os.path.join(td, unit + ".s")
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                   "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, unit), "-o", asm]
+            procs.append((unit, asm, subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)))
         n_kernels = 0
-        for unit, p in procs:
+        for unit, asm, p in procs:
             err = p.communicate()[1]
             assert p.returncode == 0, err[-2000:]
             vg = [int(x) for x in re.findall(r"VGPRs: (\d+)", err)]
@@ -30,5 +34,16 @@ def test_pingpong_gemm_register_budget():
             n_kernels += len(vg)
             assert vg and max(vg) <= 256, (unit, vg)
             assert all(o >= 2 for o in occ), (unit, occ)          # two waves per SIMD: the schedule depends on it
-            assert max(sp) <= 40 and max(sc) <= 128, (unit, sp, sc)
+            assert max(sp) <= 64 and max(sc) <= 128, (unit, sp, sc)
+            # scratch traffic inside the half-step loop (the blocks LLVM annotates "Depth=2"), per kernel
+            text = open(asm).read()
+            kernels = re.split(r"\n(?=_ZN\S*gemm_pp_kernel\S*:)", text)[1:]
+            assert len(kernels) == len(vg), (unit, len(kernels), len(vg))
+            for k in kernels:
+                body = k.split("s_endpgm")[0].split("\n")
+                assert any("v_mfma" in ln for ln in body)
+                depth2 = [i for i, ln in enumerate(body) if "Depth=2" in ln]
+                assert depth2, "K loop not found"
+                in_loop = [ln for ln in body[depth2[0]:depth2[-1] + 1] if "scratch_" in ln]
+                assert len(in_loop) <= 2, (unit, body[0][:90], in_loop)
         assert n_kernels == 24
