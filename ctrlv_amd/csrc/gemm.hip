@@ -232,10 +232,11 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   if (tile == 0) {
     // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): the persistent ping-pong tiles win on
     // every layer shape of the UNet; 256x320 where N is a multiple of 320 (C = 320 / 640 levels, conv / FF-out at
-    // 1280), 256x256 otherwise and for GEGLU (needs 64-column wave tiles); tiny-M per-clip GEMMs stay on 128x128.
+    // 1280, GEGLU at K < 1280), 256x256 otherwise (N = 3840 qkv, K = 1280 GEGLU: +7 %); tiny-M per-clip GEMMs stay on
+    // 128x128.
     const bool big = d.M >= 1024 && d.N >= 128;
     if (!big) tile = 1;
-    else if (d.N % 320 == 0 && (d.N < 3840 || d.geglu) && d.M >= 16384) tile = 6;
+    else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
   if (tile >= 5) {

@@ -71,10 +71,26 @@ __host__ __device__ inline long pp_vtable_rows(const ctrlv_gemm_desc& d) {
   return reach < d.vmod ? reach : (long)d.vmod;
 }
 
+// Bias lives in a wave-private LDS strip (WTN floats: the columns of this wave's tile), filled before the first tile
+// and re-filled at the end of every epilogue with the NEXT tile's columns (loaded into 4 VGPRs at the start of the
+// epilogue, so its latency hides behind the whole epilogue): the sub-tiles read it with two ds_read_b128 instead
+// of holding it in the VGPR prefetch queue or re-loading it from L2 -- the 320-wide tile has no registers to spare.
+template <int WTN>
+__device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wbase_n, int lane) {
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(d.bias ? (const void*)d.bias : d.W), 0, d.bias ? d.N * 4 : 0, 0x00020000);   // no bias: reads 0
+  return __builtin_amdgcn_raw_buffer_load_b128(rsB, lane < WTN / 4 ? (unsigned)((wbase_n + lane * 4) * 4) : 0xFFFFFFFFu,
+                                               0, 0);
+}
+template <int WTN>
+__device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, int lane) {
+  if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
+}
+
 template <int TM, int TN, bool GEGLU, int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
-                                                  char* p2, char* p3) {
+                                                  char* p2, char* p3, const char* bias_lds) {
   constexpr unsigned kOOB = 0xFFFFFFFFu;
   constexpr int kFlags = 0x00020000;
   const int r32 = lane & 31, hsel = lane >> 5, l4 = lane & 3;
@@ -91,8 +107,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 
   const __amdgpu_buffer_rsrc_t rsO =
       __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)((long)d.M * d.ldo * 2), kFlags);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(d.bias ? (const void*)d.bias : d.W), 0, d.bias ? d.N * 4 : 0, kFlags);   // no bias: every load reads 0
   const __amdgpu_buffer_rsrc_t rsR1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((EPI & 2) ? d.R1 : d.W), 0, (EPI & 2) ? (int)((long)d.M * d.ldr1 * 2) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsR2 = __builtin_amdgcn_make_buffer_rsrc(
@@ -116,35 +130,43 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
   }
 
   if constexpr (!GEGLU) {
-    struct Ops { u32x4_t b0, b1, r1[2], r2[2]; };
-    // operand prefetch distance in sub-tiles, bounded by the register budget of the 320-wide tile (252+ VGPRs)
-    constexpr int PF = (TN > 2 && (EPI == 3 || EPI == 6)) ? 0 : ((EPI & 4) || (TN > 2 && (EPI & 2))) ? 1 : 2;
-    Ops q[PF + 1];
+    // Residual operands are streamed from HBM (~1 us): they are prefetched through a window that GROWS as the
+    // epilogue retires accumulators -- every finished sub-tile frees 16 accumulator registers, enough for the R1 rows of
+    // two more sub-tiles (one with R2) -- so a 10-sub-tile epilogue pays the memory latency about once, not ten times.
+    struct Res { u32x4_t r1[2], r2[2]; };
+    constexpr bool HAS_RES = (EPI & 6) != 0;
+    // sub-tiles in flight before the first one is processed: bounded by what the 320-wide tile (252+ VGPRs) can hold
+    constexpr int P0 = TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3);
+    constexpr int GROW = (EPI & 4) ? 1 : (TN > 2 ? 2 : 2);          // additional sub-tiles issued per processed one
+    Res q[HAS_RES ? NSUB : 1];
     const int ocol0 = wbase_n + l4 * 8;
-    auto load_ops = [&](int s, Ops& o) {
+    auto load_res = [&](int s) {
       const int i = s / TN, j = s % TN;
       const int ocol = ocol0 + j * 32;
-      o.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, ocol * 4, 0, 0);
-      o.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, ocol * 4 + 16, 0, 0);
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const int m = m0 + i * 32 + pass * 16;
         const bool ok = m < d.M && ocol < d.n_store;
         if (EPI & 2)
-          o.r1[pass] = __builtin_amdgcn_raw_buffer_load_b128(
+          q[s].r1[pass] = __builtin_amdgcn_raw_buffer_load_b128(
               rsR1, ok ? (unsigned)m * (unsigned)(d.ldr1 * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
         if (EPI & 4)
-          o.r2[pass] = __builtin_amdgcn_raw_buffer_load_b128(
+          q[s].r2[pass] = __builtin_amdgcn_raw_buffer_load_b128(
               rsR2, ok ? (unsigned)m * (unsigned)(d.ldr2 * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
       }
     };
+    if (HAS_RES) {
 #pragma unroll
-    for (int s = 0; s < PF && s < NSUB; ++s) load_ops(s, q[s % (PF + 1)]);
+      for (int s = 0; s < P0 && s < NSUB; ++s) load_res(s);
+    }
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       const int i = s / TN, j = s % TN;
-      if (s + PF < NSUB) load_ops(s + PF, q[(s + PF) % (PF + 1)]);
-      const Ops& cur = q[s % (PF + 1)];
+      if (HAS_RES) {
+#pragma unroll
+        for (int k = P0 + GROW * s; k < P0 + GROW * (s + 1); ++k)
+          if (k < NSUB) load_res(k);
+      }
       const int ocol = ocol0 + j * 32;
       // row-vector operands (L2-resident tables): issued ahead of this sub-tile's LDS round trip
       u32x4_t vv[2][2] = {};
@@ -170,6 +192,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         img[pass][0] = *(const float4*)(rp + rx0);
         img[pass][1] = *(const float4*)(rp + rx1);
       }
+      const float4 b0 = *(const float4*)(bias_lds + (j * 32 + l4 * 8) * 4);
+      const float4 b1 = *(const float4*)(bias_lds + (j * 32 + l4 * 8 + 4) * 4);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -177,29 +201,29 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const int m = m0 + i * 32 + pass * 16;
         const bool ok = m < d.M && ocol < d.n_store;
-        const u32x4_t vv0 = vv[pass][0], vv1 = vv[pass][1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (o[e] + __uint_as_float(cur.b0[e])) * d.s_acc;
-          o[4 + e] = (o[4 + e] + __uint_as_float(cur.b1[e])) * d.s_acc;
-        }
+        o[0] = (o[0] + b0.x) * d.s_acc; o[1] = (o[1] + b0.y) * d.s_acc;
+        o[2] = (o[2] + b0.z) * d.s_acc; o[3] = (o[3] + b0.w) * d.s_acc;
+        o[4] = (o[4] + b1.x) * d.s_acc; o[5] = (o[5] + b1.y) * d.s_acc;
+        o[6] = (o[6] + b1.z) * d.s_acc; o[7] = (o[7] + b1.w) * d.s_acc;
         if (EPI & 2) {
           float f[8];
-          unpack_bf16x8(make_uint4(cur.r1[pass].x, cur.r1[pass].y, cur.r1[pass].z, cur.r1[pass].w), f);
+          const u32x4_t r = q[HAS_RES ? s : 0].r1[pass];
+          unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
         }
         if (EPI & 4) {
           float f[8];
-          unpack_bf16x8(make_uint4(cur.r2[pass].x, cur.r2[pass].y, cur.r2[pass].z, cur.r2[pass].w), f);
+          const u32x4_t r = q[HAS_RES ? s : 0].r2[pass];
+          unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
         }
         if (EPI & 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] += __uint_as_float(vv0[e]);
-            o[4 + e] += __uint_as_float(vv1[e]);
+            o[e] += __uint_as_float(vv[pass][0][e]);
+            o[4 + e] += __uint_as_float(vv[pass][1][e]);
           }
         }
         const uint4 pk = pack_bf16x8(o);
@@ -207,14 +231,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         __builtin_amdgcn_raw_buffer_store_b128(
             pv, rsO, ok ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
       }
+      // keep the machine scheduler from hoisting the later sub-tiles' loads up here: the prefetch window is sized to
+      // the registers that are free at each point, hoisting turns it into hundreds of spills
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     // GEGLU: weight rows come in 16-row (value, gate) blocks, so quads 0,1 of a 32x32 sub-tile are 16 values and
     // quads 2,3 their gates, in the same lane: out = (a + ba) * gelu(g + bg) is computed in the MFMA layout (its bias
-    // is a per-column broadcast, L2-resident) and two adjacent sub-tiles (16 outputs each) share one staged 32-column
-    // image; a lone last sub-tile fills only the left half.
+    // is a per-column broadcast from the LDS strip) and two adjacent sub-tiles (16 outputs each) share one staged
+    // 32-column image; a lone last sub-tile fills only the left half.
     constexpr int NP = (TN + 1) / 2;
-    const int gcol0 = wbase_n + 4 * hsel;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -226,16 +252,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           if (js >= TN) continue;                          // compile time
 #pragma unroll
           for (int qd = 0; qd < 2; ++qd) {
-            const int n = gcol0 + js * 32 + 8 * qd;
-            const u32x4_t ba = __builtin_amdgcn_raw_buffer_load_b128(rsB, n * 4, 0, 0);
-            const u32x4_t bg = __builtin_amdgcn_raw_buffer_load_b128(rsB, (n + 16) * 4, 0, 0);
-            const f32x4_t g = {acc[i][js][4 * (qd + 2)] + __uint_as_float(bg[0]),
-                               acc[i][js][4 * (qd + 2) + 1] + __uint_as_float(bg[1]),
-                               acc[i][js][4 * (qd + 2) + 2] + __uint_as_float(bg[2]),
-                               acc[i][js][4 * (qd + 2) + 3] + __uint_as_float(bg[3])};
-            const f32x4_t a = {acc[i][js][4 * qd] + __uint_as_float(ba[0]), acc[i][js][4 * qd + 1] + __uint_as_float(ba[1]),
-                               acc[i][js][4 * qd + 2] + __uint_as_float(ba[2]),
-                               acc[i][js][4 * qd + 3] + __uint_as_float(ba[3])};
+            const float4 ba = *(const float4*)(bias_lds + (js * 32 + 8 * qd + 4 * hsel) * 4);
+            const float4 bg = *(const float4*)(bias_lds + (js * 32 + 16 + 8 * qd + 4 * hsel) * 4);
+            const f32x4_t g = {acc[i][js][4 * (qd + 2)] + bg.x, acc[i][js][4 * (qd + 2) + 1] + bg.y,
+                               acc[i][js][4 * (qd + 2) + 2] + bg.z, acc[i][js][4 * (qd + 2) + 3] + bg.w};
+            const f32x4_t a = {acc[i][js][4 * qd] + ba.x, acc[i][js][4 * qd + 1] + ba.y, acc[i][js][4 * qd + 2] + ba.z,
+                               acc[i][js][4 * qd + 3] + ba.w};
             const f32x4_t o = a * gelu_erf4(g);
             const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
             *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
   static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
 
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 wave-private bias strips
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -447,6 +469,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   const bool b_extra = (B_Q - 1) * NW + wid < B_TOT;         // true for all waves when B_TOT % 8 == 0
   constexpr bool UNEVEN = (B_TOT % NW) != 0;
 
+  // bias strip of this wave for the first tile (see pp_bias_load); its load is retired before any DMA is issued
+  char* const bias_lds = smem + NH * SLOT + wid * (WTN * 4);
+  {
+    const int bn0 = (my_first % tiles_n) * BN;
+    const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
+    pp_bias_store<WTN>(bias_lds, b, lane);
+  }
   // ---- prologue: 3 half-steps in flight (total >= 2 always: Cin >= 64)
   issue(0);
   issue(1);
@@ -554,8 +583,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (refilled only by this
       // wave's DMA of half-step g+3, which it issues in ITS next compute phase, after this epilogue)
       char* s0 = smem + ((g - 1) & (NH - 1)) * SLOT;
+      // bias columns of the next tile: loaded now, parked in the LDS strip after this epilogue's last bias read
+      const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
+      u32x4_t nb = {0, 0, 0, 0};
+      if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
       gemm_epilogue_lds<TM, TN, GEGLU, EPI>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
-                                s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024);
+                                s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024, bias_lds);
+      if (refill) pp_bias_store<WTN>(bias_lds, nb, lane);
+      // The accumulators are dead here -- the next tile's first MFMAs overwrite them from a literal-zero C operand --
+      // but that redefinition sits behind a `j == 0` test inside the K loop, so the compiler would keep all 128-160
+      // registers live through the epilogue.  An empty asm that "defines" them ends the old live ranges at their last
+      // staging write: the epilogue's prefetch window and addresses then live in retired accumulator registers.
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) asm volatile("" : "=v"(acc[i][n]));
     }
     STAMP(t7);
     STAMP_ADD(c_epi, t6, t7);
@@ -574,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
-  constexpr int smem = 4 * (256 + BN) * 64;
+  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4;   // DMA ring + one bias strip (BN / WN floats) per wave
   static bool attr_set = false;
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI>;
   if (!attr_set) {

@@ -3,7 +3,7 @@
 The 256x320 tile runs at 252-256 VGPRs; a careless edit pushes hundreds of registers to scratch and every layer shape
 drops ~20x (seen during development).  This test compiles the three instantiation units to assembly with
 -Rpass-analysis=kernel-resource-usage and checks, for every kernel: <= 256 VGPRs, two waves per SIMD, a bounded number
-of spills, and -- what actually matters for speed -- that (almost) no scratch access sits inside the K loop: the
+of spills, and -- what actually matters for speed -- that no scratch access sits in a hot block of the K loop: the
 epilogue of the widest tile may park a few tile-invariant values in scratch once per output tile, the half-step
 loop must not."""
 import os
@@ -44,6 +44,19 @@ def test_pingpong_gemm_register_budget():
                 assert any("v_mfma" in ln for ln in body)
                 depth2 = [i for i, ln in enumerate(body) if "Depth=2" in ln]
                 assert depth2, "K loop not found"
-                in_loop = [ln for ln in body[depth2[0]:depth2[-1] + 1] if "scratch_" in ln]
-                assert len(in_loop) <= 2, (unit, body[0][:90], in_loop)
+                # basic blocks of the K loop; the HOT ones are those every half-step executes (MFMAs, barriers, fragment
+                # reads, LDS-DMA issue).  The once-per-tile `setup` branch (integer divisions for the tile coordinates)
+                # may reload a few parked values; a hot block must not touch scratch.
+                blocks, cur = [], []
+                for ln in body[depth2[0]:depth2[-1] + 1]:
+                    if ln.startswith(".LBB") or ln.startswith("; %bb."):
+                        blocks.append(cur)
+                        cur = []
+                    cur.append(ln)
+                blocks.append(cur)
+                hot_marks = ("v_mfma", "s_barrier", "ds_read_b128", " lds")
+                for blk in blocks:
+                    if any(mk in ln for ln in blk for mk in hot_marks):
+                        bad = [ln for ln in blk if "scratch_" in ln]
+                        assert not bad, (unit, body[0][:90], bad)
         assert n_kernels == 24
