@@ -22,7 +22,13 @@
 // Tiles: BN = 256 (waves 2x4, wave tile 128x64) and BN = 320 (waves 4x2, wave tile 64x160) -- the latter makes
 // N = 320 / 640 / 960 / 1920 exact multiples (the C = 320 / 640 levels of the UNet).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef CTRLV_PP_SCHED
+#define CTRLV_PP_SCHED 0      // 0: ping-pong wave groups, 1: streamed (both documented at the kernel)
+#endif
 
 namespace {
 
@@ -299,13 +305,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   constexpr int A_SLOT = BM * 64, B_SLOT = BN * 64, SLOT = A_SLOT + B_SLOT;
   constexpr int A_TOT = BM / 16, B_TOT = BN / 16;            // 1-KiB DMA pieces (16 rows x 64 B) per half-step
   constexpr int A_Q = A_TOT / NW;                            // per wave (2)
-  constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave upper bound (2 or 3)
+  constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave (2 or 3; see the dummy piece below)
   static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
   // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
-  // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue costs ~60 cycles instead of
-  // 200-450: it overlaps the matrix pipe).  Whichever phase is longer sets the slot time, so NL balances them: A/B on one
-  // device (tools/ab_build.py -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 1-2 of 5 for the
-  // 320-wide one (20 MFMAs; the 3x3 gather's address arithmetic makes its load phase longer).  The ragged last B piece of the 320-wide tile must stay in the compute phase (NL < NPIECE).
+  // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue overlaps the matrix pipe).
+  // Whichever phase is longer sets the slot time, so NL balances them: A/B on one device (tools/ab_build.py
+  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 1-2 of 5 for the 320-wide one (20 MFMAs).
   constexpr int NPIECE = A_Q + B_Q;
 #ifdef CTRLV_PP_NL
   constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
@@ -314,8 +319,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #endif
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
   static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
+  // When B_TOT is not a multiple of the wave count (320-wide: 20 pieces, 8 waves) the waves without a real last piece
+  // issue a DUMMY one -- out-of-range source (zeros, no memory traffic) into a private 1-KiB scratch strip -- so that
+  // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
+  constexpr bool UNEVEN = (B_TOT % NW) != 0;
+  constexpr int BIAS_OFF = NH * SLOT, DUMMY_OFF = BIAS_OFF + NW * WTN * 4;
 
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 wave-private bias strips
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | 8 dummy pieces
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -330,27 +340,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // tile of round r for this block: XCD-contiguous inside every window of G tiles
   const int my_first = xcd_remap(blockIdx.x, G);
   const int my_ntiles = (ntiles - my_first + G - 1) / G;       // >= 1 (grid <= ntiles)
-
-  const int J = d.taps * (d.Cin >> 5);                       // half-steps per tile
+  const int J = d.taps * (d.Cin >> 5);                       // half-steps per tile (>= 4: ctrlv_gemm_pp_supports)
   const long ktot = (long)d.taps * d.Cin;
-  const int total = my_ntiles * J;                           // half-steps this block executes
 
-  // ---- per-lane DMA row state of the tile the ISSUE stream is in.  Sources are addressed through buffer descriptors
-  // (buffer_load ... lds): a 32-bit byte offset per lane, and every invalid row (conv halo, frame edge, tile overhang)
-  // simply gets an out-of-range offset -- the hardware range check returns zeros, no zero page, no 64-bit pointer math.
+  // ---- DMA addressing.  Sources go through buffer descriptors (buffer_load ... lds): address = base + voffset (per
+  // lane) + soffset (scalar), and only the per-lane part is range-checked.  So a lane's offset is computed ONCE per
+  // tile -- the byte offset of its row (tap centre), or 0xFFFFFFFF for rows past M / tile overhang, which the hardware
+  // turns into zeros -- and a half-step only supplies a scalar: the channel offset plus, for the 3x3 / temporal gathers,
+  // the tap displacement.  Tap displacements can be negative, so the descriptor base is moved DOWN by the largest one
+  // (Wd+1 rows / S rows) and every scalar offset is >= 0.  The hot loop carries no per-lane address arithmetic beyond a
+  // tap-validity select: a single wave issues only one VALU instruction per ~10 cycles while its SIMD partner owns the
+  // matrix pipe, so every bookkeeping instruction there is on the critical path (SQ counters: LDS and TA are < 20 %
+  // busy, MFMA 40 % -- the loop was issue-bound, not bandwidth-bound).
   const int prow = lane >> 2, pslot = lane & 3;
   const unsigned coff = (pslot ^ ((prow >> 2) & 3)) * 16;    // logical chunk this lane fetches (bytes); the piece
                                                              // base row is a multiple of 16, so (row>>2)&3 == (prow>>2)&3
   const unsigned kOOB = 0xFFFFFFFFu;
   const long a_rows = MODE == 1 ? (long)(d.M / (d.Ho * d.Wo)) * d.H * d.Wd : (long)d.M;
-  const __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)(a_rows * d.lda * 2), 0x00020000);
+  const int bias_rows = MODE == 1 ? d.Wd + 1 : (MODE == 2 ? d.S : 0);
+  const long bias_a = (long)bias_rows * d.lda * 2, bias_a2 = (long)bias_rows * d.lda2 * 2;
+  // (num_records covers the bias too: the upsample gather adds its per-lane displacement, bias included, to voffset)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)d.A - bias_a), 0, (int)(a_rows * d.lda * 2 + bias_a), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(d.A2 ? d.A2 : d.A), 0, (int)(d.A2 ? a_rows * d.lda2 * 2 : 0), 0x00020000);
+      (void*)((const char*)(d.A2 ? d.A2 : d.A) - bias_a2), 0, (int)(d.A2 ? a_rows * d.lda2 * 2 + bias_a2 : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW =
       __builtin_amdgcn_make_buffer_rsrc((void*)d.W, 0, (int)((long)d.N * ktot * 2), 0x00020000);
-  int a_row[A_Q];                                            // source row index of the tap centre
-  unsigned a_mask[A_Q];                                      // bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
+  unsigned a_voff[A_Q], a_voff2[A_Q];                        // per-lane row offsets into A / A2 (kOOB if the row is invalid)
+  unsigned a_mask[A_Q];                                      // modes 1/2, bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
   unsigned b_voff[B_Q];                                      // byte offset of the weight row (+chunk), kOOB if out of range
   auto setup = [&](int tile) {
     const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
@@ -359,13 +376,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       const int m = bm + (q * NW + wid) * 16 + prow;
       const bool ok = m < d.M;
       int row = m;
-      unsigned mask = ok ? 1u : 0u;
+      unsigned mask = 0;
       if (MODE == 1) {
         const int hw = d.Ho * d.Wo;
         const int n_img = m / hw, rem = m - n_img * hw;
         const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
         int cy, cx;
-        mask = 0;
         if (d.up) { cy = yo >> 1; cx = xo >> 1; mask = ((unsigned)(yo & 1) << 16) | ((unsigned)(xo & 1) << 17); }
         else { cy = yo * d.stride; cx = xo * d.stride; }
         row = (n_img * d.H + cy) * d.Wd + cx;
@@ -380,7 +396,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
         const int f = (m / d.S) % d.F;
         mask = ok ? ((f > 0 ? 1u : 0u) | 2u | (f < d.F - 1 ? 4u : 0u)) : 0u;
       }
-      a_row[q] = ok ? row : 0;
+      a_voff[q] = ok ? (unsigned)row * (unsigned)(d.lda * 2) + coff : kOOB;
+      a_voff2[q] = ok ? (unsigned)row * (unsigned)(d.lda2 * 2) + coff : kOOB;
       a_mask[q] = mask;
     }
 #pragma unroll
@@ -391,197 +408,249 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     }
   };
 
-  // issue stream state (global half-step g about to be issued; its tile-local index, tap and channel offset)
-  int is_tile = my_first, is_j = 0, is_tap = 0, is_cc = 0;
-  setup(is_tile);
-  const bool dbg_nodma = (d.out_f32 & 4) != 0;   // profiling aid (tools/gemm_sweep.py)
-  // One half-step's DMA is issued piece by piece (issue_begin, issue_a(q)..., issue_b(q)..., issue_end) so that the
-  // pieces can sit in the gaps of an MFMA cluster: an LDS-DMA piece costs 100-200 cycles of issue when four waves
-  // of a CU issue together (measured with tools/gemm_stamp.py: 934 cycles per half-step in the load phase), ~60
-  // among MFMAs (MI355X_MICROARCH cycle constants).
+  // issue-stream state (scalars): tile-local half-step about to be issued = (is_tap, is_cc); the tile itself is switched
+  // by the K loop below (three half-steps before the consuming stream gets there)
+  int is_tap = 0, is_cc = 0;
   char* is_sa = nullptr;
   char* is_sb = nullptr;
   bool is_second = false;
-  int is_ld2 = 0, is_dyo = 0, is_dxo = 0, is_wsoff = 0;
-  unsigned is_uni = 0;
+  unsigned is_so_a = 0, is_so_w = 0;
+  int is_dyo = 0, is_dxo = 0, is_ld2 = 0;
   auto issue_begin = [&](int g) {
-    if (is_j == J) {                                         // the stream crosses into this block's next tile
-      is_tile += G; is_j = 0; is_tap = 0; is_cc = 0;
-      setup(is_tile);
-    }
     is_sa = smem + (g & (NH - 1)) * SLOT;
     is_sb = is_sa + A_SLOT;
     is_second = d.A2 != nullptr && is_cc >= d.c_split;
-    is_ld2 = (is_second ? d.lda2 : d.lda) * 2;               // row pitch in bytes
-    int roff = 0;
-    is_dyo = 0; is_dxo = 0;
+    is_ld2 = (is_second ? d.lda2 : d.lda) * 2;               // row pitch in bytes of the active source
+    int roff = 0;                                            // tap displacement in rows, biased to be >= 0
     if (MODE == 1) {
       is_dyo = is_tap / 3 - 1; is_dxo = is_tap % 3 - 1;
-      if (!d.up) roff = is_dyo * d.Wd + is_dxo;
+      roff = d.up ? 0 : (is_dyo + 1) * d.Wd + is_dxo + 1;    // upsample: per-lane (parity), see issue_a
     } else if (MODE == 2) {
-      roff = (is_tap - 1) * d.S;
+      roff = is_tap * d.S;
     }
-    // uniform part of the byte offset (may be "negative": 32-bit modular arithmetic, the per-lane sum is in range)
-    is_uni = (unsigned)(roff * is_ld2) + (unsigned)((is_second ? is_cc - d.c_split : is_cc) * 2);
-    is_wsoff = (is_tap * d.Cin + is_cc) * 2;                 // == is_j * 64: K offset of this half-step (scalar)
+    // (readfirstlane: these are wave-uniform by construction; it keeps the compiler from wrapping the loads in a
+    // waterfall loop when it has routed the arithmetic through vector registers)
+    is_so_a = __builtin_amdgcn_readfirstlane((unsigned)(roff * is_ld2) + (unsigned)((is_second ? is_cc - d.c_split : is_cc) * 2));
+    is_so_w = __builtin_amdgcn_readfirstlane((unsigned)((is_tap * d.Cin + is_cc) * 2));
   };
   auto issue_a = [&](int q) {
-    if (dbg_nodma) return;
-    int row = a_row[q];
-    if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1)
-      const int oy = ((int)((a_mask[q] >> 16) & 1) + is_dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + is_dxo) >> 1;
-      row += oy * d.Wd + ox;
+    unsigned voff = is_second ? a_voff2[q] : a_voff[q];
+    if (MODE != 0) {
+      if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1), relative to the centre
+        const int oy = ((int)((a_mask[q] >> 16) & 1) + is_dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + is_dxo) >> 1;
+        voff += (unsigned)((oy * d.Wd + ox + d.Wd + 1) * is_ld2);
+      }
+      if (!((a_mask[q] >> is_tap) & 1u)) voff = kOOB;
     }
-    const bool ok = (a_mask[q] >> (MODE == 0 ? 0 : is_tap)) & 1u;
-    const unsigned voff = ok ? (unsigned)row * (unsigned)is_ld2 + coff + is_uni : kOOB;
     if (is_second)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, is_so_a, 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, is_so_a, 0, 0);
   };
   auto issue_b = [&](int q) {
-    if (dbg_nodma) return;
-    if (q * NW + wid < B_TOT)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(is_sb + (q * NW + wid) * 1024), 16, b_voff[q], is_wsoff,
-                                               0, 0);
+    if (!UNEVEN || q < B_Q - 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(is_sb + (q * NW + wid) * 1024), 16, b_voff[q], is_so_w, 0, 0);
+    } else {
+      char* dst = (q * NW + wid < B_TOT) ? is_sb + (q * NW + wid) * 1024 : smem + DUMMY_OFF + wid * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst), 16, b_voff[q], is_so_w, 0, 0);
+    }
   };
   auto issue_piece = [&](int pc) {
     if (pc < A_Q) issue_a(pc); else issue_b(pc - A_Q);
   };
   auto issue_end = [&]() {
-    ++is_j;
     is_cc += 32;
     if (is_cc == d.Cin) { is_cc = 0; ++is_tap; }
   };
   auto issue = [&](int g) {                                  // whole half-step at once (prologue)
     issue_begin(g);
 #pragma unroll
-    for (int q = 0; q < A_Q; ++q) issue_a(q);
-#pragma unroll
-    for (int q = 0; q < B_Q; ++q) issue_b(q);
+    for (int pc = 0; pc < NPIECE; ++pc) issue_piece(pc);
     issue_end();
+  };
+  auto next_tile = [&](int tile) {                           // the issue stream moves to `tile` (may be past the last
+    setup(tile);                                             // one: its rows are all invalid, the pieces read zeros)
+    is_tap = 0;
+    is_cc = 0;
   };
 
   const int sw = (r32 >> 2) & 3;
   const int a_frag = (wr * WTM + r32) * 64;
   const int b_frag = A_SLOT + (wc * WTN + r32) * 64;
-  // DMA pieces this wave issues per half-step (uniform per wave): A_Q + (B pieces)
-  const bool b_extra = (B_Q - 1) * NW + wid < B_TOT;         // true for all waves when B_TOT % 8 == 0
-  constexpr bool UNEVEN = (B_TOT % NW) != 0;
 
   // bias strip of this wave for the first tile (see pp_bias_load); its load is retired before any DMA is issued
-  char* const bias_lds = smem + NH * SLOT + wid * (WTN * 4);
+  char* const bias_lds = smem + BIAS_OFF + wid * (WTN * 4);
   {
     const int bn0 = (my_first % tiles_n) * BN;
     const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
     pp_bias_store<WTN>(bias_lds, b, lane);
   }
-  // ---- prologue: 3 half-steps in flight (total >= 2 always: Cin >= 64)
+  // ---- prologue: 3 half-steps in flight
+  int is_tile = my_first;
+  next_tile(is_tile);
   issue(0);
   issue(1);
-  if (total > 2) issue(2);
-  if (total > 2) { if (UNEVEN && !b_extra) wait_vmcnt<2 * (A_Q + B_Q - 1)>(); else wait_vmcnt<2 * (A_Q + B_Q)>(); }
-  else { if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>(); }
+  issue(2);
+  wait_vmcnt<2 * NPIECE>();
   raw_barrier();
-  if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
 
   f32x16 acc[TM][TN];
   int g = 0;
-#ifdef CTRLV_PP_STAMP
-  unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
-  STAMP(t_begin);
+  constexpr int HM = TM / 2;
+#if CTRLV_PP_SCHED == 1
+  // ================= STREAMED schedule: no wave groups, one barrier per half-step, fragments double-buffered at
+  // k16 granularity (the same 2 x (TM + TN) fragment registers as the ping-pong loop, used as two k16 buffers).
+  //   first half  of half-step g: MFMAs on F0 = frag(g, k16 0) while F1 = frag(g, k16 1) streams in from slot g;
+  //   middle                    : retire own DMA(g+1), s_barrier  -> slot g+1 complete, slot g-1 no longer read;
+  //   second half               : MFMAs on F1 while F0 = frag(g+1, k16 0) streams in from slot g+1.
+  // The DMA pieces of half-step g+3 (into slot (g-1)&3, whose last reads every wave retired before the barrier of
+  // half-step g-1) sit in the gaps of the MFMA groups.  Both waves of a SIMD run this same loop, so the matrix pipe is
+  // fed by whichever has operands ready; nobody alternates phases.
+  auto read_frags = [&](const char* st, int ks, bf16x8 (&af)[TM], bf16x8 (&wf)[TN]) {
+    const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) wf[n] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
+  };
+  bf16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
+  read_frags(smem, 0, af0, wf0);
+  constexpr int N1 = (NPIECE + 1) / 2;                       // pieces issued in the first half
+  auto half_step = [&](int j, bool last_of_tile, auto first_tag) {
+    constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
+    const char* st = smem + (g & (NH - 1)) * SLOT;
+    read_frags(st, 1, af1, wf1);
+    issue_begin(g + 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i0 = h * HM;
+      __builtin_amdgcn_s_setprio(1);
+      if (MAY_BE_FIRST && j == 0) {
+        f32x16 zero;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+#pragma unroll
+        for (int i = i0; i < i0 + HM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], zero, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = i0; i < i0 + HM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], acc[i][n], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < N1; ++k)
+        if (k * 2 / N1 == h) issue_piece(k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // middle: own DMA(g+1) retired (DMA(g+2) and the N1 pieces just issued may stay in flight), F1 landed
+    wait_vmcnt<NPIECE + N1>();
+    lds_done_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last_of_tile) read_frags(smem + ((g + 1) & (NH - 1)) * SLOT, 0, af0, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i0 = h * HM;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = i0; i < i0 + HM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[n], af1[i], acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NPIECE - N1; ++k)
+        if (k * 2 / (NPIECE - N1) == h) issue_piece(N1 + k);
+      if (h == 1) issue_end();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+#else
+  // ================= PING-PONG schedule (see the header of this file)
+  if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
+  auto half_step = [&](int j, bool /*last_of_tile*/, auto first_tag) {
+    constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
+    // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
+    const char* st = smem + (g & (NH - 1)) * SLOT;
+    bf16x8 af[TM][2], wf[TN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
+    }
+    // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
+    // cluster below.  Then retire own DMA(g+1): the pieces of g+2 and the NL pieces just issued may stay in flight.
+    issue_begin(g + 3);
+#pragma unroll
+    for (int pc = 0; pc < NL; ++pc) issue_piece(pc);
+    wait_vmcnt<NPIECE + NL>();
+    lds_done_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
+    // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
+#pragma unroll
+    for (int grpi = 0; grpi < 4; ++grpi) {
+      const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
+      __builtin_amdgcn_s_setprio(1);
+      if (MAY_BE_FIRST && j == 0 && ks == 0) {
+        f32x16 zero;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+#pragma unroll
+        for (int i = i0; i < i0 + HM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = i0; i < i0 + HM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k * 4 / NC == grpi) issue_piece(NL + k);
+      if (grpi == 3) issue_end();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // post-C barrier (pairs with the other group's post-L barrier)
+    raw_barrier();
+  };
 #endif
+
   for (int tr = 0; tr < my_ntiles; ++tr) {
     const int tile = my_first + tr * G;
     const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
-    for (int j = 0; j < J; ++j, ++g) {
-      // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
-      const char* st = smem + (g & (NH - 1)) * SLOT;
-      bf16x8 af[TM][2], wf[TN][2];
-      STAMP(t0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int coff = ((ks * 2 + hsel) ^ sw) * 16;
-#pragma unroll
-        for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff);
-      }
-      STAMP(t1);
-      // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
-      // cluster below.  Then retire own DMA(g+1): the pieces of g+2 and the NL pieces just issued may stay in flight.
-      const bool do_issue = g + 3 < total;
-      if (do_issue) {
-        issue_begin(g + 3);
-#pragma unroll
-        for (int pc = 0; pc < NL; ++pc) issue_piece(pc);
-        STAMP(t1b);
-        STAMP_ADD(c_lissue, t1, t1b);
-        if (UNEVEN && !b_extra) wait_vmcnt<NPIECE - 1 + NL>(); else wait_vmcnt<NPIECE + NL>();
-      } else if (g + 2 < total) {
-        if (UNEVEN && !b_extra) wait_vmcnt<A_Q + B_Q - 1>(); else wait_vmcnt<A_Q + B_Q>();
-      } else {
-        wait_vmcnt<0>();
-      }
-      STAMP(t2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      STAMP(t2b);
-      lds_done_barrier();
-      STAMP(t3);
-      STAMP_ADD(c_lread, t0, t1);
-      STAMP_ADD(c_lwait, t1, t2b);
-      STAMP_ADD(c_lbar, t2b, t3);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
-      // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
-#pragma unroll
-      for (int grpi = 0; grpi < 4; ++grpi) {
-        constexpr int HM = TM / 2;
-        const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
-        __builtin_amdgcn_s_setprio(1);
-        if (j == 0 && ks == 0) {
-          f32x16 zero;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-#pragma unroll
-          for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_issue) {
-#pragma unroll
-          for (int k = 0; k < NC; ++k)
-            if (k * 4 / NC == grpi) issue_piece(NL + k);
-          if (grpi == 3) issue_end();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      STAMP(t4);
-      // post-C barrier (pairs with the other group's post-L barrier)
-      raw_barrier();
-      STAMP(t5);
-      STAMP_ADD(c_mfma, t3, t4);
-      STAMP_ADD(c_cbar, t4, t5);
-    }
+    // The issue stream runs three half-steps ahead of the consuming one: it stays in this tile for J-3 half-steps and
+    // then moves to the block's next tile (two K loops, so that the per-tile lane state is loop-invariant in each --
+    // one loop with a conditional switch costs a dozen register copies per half-step).
+    for (int j = 0; j < J - 3; ++j, ++g) half_step(j, false, std::true_type{});
+    is_tile += G;
+    next_tile(is_tile);
+    for (int j = J - 3; j < J; ++j, ++g) half_step(j, j == J - 1, std::false_type{});
+#if CTRLV_PP_SCHED != 1
     // Tile boundary.  Group 0 takes one EXTRA barrier before its epilogue (it pairs with group 1's last post-C
     // barrier) and group 1 one after its epilogue (pairing with group 0's first post-L barrier of the next tile), so
     // that the two epilogues run CONCURRENTLY instead of each group stalling at a barrier for the whole epilogue of
     // the other (stamps: "C:barrier" was 1.3-2.5x the epilogue itself on the K = 320 layers).  The extra barrier also
     // orders group 0's staging writes after group 1's last load phase, which still reads those ring pieces.
     if (grp == 0) raw_barrier();
-    STAMP(t6);
+#endif
     {
-      // wave-private staging: this wave's own four DMA pieces of the slot consumed last (refilled only by this
-      // wave's DMA of half-step g+3, which it issues in ITS next compute phase, after this epilogue)
+      // wave-private staging: this wave's own four DMA pieces of the slot consumed last (every wave retired its reads
+      // of that slot before the last barrier; only this wave's own DMA, issued after this epilogue, refills them)
       char* s0 = smem + ((g - 1) & (NH - 1)) * SLOT;
       // bias columns of the next tile: loaded now, parked in the LDS strip after this epilogue's last bias read
       const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
@@ -599,24 +668,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) asm volatile("" : "=v"(acc[i][n]));
     }
-    STAMP(t7);
-    STAMP_ADD(c_epi, t6, t7);
+#if CTRLV_PP_SCHED == 1
+    if (tr + 1 < my_ntiles) {     // first fragments of the next tile (its slot was completed by the last barrier)
+      read_frags(smem + (g & (NH - 1)) * SLOT, 0, af0, wf0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#else
     if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
-  }
-#ifdef CTRLV_PP_STAMP
-  STAMP(t_end);
-  if (lane == 0 && d.V != nullptr && d.vmode == 0) {
-    unsigned long long* o = (unsigned long long*)d.V + ((long)blockIdx.x * 8 + wid) * 10;
-    o[0] = t_end - t_begin; o[1] = c_lread; o[2] = c_lissue; o[3] = c_lwait; o[4] = c_lbar; o[5] = c_mfma;
-    o[6] = c_cbar; o[7] = c_epi; o[8] = (unsigned long long)total; o[9] = (unsigned long long)my_ntiles;
-  }
 #endif
+  }
+  // the issue stream ran three half-steps past the end (zero-filled pieces): nothing may be in flight when the
+  // workgroup's LDS is released
+  wait_vmcnt<0>();
 #endif
 }
 
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
-  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4;   // DMA ring + one bias strip (BN / WN floats) per wave
+  // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
+  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0);
   static bool attr_set = false;
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI>;
   if (!attr_set) {

@@ -12,6 +12,14 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   if (d.R1 && (long)d.M * d.ldr1 * 2 > lim) return false;
   if (d.R2 && (long)d.M * d.ldr2 * 2 > lim) return false;
   if (d.vmode && pp_vtable_rows(d) * d.ldv * 4 > lim) return false;
+  {  // sources: 32-bit offsets as well (row offset + the tap-displacement bias the descriptor base is moved down by)
+    const long a_rows = d.mode == 1 ? (long)(d.M / (d.Ho * d.Wo)) * d.H * d.Wd : (long)d.M;
+    const long bias_rows = d.mode == 1 ? d.Wd + 1 : (d.mode == 2 ? d.S : 0);
+    const long ld = d.lda > d.lda2 ? d.lda : d.lda2;
+    if ((a_rows + 2 * bias_rows) * ld * 2 > lim) return false;
+    if ((long)d.N * d.taps * d.Cin * 2 > lim) return false;
+  }
+  if (d.taps * (d.Cin >> 5) < 4) return false;       // the DMA ring runs three half-steps ahead inside one tile
   if (d.geglu) return d.mode == 0;
   const int e = pp_epi_of(d);
   if (e < 0) return false;
