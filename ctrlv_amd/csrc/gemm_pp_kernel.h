@@ -310,12 +310,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
   // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue overlaps the matrix pipe).
   // Whichever phase is longer sets the slot time, so NL balances them: A/B on one device (tools/ab_build.py
-  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 1-2 of 5 for the 320-wide one (20 MFMAs).
+  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 2 of 5 for the 320-wide one (20 MFMAs).
   constexpr int NPIECE = A_Q + B_Q;
 #ifdef CTRLV_PP_NL
   constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
 #else
-  constexpr int NL = BN == 256 ? A_Q + 1 : (MODE == 1 ? A_Q - 1 : A_Q);   // 320-wide: conv 1 (+3 %), linear / temporal 2
+  constexpr int NL = BN == 256 ? A_Q + 1 : A_Q;
 #endif
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
   static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     // (readfirstlane: these are wave-uniform by construction; it keeps the compiler from wrapping the loads in a
     // waterfall loop when it has routed the arithmetic through vector registers)
     is_so_a = __builtin_amdgcn_readfirstlane((unsigned)(roff * is_ld2) + (unsigned)((is_second ? is_cc - d.c_split : is_cc) * 2));
-    is_so_w = __builtin_amdgcn_readfirstlane((unsigned)((is_tap * d.Cin + is_cc) * 2));
+    is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((MODE == 0 ? 0 : is_tap * d.Cin) + is_cc) * 2));
   };
   auto issue_a = [&](int q) {
     unsigned voff = is_second ? a_voff2[q] : a_voff[q];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   };
   auto issue_end = [&]() {
     is_cc += 32;
-    if (is_cc == d.Cin) { is_cc = 0; ++is_tap; }
+    if (MODE != 0 && is_cc == d.Cin) { is_cc = 0; ++is_tap; }   // (plain GEMM: one tap, next_tile() rewinds)
   };
   auto issue = [&](int g) {                                  // whole half-step at once (prologue)
     issue_begin(g);
