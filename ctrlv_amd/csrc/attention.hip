@@ -16,6 +16,10 @@
 
 #include "common.h"
 
+#ifndef CTRLV_ATTN_DBG
+#define CTRLV_ATTN_DBG 0
+#endif
+
 namespace {
 
 constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
@@ -212,10 +216,17 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   issue(0, 0);
   if (NSLOT == 3 && nt > 1) issue(1, 1);
   for (int t = 0; t < nt_full; ++t) {
+#if CTRLV_ATTN_DBG == 1          // diagnostic build: no K/V traffic, no workgroup sync after the first tile (wrong results)
+    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("s_barrier" ::: "memory"); }
+#elif CTRLV_ATTN_DBG == 2        // diagnostic build: K/V traffic but no workgroup barrier (wrong results)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + NSLOT - 1 < nt) issue(t + NSLOT - 1, (t + NSLOT - 1) % NSLOT);
+#else
     if (NSLOT == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (t + NSLOT - 1 < nt) issue(t + NSLOT - 1, (t + NSLOT - 1) % NSLOT);
+#endif
     tile(t, std::false_type{});
   }
   if (nt_full < nt) {      // ragged last tile: separate instantiation with key masking

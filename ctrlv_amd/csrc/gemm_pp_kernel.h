@@ -9,10 +9,12 @@
 //     (MI355X_MICROARCH "Two waves per SIMD"; guide T3/T4).
 //   * K advances in half-steps of 32; a ring of 4 LDS slots (4 x (256+BN) x 64 B) keeps 3 half-steps of LDS-DMA in
 //     flight across the raw s_barriers; waits are COUNTED (`s_waitcnt vmcnt(2*per_wave)`), never 0 in steady state.
-//   * hazards: slot of half-step j is read in phase L_j (group 0: slot 2j, group 1: slot 2j+1), re-filled by the DMA
-//     of half-step j+4 issued in L_{j+1}; every wave retires its own DMA(j+1) before the barrier that ends its L_j and
-//     finishes its ds_reads (lgkmcnt(0)) before that same barrier -- RAW and WAR are each separated by >= 1 barrier
-//     that all 8 waves pass.
+//   * hazards: the ring slot of half-step j is read in phase L_j (group 0 in barrier slot 2j, group 1 in 2j+1) and
+//     re-filled by the DMA of half-step j+4, issued in L_{j+1} / C_{j+1}; every wave retires its own DMA(j+1) before
+//     the barrier that ends its L_j and finishes its ds_reads (lgkmcnt(0)) before that same barrier -- RAW and WAR are
+//     each separated by >= 1 barrier that all 8 waves pass.  The issue stream simply runs three half-steps past the
+//     block's last tile (all rows out of range: zeros, no memory traffic), so the loop has no tail cases.
+//   * the hot loop is instruction-issue-bound: lane offsets are per tile, a half-step adds scalars.
 //   * 64-B LDS rows (32 bf16): physical 16-B chunk = logical ^ ((row>>2)&3) keeps ds_read_b128 conflict-free; the
 //     swizzle is applied on the per-lane DMA source address.
 //   * PERSISTENT: one workgroup per CU walks its tiles (XCD-contiguous windows) and the DMA ring runs straight
@@ -497,6 +499,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   f32x16 acc[TM][TN];
   int g = 0;
   constexpr int HM = TM / 2;
+#ifdef CTRLV_PP_STAMP
+  unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
+  STAMP(t_begin);
+#endif
 #if CTRLV_PP_SCHED == 1
   // ================= STREAMED schedule: no wave groups, one barrier per half-step, fragments double-buffered at
   // k16 granularity (the same 2 x (TM + TN) fragment registers as the ping-pong loop, used as two k16 buffers).
@@ -579,6 +585,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
     const char* st = smem + (g & (NH - 1)) * SLOT;
     bf16x8 af[TM][2], wf[TN][2];
+    STAMP(t0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
@@ -587,13 +594,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
     }
+    STAMP(t1);
     // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
     // cluster below.  Then retire own DMA(g+1): the pieces of g+2 and the NL pieces just issued may stay in flight.
     issue_begin(g + 3);
 #pragma unroll
     for (int pc = 0; pc < NL; ++pc) issue_piece(pc);
+    STAMP(t1b);
     wait_vmcnt<NPIECE + NL>();
+    STAMP(t2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(t2b);
     lds_done_barrier();
+    STAMP(t3);
+    STAMP_ADD(c_lread, t0, t1);
+    STAMP_ADD(c_lissue, t1, t1b);
+    STAMP_ADD(c_lwait, t1b, t2b);
+    STAMP_ADD(c_lbar, t2b, t3);
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
     // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
@@ -625,8 +642,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       if (grpi == 3) issue_end();
       __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(t4);
     // post-C barrier (pairs with the other group's post-L barrier)
     raw_barrier();
+    STAMP(t5);
+    STAMP_ADD(c_mfma, t3, t4);
+    STAMP_ADD(c_cbar, t4, t5);
   };
 #endif
 
@@ -648,6 +669,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     // orders group 0's staging writes after group 1's last load phase, which still reads those ring pieces.
     if (grp == 0) raw_barrier();
 #endif
+    STAMP(t6);
     {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (every wave retired its reads
       // of that slot before the last barrier; only this wave's own DMA, issued after this epilogue, refills them)
@@ -668,6 +690,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) asm volatile("" : "=v"(acc[i][n]));
     }
+    STAMP(t7);
+    STAMP_ADD(c_epi, t6, t7);
 #if CTRLV_PP_SCHED == 1
     if (tr + 1 < my_ntiles) {     // first fragments of the next tile (its slot was completed by the last barrier)
       read_frags(smem + (g & (NH - 1)) * SLOT, 0, af0, wf0);
@@ -680,6 +704,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // the issue stream ran three half-steps past the end (zero-filled pieces): nothing may be in flight when the
   // workgroup's LDS is released
   wait_vmcnt<0>();
+#ifdef CTRLV_PP_STAMP
+  STAMP(t_end);
+  if (lane == 0 && d.V != nullptr && d.vmode == 0) {
+    unsigned long long* o = (unsigned long long*)d.V + ((long)blockIdx.x * 8 + wid) * 10;
+    o[0] = t_end - t_begin; o[1] = c_lread; o[2] = c_lissue; o[3] = c_lwait; o[4] = c_lbar; o[5] = c_mfma;
+    o[6] = c_cbar; o[7] = c_epi; o[8] = (unsigned long long)my_ntiles * J; o[9] = (unsigned long long)my_ntiles;
+  }
+#endif
 #endif
 }
 

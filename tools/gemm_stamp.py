@@ -46,7 +46,7 @@ def main():
               ("L0 conv3x3 320->320", N0, 320, 320, 9, 1, (72, 128, 72, 128, 1, 0), 6, 0),
               ("L1 conv3x3 1920->640", N1, 640, 1920, 9, 1, (36, 64, 36, 64, 1, 0), 6, 0),
               ("L1 geglu 640->5120", N1, 5120, 640, 1, 0, None, 5, 0)]
-    names = ["total", "L:ds_read issue", "L:dma issue", "L:vmcnt wait", "L:lgkm+barrier", "C:mfma", "C:barrier",
+    names = ["total", "L:ds_read issue", "L:dma issue", "L:vmcnt+lgkm wait", "L:barrier", "C:mfma+dma", "C:barrier",
              "epilogue"]
     for name, M, N, K, taps, mode, geo, tile, r1 in shapes:
         A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)

@@ -50,6 +50,6 @@ void run(int wps) {
 }
 
 int main() {
-  for (int w = 1; w <= 4; w *= 2) { run<4>(w); run<8>(w); run<10>(w); }
+  for (int w = 1; w <= 4; w *= 2) { run<1>(w); run<2>(w); run<4>(w); run<8>(w); run<10>(w); }
   return 0;
 }
