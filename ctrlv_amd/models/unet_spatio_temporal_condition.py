@@ -159,6 +159,9 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
             if len(down_block_additional_residuals) != len(taps):
                 raise ValueError(f"expected {len(taps)} down_block_additional_residuals, got "
                                  f"{len(down_block_additional_residuals)}")
+            fence = getattr(self, "_residual_fence", None)     # DenoiseStepper: the ControlNet ran on a side stream
+            if fence is not None:
+                fence()
             mk = ws.mark()
             for (s, sh, sw), r in zip(taps, down_block_additional_residuals):
                 ops.axpby(s, self._residual_rows(ws, r, s.shape[0], s.shape[1]), 1.0, 1.0, s)

@@ -9,6 +9,7 @@ host, so a step is `ControlNet fwd + UNet fwd + 1 kernel + 2 small copies` with 
 VAE and CLIP are caller-supplied PyTorch-ROCm modules (out of the hot path, once per clip).
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Union
 
@@ -355,6 +356,8 @@ class DenoiseStepper:
         self.set_latents(self.latents, 0)
         self.t_dev = torch.zeros((), dtype=torch.float32, device=device)
         self.use_hip_graph = use_hip_graph
+        self.overlap_controlnet = os.environ.get("CTRLV_OVERLAP", "1") != "0"
+        self._side = None
         self._graph = None
         self._noise_pred = None
         self._eager_runs = 0
@@ -364,15 +367,35 @@ class DenoiseStepper:
         s = self.scheduler.sigma_at(sigma_index)
         self.scaled.copy_(self.latents / math.sqrt(s ** 2 + 1))
 
-    def _forward(self, t):
+    def _forward(self, t, overlap=False):
+        """ControlNet forward then UNet forward.  With `overlap` (HIP-graph mode) the ControlNet runs on a side stream
+        concurrently with the UNet's down / mid blocks -- the two are independent until the residual adds of
+        unet_spatio_temporal_condition.py:119-127 -- and the UNet joins the side stream right before it consumes the
+        residuals.  The GEMMs are persistent kernels with one workgroup per CU, so when one model's kernel reaches
+        its last, partially filled round of tiles (12 % of the N = C layers: 1800 tiles on 256 CUs) the idle CUs pick
+        up the other model's workgroups instead of waiting."""
         down = mid = None
-        if self.controlnet is not None:
-            down, mid = self.controlnet(self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
-                                        added_time_ids=self.added_time_ids, control_cond=self.cond_em,
-                                        conditioning_scale=self.control_scale, return_dict=False)
-        return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
-                         added_time_ids=self.added_time_ids, down_block_additional_residuals=down,
-                         mid_block_additional_residuals=mid, return_dict=False)[0]
+        if self.controlnet is None:
+            return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
+                             added_time_ids=self.added_time_ids, return_dict=False)[0]
+        kw = dict(timestep=t, encoder_hidden_states=self.image_embeddings, added_time_ids=self.added_time_ids,
+                  control_cond=self.cond_em, conditioning_scale=self.control_scale, return_dict=False)
+        if not overlap:
+            down, mid = self.controlnet(self.lmi, **kw)
+        else:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.latents.device)
+            self._side.wait_stream(main)                      # fork (inputs were written on the main stream)
+            with torch.cuda.stream(self._side):
+                down, mid = self.controlnet(self.lmi, **kw)
+            self.unet._residual_fence = lambda: main.wait_stream(self._side)     # join, called by the UNet
+        try:
+            return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
+                             added_time_ids=self.added_time_ids, down_block_additional_residuals=down,
+                             mid_block_additional_residuals=mid, return_dict=False)[0]
+        finally:
+            self.unet._residual_fence = None
 
     def step(self, i):
         B, c = self.B, self.c_lat
@@ -392,7 +415,7 @@ class DenoiseStepper:
                     torch.cuda.synchronize()
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph):
-                        self._noise_pred = self._forward(self.t_dev)
+                        self._noise_pred = self._forward(self.t_dev, overlap=self.overlap_controlnet)
                 self._graph.replay()
                 noise_pred = self._noise_pred
         ops.cfg_euler_step(self.latents, noise_pred.contiguous(), self.guidance, self.scheduler.sigma_at(i),

@@ -113,7 +113,7 @@ def test_box2video_pipeline_matches_oracle_loop(hip_lib):
                generator=torch.Generator().manual_seed(0), output_type="latent").frames
     assert out.shape == (1, 3, 4, 16, 16)
     assert rel_l2(out, ref) < 5e-2
-    # HIP-graph replay of the two forwards gives bit-identical latents
+    # HIP-graph replay (ControlNet on a side stream, concurrent with the UNet down path) gives bit-identical latents
     pipe.use_hip_graph = True
     out_g = pipe(image.to(DEV, torch.bfloat16), cond_images=cond.to(DEV), height=128, width=128, num_frames=3,
                  num_inference_steps=3, noise_aug_strength=0.0, latents=latents.to(DEV, torch.bfloat16),
