@@ -251,6 +251,193 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   }
 }
 
+// ---------------------------------------------------------------------------------------------- spatial, 64 rows / wave
+// Same algorithm with TWO 32-row query blocks per wave (256 queries per workgroup): every K / V^T fragment read from
+// LDS feeds two MFMAs, the per-tile loop / DMA / barrier overhead is shared by 32 MFMAs instead of 16, and a wave
+// carries four independent accumulator chains.  The spatial kernel is bound by instruction issue around the MFMAs
+// (SQ counters: MFMA busy 36 %, LDS and VMEM waits negligible; no-traffic diagnostic build only +10 %), so fewer
+// instructions per MFMA is what moves it.  ~200 VGPRs => 2 waves per SIMD.
+__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              int S, int C) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const long row0 = (long)img * S;
+  const int ld = 3 * C;
+  const bf16_t* qp = qkv + head * 64;
+
+  int qrow[2];
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    qrow[rb] = blockIdx.x * 256 + wid * 64 + rb * 32 + r32;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qrow[rb] < S) v = *(const uint4*)(qp + (row0 + qrow[rb]) * ld + 16 * ks + 8 * hsel);
+      qf[rb][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  const int prow = lane >> 3, pslot = lane & 7;
+  const __amdgpu_buffer_rsrc_t rs_kv =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + row0 * ld), 0, (int)((long)S * ld * 2), 0x00020000);
+  const int rt0 = wid * 8 + prow;
+  const unsigned koff = (unsigned)(rt0 * ld + C + head * 64 + (pslot ^ ((rt0 >> 1) & 7)) * 8) * 2u;
+  const unsigned voff = (unsigned)(rt0 * ld + 2 * C + head * 64 + (pslot ^ (((rt0 >> 1) & 1) << 2)) * 8) * 2u;
+  const int tile_bytes = 64 * ld * 2;
+  auto issue = [&](int t, int stage) {
+    char* ks_ = smem + stage * 16384;
+    char* vs_ = ks_ + 8192;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int so = t * tile_bytes + q * (tile_bytes >> 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, koff, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, voff, so, 0, 0);
+    }
+  };
+
+  f32x16 oacc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[rb][dt][e] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  const int i16 = lane & 15;
+  const int vkey = 4 * hsel + (i16 >> 2);
+  const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+
+  constexpr float kSumLimit = 4096.0f;
+  auto scores = [&](const char* kst, f32x16 (&sacc)[2][2], int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[rb][kt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          sacc[rb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sacc[rb][kt], 0, 0, 0);
+      }
+      if (kt == 0) asm volatile("" ::: "memory");   // keep the second half's K fragments out of flight (registers)
+    }
+    if (MASKED) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = t * 64 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
+            if (key >= S) sacc[rb][kt][e] = -INFINITY;
+          }
+    }
+  };
+  auto exp_sum = [&](f32x16 (&sacc)[2], float m) -> float {
+    f32x2_t rs2 = {0.f, 0.f};
+    const f32x2_t nm = {-m, -m};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        f32x2_t x = {sacc[kt][e], sacc[kt][e + 1]};
+        x = x * kScaleLog2 + nm;
+        f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+        sacc[kt][e] = pe.x;
+        sacc[kt][e + 1] = pe.y;
+        rs2 += pe;
+      }
+    return rs2.x + rs2.y;
+  };
+  auto tile = [&](int t, auto masked_tag) {
+    const char* kst = smem + (t & 1) * 16384;
+    const char* vst = kst + 8192;
+    f32x16 sacc[2][2];
+    scores(kst, sacc, t, masked_tag);
+    float rs[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) rs[rb] = exp_sum(sacc[rb], m_run[rb]);
+    if (!__all(rs[0] <= kSumLimit && rs[1] <= kSumLimit)) {       // slow path: see attn_spatial_kernel
+      scores(kst, sacc, t, masked_tag);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float mx = sacc[rb][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[rb][kt][e]);
+        mx = half_max(mx) * kScaleLog2;
+        const float m_new = fmaxf(m_run[rb], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
+        rs[rb] = exp_sum(sacc[rb], m_run[rb]);
+      }
+    }
+    l_run[0] += rs[0];
+    l_run[1] += rs[1];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf0 = pack_p(sacc[0][kt], s), pf1 = pack_p(sacc[1][kt], s);
+        const int kb = kt * 32 + 16 * s + vkey;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0, oacc[0][dt], 0, 0, 0);
+          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1, oacc[1][dt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const int nt = (S + 63) / 64;
+  const int nt_full = S / 64;
+  issue(0, 0);
+  for (int t = 0; t < nt_full; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    tile(t, std::false_type{});
+  }
+  if (nt_full < nt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    tile(nt_full, std::true_type{});
+  }
+
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const float inv = 1.0f / half_sum(l_run[rb]);
+    if (qrow[rb] < S) {
+      bf16_t* op = out + (row0 + qrow[rb]) * C + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dcol = dt * 32 + 8 * q + 4 * hsel;
+          uint2 pk = make_uint2(pack_bf16x2(oacc[rb][dt][4 * q] * inv, oacc[rb][dt][4 * q + 1] * inv),
+                                pack_bf16x2(oacc[rb][dt][4 * q + 2] * inv, oacc[rb][dt][4 * q + 3] * inv));
+          *(uint2*)(op + dcol) = pk;
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- temporal
 __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             int B, int F, int S, int C) {
@@ -353,6 +540,20 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
   CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
   CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
+  // 64 query rows per wave on the long sequences; CTRLV_ATTN_ROWS=32|64 forces one (A/B, tests)
+  static int rows = 0;
+  if (rows == 0) {
+    const char* e = getenv("CTRLV_ATTN_ROWS");
+    rows = (e && e[0] == '3') ? 32 : (e && e[0] == '6') ? 64 : -1;
+  }
+  const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
+  if (use64) {
+    dim3 grid64((S + 255) / 256, C / 64, n_img);
+    hipLaunchKernelGGL(attn_spatial64_kernel, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)out, S, C);
+    CTRLV_LAUNCH_CHECK();
+    return CTRLV_OK;
+  }
   dim3 grid((S + 127) / 128, C / 64, n_img);
   // K/V ring depth: 2 slots (32 KiB LDS, 4 waves/SIMD) measured 883 TFLOP/s at S = 9216 against 810 for 3 slots (two
   // tiles of LDS-DMA in flight but 3 waves/SIMD): occupancy beats prefetch depth for this VALU-heavy d = 64 kernel.

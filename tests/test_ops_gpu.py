@@ -268,7 +268,10 @@ def _sdpa_ref(q, k, v):        # [batch, heads, S, 64] fp32
     return F.scaled_dot_product_attention(q, k, v)
 
 
-@pytest.mark.parametrize("n_img,S,C", [(3, 200, 128), (2, 576, 64), (1, 2304, 320), (5, 16, 128), (2, 4, 64)])
+# S >= 1024 runs the 64-rows-per-wave kernel (2304: full tiles; 1100: ragged last key tile and a partly empty last
+# 256-query block), shorter sequences the 32-row one
+@pytest.mark.parametrize("n_img,S,C", [(3, 200, 128), (2, 576, 64), (1, 2304, 320), (2, 1100, 128), (5, 16, 128),
+                                       (2, 4, 64)])
 def test_attention_spatial(ops, n_img, S, C):
     heads = C // 64
     qkv = bf(torch.randn(n_img * S, 3 * C, generator=g(1)))
@@ -280,12 +283,14 @@ def test_attention_spatial(ops, n_img, S, C):
     assert rel_l2(out, ref) < 5e-3
 
 
-def test_attention_spatial_peaked(ops):
-    """Online-softmax rescale path: one key dominates late in the sequence (running max jumps at a later tile)."""
-    n_img, S, C = 1, 320, 64
+@pytest.mark.parametrize("S,kpk", [(320, 300), (1280, 1200)])
+def test_attention_spatial_peaked(ops, S, kpk):
+    """Online-softmax rescale path: one key dominates late in the sequence (running max jumps at a later tile); both the
+    32-row (S = 320) and the 64-row (S = 1280) kernels."""
+    n_img, C = 1, 64
     qkv = torch.randn(S, 3 * C, generator=g(1))
     qkv[:, :64] *= 3.0
-    qkv[300, 64:128] = qkv[7, :64] * 4.0          # key 300 aligned with query 7
+    qkv[kpk, 64:128] = qkv[7, :64] * 4.0          # key kpk aligned with query 7
     qkv = bf(qkv)
     f = qkv.float().reshape(1, S, 3, 1, 64)
     q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
