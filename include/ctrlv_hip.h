@@ -51,7 +51,8 @@ int ctrlv_last_error(char* buf, size_t n);
  *
  * A, A2, R1, R2, out(bf16) are bf16; W is bf16 [N][taps*Cin] (K contiguous, tap-major); bias, V are fp32.
  * Epilogue, in fp32:  v = s_acc*(acc + bias[n]) + s1*R1[m,n] + s2*R2[m,n] + V[vidx(m), n];  v = silu(v) if act;
- * GEGLU (geglu=1): weight rows are interleaved in blocks of 16 (value block, gate block); out[m, j] = a_j * gelu_erf(g_j),
+ * GEGLU (geglu=1): weight rows are interleaved in blocks of 16 (value block, gate block); out[m, j] = a_j * gelu_erf(g_j)
+ * (erf-GELU x*Phi(x) evaluated in fp32 by a polynomial, |absolute error| <= 2.1e-6 -- csrc/common.h),
  * out has N/2 columns.  This fuses AlphaBlender, residual adds, the temb broadcast add, the frame
  * positional embedding and the degenerate 1-key CLIP cross-attention (a row vector per clip) into the GEMM.
  * ------------------------------------------------------------------------------------------------------------------ */
