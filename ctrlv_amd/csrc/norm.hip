@@ -32,7 +32,22 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   float sm[8], sq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
-  for (int r = r0 + rsub; r < r1; r += s.RPP) {
+  // four rows per trip: four independent 16-byte loads in flight per lane (HBM latency ~1 us; one load per trip left
+  // the kernel latency-bound at 3.6 TB/s)
+  int r = r0 + rsub;
+  for (; r + 3 * s.RPP < r1; r += 4 * s.RPP) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r + u * s.RPP, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack_bf16x8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+    }
+  }
+  for (; r < r1; r += s.RPP) {
     const uint4 v = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0);
     float f[8];
     unpack_bf16x8(v, f);
@@ -106,9 +121,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   }
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
-  for (int r = r0 + rsub; r < r1; r += s.RPP) {
-    const long row = (long)n * s.S + r;
-    const uint4 v = gn_load(x, x2, s.c_split, s.C, row, c0);
+  auto apply_row = [&](const uint4& v, long row) {
     float f[8];
     unpack_bf16x8(v, f);
 #pragma unroll
@@ -117,7 +130,16 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
       f[e] = silu ? silu_f(t) : t;
     }
     *(uint4*)(y + row * s.C + c0) = pack_bf16x8(f);
+  };
+  int r = r0 + rsub;
+  for (; r + 3 * s.RPP < r1; r += 4 * s.RPP) {      // four loads in flight per lane, as in the statistics pass
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r + u * s.RPP, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) apply_row(v[u], (long)n * s.S + r + u * s.RPP);
   }
+  for (; r < r1; r += s.RPP) apply_row(gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0), (long)n * s.S + r);
 }
 
 int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x2, GnShape* s) {
