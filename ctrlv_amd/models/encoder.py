@@ -58,6 +58,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         self.mid_block = UNetMidBlockSpatioTemporal(boc[-1], time_embed_dim, heads[-1], cross[-1])
         self._packed = False
         self._ws = None
+        self._wss = {}
 
     # ------------------------------------------------------------------------------------------- packing
     def _apply(self, fn, *a, **k):          # .to() / .cuda() / .half() invalidate the packed weights
@@ -132,10 +133,16 @@ class SpatioTemporalEncoderBase(HipModelMixin):
             raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
         if not self._packed:
             self.pack()
-        if self._ws is None or self._ws.device != sample.device:
-            self._ws = Workspace(sample.device)
-        self._ws.reset()
-        return self._ws
+        # one activation arena per execution lane: DenoiseStepper runs the two CFG halves of a step as concurrent
+        # forwards of this one model (shared packed weights) on different streams
+        lane = getattr(self, "_lane", 0)
+        ws = self._wss.get(lane)
+        if ws is None or ws.device != sample.device:
+            ws = self._wss[lane] = Workspace(sample.device)
+        if lane == 0:
+            self._ws = ws
+        ws.reset()
+        return ws
 
     # ------------------------------------------------------------------------------------------- embeddings
     @staticmethod

@@ -357,6 +357,9 @@ class DenoiseStepper:
         self.t_dev = torch.zeros((), dtype=torch.float32, device=device)
         self.use_hip_graph = use_hip_graph
         self.overlap_controlnet = os.environ.get("CTRLV_OVERLAP", "1") != "0"
+        # measured on MI355X: four concurrent half-batch forwards are 9 % SLOWER than two full-batch ones (258.8 ->
+        # 282.0 ms/step): twice the kernels, every weight tile fetched twice, L2 shared four ways.  Opt-in only.
+        self.split_cfg = self.overlap_controlnet and os.environ.get("CTRLV_SPLIT_CFG", "0") == "1"
         self._side = None
         self._graph = None
         self._noise_pred = None
@@ -367,35 +370,56 @@ class DenoiseStepper:
         s = self.scheduler.sigma_at(sigma_index)
         self.scaled.copy_(self.latents / math.sqrt(s ** 2 + 1))
 
-    def _forward(self, t, overlap=False):
-        """ControlNet forward then UNet forward.  With `overlap` (HIP-graph mode) the ControlNet runs on a side stream
-        concurrently with the UNet's down / mid blocks -- the two are independent until the residual adds of
-        unet_spatio_temporal_condition.py:119-127 -- and the UNet joins the side stream right before it consumes the
-        residuals.  The GEMMs are persistent kernels with one workgroup per CU, so when one model's kernel reaches
-        its last, partially filled round of tiles (12 % of the N = C layers: 1800 tiles on 256 CUs) the idle CUs pick
-        up the other model's workgroups instead of waiting."""
-        down = mid = None
-        if self.controlnet is None:
-            return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
-                             added_time_ids=self.added_time_ids, return_dict=False)[0]
-        kw = dict(timestep=t, encoder_hidden_states=self.image_embeddings, added_time_ids=self.added_time_ids,
-                  control_cond=self.cond_em, conditioning_scale=self.control_scale, return_dict=False)
-        if not overlap:
-            down, mid = self.controlnet(self.lmi, **kw)
-        else:
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.latents.device)
-            self._side.wait_stream(main)                      # fork (inputs were written on the main stream)
-            with torch.cuda.stream(self._side):
-                down, mid = self.controlnet(self.lmi, **kw)
-            self.unet._residual_fence = lambda: main.wait_stream(self._side)     # join, called by the UNet
+    def _forward(self, t, overlap=False, split=False):
+        """ControlNet forward then UNet forward.
+
+        `overlap` (HIP-graph mode): the ControlNet runs on a side stream concurrently with the UNet's down / mid blocks
+        -- the two are independent until the residual adds of unet_spatio_temporal_condition.py:119-127 -- and the UNet
+        joins the side stream right before it consumes the residuals.  `split`: the two classifier-free-guidance
+        halves of the batch (independent everywhere: a batch-2 forward is bit-identical to two batch-1 forwards) run
+        as separate forwards, with `overlap` on their own streams.  The GEMMs are persistent kernels with one
+        workgroup per CU, so when one forward's kernel reaches its last, partially filled round of tiles (12 % of the
+        N = C layers: 1800 tiles on 256 CUs) the idle CUs pick up another forward's workgroups instead of waiting."""
+        nb = self.lmi.shape[0]
+        parts = [(0, nb)]
+        if split and nb >= 2 and nb % 2 == 0:
+            parts = [(0, nb // 2), (nb // 2, nb)]
+        main = torch.cuda.current_stream()
+        if overlap and self._side is None:
+            self._side = [torch.cuda.Stream(device=self.latents.device) for _ in range(3)]
+        outs = []
         try:
-            return self.unet(sample=self.lmi, timestep=t, encoder_hidden_states=self.image_embeddings,
-                             added_time_ids=self.added_time_ids, down_block_additional_residuals=down,
-                             mid_block_additional_residuals=mid, return_dict=False)[0]
+            for k, (a, b) in enumerate(parts):
+                su = main if (k == 0 or not overlap) else self._side[0]           # UNet stream of this part
+                sc = su if not overlap else self._side[1 + k]                     # its ControlNet stream
+                if overlap:
+                    if su is not main:
+                        su.wait_stream(main)                                      # fork (inputs written on main)
+                    sc.wait_stream(main)
+                down = mid = None
+                if self.controlnet is not None:
+                    self.controlnet._lane = k
+                    with torch.cuda.stream(sc):
+                        down, mid = self.controlnet(
+                            self.lmi[a:b], timestep=t, encoder_hidden_states=self.image_embeddings[a:b],
+                            added_time_ids=self.added_time_ids[a:b], control_cond=self.cond_em[a:b],
+                            conditioning_scale=self.control_scale, return_dict=False)
+                self.unet._lane = k
+                self.unet._residual_fence = (lambda su=su, sc=sc: su.wait_stream(sc)) if sc is not su else None
+                with torch.cuda.stream(su):
+                    outs.append(self.unet(sample=self.lmi[a:b], timestep=t,
+                                          encoder_hidden_states=self.image_embeddings[a:b],
+                                          added_time_ids=self.added_time_ids[a:b],
+                                          down_block_additional_residuals=down, mid_block_additional_residuals=mid,
+                                          return_dict=False)[0])
+                if su is not main:
+                    main.wait_stream(su)                                          # join
         finally:
             self.unet._residual_fence = None
+            self.unet._lane = 0
+            if self.controlnet is not None:
+                self.controlnet._lane = 0
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     def step(self, i):
         B, c = self.B, self.c_lat
@@ -408,14 +432,16 @@ class DenoiseStepper:
         else:
             self.t_dev.copy_(t)
             if self._graph is None and self._eager_runs < 1:
-                noise_pred = self._forward(self.t_dev)        # warm-up: sizes workspaces, packs weights
+                # warm-up: sizes the workspaces of every lane, packs weights
+                noise_pred = self._forward(self.t_dev, split=self.split_cfg)
                 self._eager_runs += 1
             else:
                 if self._graph is None:
                     torch.cuda.synchronize()
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph):
-                        self._noise_pred = self._forward(self.t_dev, overlap=self.overlap_controlnet)
+                        self._noise_pred = self._forward(self.t_dev, overlap=self.overlap_controlnet,
+                                                         split=self.split_cfg)
                 self._graph.replay()
                 noise_pred = self._noise_pred
         ops.cfg_euler_step(self.latents, noise_pred.contiguous(), self.guidance, self.scheduler.sigma_at(i),
