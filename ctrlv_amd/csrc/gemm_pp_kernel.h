@@ -28,6 +28,12 @@
 
 #include "common.h"
 
+// s_setprio around the MFMA groups measured 0.5-1 % SLOWER than none (each is an issue slot in an issue-bound loop)
+#ifdef CTRLV_PP_PRIO
+#define PP_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PP_SETPRIO(x)
+#endif
 #ifndef CTRLV_PP_SCHED
 #define CTRLV_PP_SCHED 0      // 0: ping-pong wave groups, 1: streamed (both documented at the kernel)
 #endif
@@ -298,7 +304,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
   }
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
+// HAS_A2: the launch has a second A source for channels >= c_split (skip concat).  Only the plain-GEMM / bias-only
+// combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
+// output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   auto issue_begin = [&](int g) {
     is_sa = smem + (g & (NH - 1)) * SLOT;
     is_sb = is_sa + A_SLOT;
-    is_second = d.A2 != nullptr && is_cc >= d.c_split;
+    is_second = HAS_A2 && is_cc >= d.c_split;
     is_ld2 = (is_second ? d.lda2 : d.lda) * 2;               // row pitch in bytes of the active source
     int roff = 0;                                            // tap displacement in rows, biased to be >= 0
     if (MODE == 1) {
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((MODE == 0 ? 0 : is_tap * d.Cin) + is_cc) * 2));
   };
   auto issue_a = [&](int q) {
-    unsigned voff = is_second ? a_voff2[q] : a_voff[q];
+    unsigned voff = (HAS_A2 && is_second) ? a_voff2[q] : a_voff[q];
     if (MODE != 0) {
       if (MODE == 1 && d.up) {   // nearest x2: source = ((yo + dy - 1) >> 1, (xo + dx - 1) >> 1), relative to the centre
         const int oy = ((int)((a_mask[q] >> 16) & 1) + is_dyo) >> 1, ox = ((int)((a_mask[q] >> 17) & 1) + is_dxo) >> 1;
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       }
       if (!((a_mask[q] >> is_tap) & 1u)) voff = kOOB;
     }
-    if (is_second)
+    if (HAS_A2 && is_second)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, is_so_a, 0, 0);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(is_sa + (q * NW + wid) * 1024), 16, voff, is_so_a, 0, 0);
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int i0 = h * HM;
-      __builtin_amdgcn_s_setprio(1);
+      PP_SETPRIO(1);
       if (MAY_BE_FIRST && j == 0) {
         f32x16 zero;
 #pragma unroll
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
           for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], acc[i][n], 0, 0, 0);
       }
-      __builtin_amdgcn_s_setprio(0);
+      PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < N1; ++k)
@@ -562,12 +571,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int i0 = h * HM;
-      __builtin_amdgcn_s_setprio(1);
+      PP_SETPRIO(1);
 #pragma unroll
       for (int i = i0; i < i0 + HM; ++i)
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[n], af1[i], acc[i][n], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NPIECE - N1; ++k)
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #pragma unroll
     for (int grpi = 0; grpi < 4; ++grpi) {
       const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
-      __builtin_amdgcn_s_setprio(1);
+      PP_SETPRIO(1);
       if (MAY_BE_FIRST && j == 0 && ks == 0) {
         f32x16 zero;
 #pragma unroll
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
           for (int n = 0; n < TN; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
       }
-      __builtin_amdgcn_s_setprio(0);
+      PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NC; ++k)
@@ -715,12 +724,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
   constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0);
   static bool attr_set = false;
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2>;
   if (!attr_set) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -750,7 +759,11 @@ inline int pp_epi_of(const ctrlv_gemm_desc& d) {
 template <int BN, int WM, int WN, int MODE>
 int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   switch (pp_epi_of(d)) {
-    case 0: return launch_one<BN, WM, WN, MODE, false, 0>(d, persistent, stream);
+    case 0:
+      if constexpr (MODE == 0) {
+        if (d.A2) return launch_one<BN, WM, WN, MODE, false, 0, true>(d, persistent, stream);
+      }
+      return launch_one<BN, WM, WN, MODE, false, 0>(d, persistent, stream);
     case 1: return launch_one<BN, WM, WN, MODE, false, 1>(d, persistent, stream);
     case 2: return launch_one<BN, WM, WN, MODE, false, 2>(d, persistent, stream);
     case 3:

@@ -20,6 +20,8 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
     if ((long)d.N * d.taps * d.Cin * 2 > lim) return false;
   }
   if (d.taps * (d.Cin >> 5) < 4) return false;       // the DMA ring runs three half-steps ahead inside one tile
+  // a second A source (skip concat) is instantiated for the plain GEMM with a bias-only epilogue (1x1 shortcut convs)
+  if (d.A2 && !(d.mode == 0 && !d.geglu && pp_epi_of(d) == 0)) return false;
   if (d.geglu) return d.mode == 0;
   const int e = pp_epi_of(d);
   if (e < 0) return false;

@@ -58,7 +58,8 @@ int ctrlv_last_error(char* buf, size_t n);
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ctrlv_gemm_desc {
   const void* A;      /* [rows, lda] bf16 */
-  const void* A2;     /* optional second source for channels >= c_split (skip-concat, torch.cat dim=1) or NULL */
+  const void* A2;     /* optional second source for channels >= c_split (skip-concat, torch.cat dim=1) or NULL;
+                         every mode accepts it (fast path: plain GEMM with a bias-only epilogue, the 1x1 shortcuts) */
   const void* W;      /* [N, taps*Cin] bf16 */
   void* out;          /* [M, ldo] bf16 (or fp32 if out_f32) */
   const float* bias;  /* [N] or NULL */
