@@ -150,9 +150,12 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
   s->n_img = n_img; s->S = S; s->C = C; s->imgs_per_stat = imgs_per_stat; s->c_split = c_split;
   s->CV = C / 8;
   s->RPP = s->CV >= 256 ? 1 : 256 / s->CV;
-  int target = 2048 / n_img; if (target < 1) target = 1;
-  int nc = (S + 63) / 64; if (nc > target) nc = target; if (nc < 1) nc = 1;
-  s->rows_per_chunk = (S + nc - 1) / nc;
+  // The row chunking -- and with it the order of every partial sum -- depends on the image size only, never on how
+  // many images are in the batch: a clip's statistics are bit-identical whether it is normalised alone or in a batch
+  // (clip independence, tests/test_fullsize_gpu.py).  ~1000-2000 workgroups at the cfg3 batch of 50 images:
+  // 256-row chunks at S = 9216, 64 at S = 2304, 32 below.
+  s->rows_per_chunk = S >= 4096 ? 256 : (S >= 1024 ? 64 : 32);
+  if (s->rows_per_chunk > S) s->rows_per_chunk = S;
   s->n_chunks = (S + s->rows_per_chunk - 1) / s->rows_per_chunk;
   return CTRLV_OK;
 }

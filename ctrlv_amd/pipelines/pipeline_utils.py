@@ -359,7 +359,8 @@ class DenoiseStepper:
         self.overlap_controlnet = os.environ.get("CTRLV_OVERLAP", "1") != "0"
         # measured on MI355X: four concurrent half-batch forwards are 9 % SLOWER than two full-batch ones (258.8 ->
         # 282.0 ms/step): twice the kernels, every weight tile fetched twice, L2 shared four ways.  Opt-in only.
-        self.split_cfg = self.overlap_controlnet and os.environ.get("CTRLV_SPLIT_CFG", "0") == "1"
+        self.split_cfg = (self.overlap_controlnet and os.environ.get("CTRLV_SPLIT_CFG", "0") == "1"
+                          and getattr(unet, "time_context_order", "sb") == "bs")
         self._side = None
         self._graph = None
         self._noise_pred = None
@@ -375,9 +376,11 @@ class DenoiseStepper:
 
         `overlap` (HIP-graph mode): the ControlNet runs on a side stream concurrently with the UNet's down / mid blocks
         -- the two are independent until the residual adds of unet_spatio_temporal_condition.py:119-127 -- and the UNet
-        joins the side stream right before it consumes the residuals.  `split`: the two classifier-free-guidance
-        halves of the batch (independent everywhere: a batch-2 forward is bit-identical to two batch-1 forwards) run
-        as separate forwards, with `overlap` on their own streams.  The GEMMs are persistent kernels with one
+        joins the side stream right before it consumes the residuals.  `split` (experiment, off by default): the two
+        classifier-free-guidance halves of the batch run as separate forwards, with `overlap` on their own streams.
+        NOTE: that is bit-identical to the batched forward only with time_context_order == "bs"; under the default
+        diffusers-0.27.2 ordering quirk ("sb") the temporal cross-attention of one half reads the other half's
+        embedding, which a split forward cannot reproduce.  The GEMMs are persistent kernels with one
         workgroup per CU, so when one forward's kernel reaches its last, partially filled round of tiles (12 % of the
         N = C layers: 1800 tiles on 256 CUs) the idle CUs pick up another forward's workgroups instead of waiting."""
         nb = self.lmi.shape[0]
