@@ -135,8 +135,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
       for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+#if CTRLV_ATTN_DBG == 5          // diagnostic build (timing only): no K.Q^T (K fragment reads + MFMAs)
+        sacc[kt][ks] = (float)lane;
+#else
         const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+#endif
       }
       // keep the four K fragments of the second 32-key half out of flight until the first half is consumed: the
       // kernel has to fit 128 VGPRs (4 waves per SIMD), and hoisting all eight costs 16 registers
@@ -160,8 +164,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         f32x2_t x = {sacc[kt][e], sacc[kt][e + 1]};
+#if CTRLV_ATTN_DBG == 3          // diagnostic build (timing only): no softmax arithmetic
+        f32x2_t pe = x;
+#else
         x = x * kScaleLog2 + nm;
         f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#endif
         sacc[kt][e] = pe.x;
         sacc[kt][e + 1] = pe.y;
         rs2 += pe;
@@ -201,8 +209,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+#if CTRLV_ATTN_DBG == 4          // diagnostic build (timing only): no P.V (V fragment reads + MFMAs)
+          asm volatile("" ::"v"(pf));
+#else
           const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+#endif
         }
       }
     }
@@ -328,7 +340,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
         for (int rb = 0; rb < 2; ++rb)
           sacc[rb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sacc[rb][kt], 0, 0, 0);
       }
+#ifdef CTRLV_ATTN64_SERIAL
       if (kt == 0) asm volatile("" ::: "memory");   // keep the second half's K fragments out of flight (registers)
+#endif
     }
     if (MASKED) {
 #pragma unroll
