@@ -96,14 +96,20 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   const unsigned koff = (unsigned)(rt0 * ld + C + head * 64 + (pslot ^ ((rt0 >> 1) & 7)) * 8) * 2u;
   const unsigned voff = (unsigned)(rt0 * ld + 2 * C + head * 64 + (pslot ^ (((rt0 >> 1) & 1) << 2)) * 8) * 2u;
   const int tile_bytes = 64 * ld * 2;
+  const int full_tiles = S / 64;
   auto issue = [&](int t, int stage) {
     char* ks_ = smem + stage * 16384;
     char* vs_ = ks_ + 8192;
+    // only the per-lane offset is range-checked: full tiles pass the tile offset as a scalar, the ragged last tile adds
+    // it to the lane offset so that keys >= S fall past num_records (zeros) instead of reading the next image
+    const bool ragged = t >= full_tiles;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int so = t * tile_bytes + q * (tile_bytes >> 1);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, koff, so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, voff, so, 0, 0);
+      const unsigned ko = ragged ? koff + (unsigned)so : koff, vo = ragged ? voff + (unsigned)so : voff;
+      const int sso = ragged ? 0 : so;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, ko, sso, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, vo, sso, 0, 0);
     }
   };
 
@@ -300,14 +306,20 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
   const unsigned koff = (unsigned)(rt0 * ld + C + head * 64 + (pslot ^ ((rt0 >> 1) & 7)) * 8) * 2u;
   const unsigned voff = (unsigned)(rt0 * ld + 2 * C + head * 64 + (pslot ^ (((rt0 >> 1) & 1) << 2)) * 8) * 2u;
   const int tile_bytes = 64 * ld * 2;
+  const int full_tiles = S / 64;
   auto issue = [&](int t, int stage) {
     char* ks_ = smem + stage * 16384;
     char* vs_ = ks_ + 8192;
+    // only the per-lane offset is range-checked: full tiles pass the tile offset as a scalar, the ragged last tile adds
+    // it to the lane offset so that keys >= S fall past num_records (zeros) instead of reading the next image
+    const bool ragged = t >= full_tiles;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int so = t * tile_bytes + q * (tile_bytes >> 1);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, koff, so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, voff, so, 0, 0);
+      const unsigned ko = ragged ? koff + (unsigned)so : koff, vo = ragged ? voff + (unsigned)so : voff;
+      const int sso = ragged ? 0 : so;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(ks_ + (q * 4 + wid) * 1024), 16, ko, sso, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, LDS_PTR(vs_ + (q * 4 + wid) * 1024), 16, vo, sso, 0, 0);
     }
   };
 
@@ -453,9 +465,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
 }
 
 // ---------------------------------------------------------------------------------------------- temporal
+// One wave per (clip, pixel, head): Q, K and V of the 25 frames (32 x 64 tiles, rows >= F zero) all arrive by LDS-DMA
+// through a per-clip buffer descriptor -- every load is 8 rows x 128 contiguous bytes, frames >= F are out of range --
+// and the 25 x 64 output goes back through the (dead) Q tile so that the stores are 16 B per lane, row-contiguous.
+// The first version gathered Q / K fragments straight from global memory (32 B per cache line per instruction) and
+// stored 8 B per lane at a 17 MB row stride: 3.07 TB/s on a kernel that moves 4 x M x C x 2 bytes and nothing else.
 __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             int B, int F, int S, int C) {
-  __shared__ __attribute__((aligned(1024))) char smem[4 * 4096];  // one 32x64 V tile per wave
+  __shared__ __attribute__((aligned(1024))) char smem[4 * 12288];  // per wave: Q | K | V tiles of 32 x 64 bf16
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int heads = C >> 6;
@@ -466,37 +483,44 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
   const long bs = pid / heads;
   const int b = (int)(bs / S), s = (int)(bs % S);
   const int ld = 3 * C;
-  const long fstride = (long)S * ld;  // qkv elements between consecutive frames of one (b, s)
-  const bf16_t* qp = qkv + ((long)b * F * S + s) * ld + head * 64;
-  const bf16_t* kp = qp + C;
-  const bf16_t* vp = qp + 2 * C;
-  const int r32 = lane & 31, hsel = lane >> 5;
+  const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
 
-  char* vst = smem + wid * 4096;
+  char* qst = smem + wid * 12288;
+  char* kst = qst + 4096;
+  char* vst = qst + 8192;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(qkv + (long)b * F * S * ld), 0, (int)((long)F * S * ld * 2), 0x00020000);
   const int prow = lane >> 3, pslot = lane & 7;
+  const unsigned row_off = (unsigned)((prow * S + s) * ld + head * 64) * 2u;      // frame `prow` of this pixel / head
+  // swizzles (see the spatial kernel): Q / K chunk ^= (row >> 1) & 7, V chunk ^= ((row >> 1) & 1) << 2; row = 8 q + prow
+  const unsigned qk_even = row_off + (unsigned)((pslot ^ (prow >> 1)) * 16);
+  const unsigned qk_odd = row_off + (unsigned)((pslot ^ ((prow >> 1) | 4)) * 16);
+  const unsigned v_voff = row_off + (unsigned)((pslot ^ (((prow >> 1) & 1) << 2)) * 16);
+  const int frame8 = 8 * S * ld * 2;                                              // bytes between row groups of 8 frames
+  // (only the per-lane offset is range-checked, so the frame-group term must be part of it: frames >= F are then past
+  // num_records and read zeros; the q | k | v column block is a scalar offset)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int key = q * 8 + prow;
-    const char* pv = key < F ? (const char*)(vp + key * fstride + (pslot ^ (((key >> 1) & 1) << 2)) * 8)
-                             : (const char*)g_ctrlv_zeros + pslot * 16;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vst + q * 1024), 16, 0, 0);
+    const unsigned qk = ((q & 1) ? qk_odd : qk_even) + (unsigned)(q * frame8);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(qst + q * 1024), 16, qk, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(kst + q * 1024), 16, qk, C * 2, 0, 0);
   }
-  bf16x8 qf[4], kf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    uint4 vq = make_uint4(0, 0, 0, 0), vk = make_uint4(0, 0, 0, 0);
-    if (r32 < F) {
-      vq = *(const uint4*)(qp + r32 * fstride + 16 * ks + 8 * hsel);
-      vk = *(const uint4*)(kp + r32 * fstride + 16 * ks + 8 * hsel);
-    }
-    qf[ks] = __builtin_bit_cast(bf16x8, vq);
-    kf[ks] = __builtin_bit_cast(bf16x8, vk);
-  }
+  for (int q = 0; q < 4; ++q)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(vst + q * 1024), 16, v_voff + (unsigned)(q * frame8), C * 4, 0, 0);
+
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's own Q and K pieces have landed (V may still fly)
+  __builtin_amdgcn_sched_barrier(0);
   f32x16 sacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+  for (int ks = 0; ks < 4; ++ks) {
+    const int fo = r32 * 128 + (((ks * 2 + hsel) ^ sw) * 16);
+    const bf16x8 kf = *(const bf16x8*)(kst + fo);
+    const bf16x8 qf = *(const bf16x8*)(qst + fo);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -505,14 +529,14 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
     mx = fmaxf(mx, sacc[e]);
   }
   mx = half_max(mx) * kScaleLog2;
-  float rs = 0.f;
+  float rs_ = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const float p = __builtin_amdgcn_exp2f(sacc[e] * kScaleLog2 - mx);
     sacc[e] = p;
-    rs += p;
+    rs_ += p;
   }
-  const float inv = 1.0f / half_sum(rs);
+  const float inv = 1.0f / half_sum(rs_);
 
   f32x16 oacc[2];
 #pragma unroll
@@ -522,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
   const int i16 = lane & 15;
   const int vkey = 4 * hsel + (i16 >> 2);
   const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own LDS-DMA has landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // V landed
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -534,17 +558,23 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
       oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
     }
   }
-  if (r32 < F) {
-    bf16_t* op = out + ((long)(b * F + r32) * S + s) * C + head * 64;
+  // O^T (lane = query frame r32, 32 d-values) -> row-major [frame][64] bf16 in the Q tile (its fragments are consumed;
+  // LDS accesses of one wave execute in order), 16-B chunk index XOR (row & 7) against bank conflicts
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int dcol = dt * 32 + 8 * q + 4 * hsel;
-        uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
-                              pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
-        *(uint2*)(op + dcol) = pk;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int dcol = dt * 32 + 8 * q + 4 * hsel;
+      const uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
+                                  pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
+      *(uint2*)(qst + r32 * 128 + (((dcol >> 3) ^ (r32 & 7)) * 16) + (dcol & 4) * 2) = pk;
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int fr = q * 8 + prow;
+    const uint4 v = *(const uint4*)(qst + fr * 128 + ((pslot ^ (fr & 7)) * 16));
+    if (fr < F) *(uint4*)(out + ((long)(b * F + fr) * S + s) * C + head * 64 + pslot * 8) = v;
   }
 }
 
