@@ -178,15 +178,32 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, i
     }
   }
   const float inv_c = 1.0f / (float)C;
-  for (long m = (long)blockIdx.x * 4 + wid; m < M; m += (long)gridDim.x * 4) {
+  // the row of the NEXT trip is loaded before this trip's two wave reductions (dependent shuffle chains): with one load
+  // per trip in flight the kernel was latency-bound
+  const long step = (long)gridDim.x * 4;
+  long m = (long)blockIdx.x * 4 + wid;
+  uint4 nxt[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int cv = lane + k * 64;
+    nxt[k] = (m < M && cv < CV) ? *(const uint4*)(x + m * C + cv * 8) : make_uint4(0, 0, 0, 0);
+  }
+  for (; m < M; m += step) {
     float f[NV][8];
     float s = 0.f;
     const float* vrow = V ? V + (long)((m / vdiv) % vmod) * ldv : nullptr;
+    uint4 cur[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      cur[k] = nxt[k];
+      nxt[k] = (m + step < M && cv < CV) ? *(const uint4*)(x + (m + step) * C + cv * 8) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int cv = lane + k * 64;
       if (cv < CV) {
-        const uint4 v = *(const uint4*)(x + m * C + cv * 8);
+        const uint4 v = cur[k];
         unpack_bf16x8(v, f[k]);
         if (vrow) {
 #pragma unroll
