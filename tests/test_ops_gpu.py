@@ -306,6 +306,29 @@ def test_attention_spatial_peaked(ops, S, kpk):
     assert rel_l2(out, ref) < 5e-3
 
 
+@pytest.mark.parametrize("S", [448, 1216])
+@pytest.mark.parametrize("scale", [6.0, 40.0])
+def test_attention_spatial_large_scores(ops, S, scale):
+    """Softmax robustness of the sum-triggered rescale (no per-element max pass): logits of magnitude ~scale^2 * 8 / 8
+    (hundreds to thousands -- exp2 overflows without the max), drifting upwards along the key axis so that the running
+    max has to be raised again and again, and long runs of near-equal large logits (row sums far above the 2^12 limit
+    that triggers the slow path).  Both kernels (S < 1024: 32 rows per wave, S >= 1024: 64)."""
+    n_img, C = 1, 64
+    qkv = torch.randn(S, 3 * C, generator=g(3))
+    ramp = torch.linspace(0.2, 1.0, S)[:, None]
+    qkv[:, :64] *= scale
+    qkv[:, 64:128] = (qkv[:, 64:128] * ramp + 0.5 * ramp) * scale          # keys grow along the sequence
+    qkv[S // 2:S // 2 + 40, 64:128] = qkv[S // 2, 64:128]                  # 40 identical keys
+    qkv = bf(qkv)
+    f = qkv.float().reshape(1, S, 3, 1, 64)
+    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(S, C)
+    out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 6e-3
+
+
 @pytest.mark.parametrize("B,Fr,S,C", [(2, 25, 10, 128), (1, 3, 7, 64), (2, 32, 5, 320), (1, 1, 3, 64)])
 def test_attention_temporal(ops, B, Fr, S, C):
     heads = C // 64
