@@ -122,16 +122,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   // fragment read offsets: row (lane&31) of the 32-row sub-tile, 16-B chunk (2*ks + lane>>5) ^ swizzle
   const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
+  // accumulators start from the bias (result layout: accumulator e of a 32-column sub-tile is column 8*(e>>2) + 4*hsel
+  // + (e&3)) -- the same summation order as the ping-pong kernels, so a layer gives bit-identical results whichever
+  // tile serves it (tests: a 2-clip batch and its two 1-clip halves pick different tiles)
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int col = bn + wc * WTN + j * 32 + 8 * (e >> 2) + 4 * hsel + (e & 3);
+      const float bv = (d.bias != nullptr && col < d.N) ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][j][e] = bv;
+    }
+
   const int a_frag_base = (wr * WTM + r32) * 128;
   const int b_frag_base = A_BYTES + (wc * WTN + r32) * 128;
 

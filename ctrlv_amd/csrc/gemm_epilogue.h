@@ -1,6 +1,6 @@
 // Shared epilogue of the gather-GEMM kernels (see gemm.hip header).  Each lane owns output row m of every 32x32 MFMA
 // sub-tile (weight tile = A operand) and accumulator quad q holds columns n0 + 8q + 4*(lane>>5) + {0..3}.
-//   v = s_acc*(acc + bias[n]) + s1*R1[m,n] + s2*R2[m,n] + V[vidx(m), n];  optional SiLU; optional GEGLU pairing.
+//   v = s_acc*acc + s1*R1[m,n] + s2*R2[m,n] + V[vidx(m), n]   (acc already contains the bias: gemm.hip starts from it);  optional SiLU; optional GEGLU pairing.
 #pragma once
 #include "common.h"
 
@@ -31,7 +31,6 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float a = acc[i][j][4 * q + e], g = acc[i][j][4 * (q + 2) + e];
-            if (d.bias) { a += d.bias[ncol + e]; g += d.bias[ncol + 16 + e]; }
             o[e] = a * gelu_erf_f(g);
           }
           if (ocol < d.n_store) {
@@ -50,10 +49,6 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
-          if (d.bias) {
-            const float4 b = *(const float4*)(d.bias + ncol);
-            o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
-          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] *= d.s_acc;
           if (d.R1) {

@@ -87,8 +87,8 @@ __host__ __device__ inline long pp_vtable_rows(const ctrlv_gemm_desc& d) {
 
 // Bias lives in a wave-private LDS strip (WTN floats: the columns of this wave's tile), filled before the first tile
 // and re-filled at the end of every epilogue with the NEXT tile's columns (loaded into 4 VGPRs at the start of the
-// epilogue, so its latency hides behind the whole epilogue): the sub-tiles read it with two ds_read_b128 instead
-// of holding it in the VGPR prefetch queue or re-loading it from L2 -- the 320-wide tile has no registers to spare.
+// epilogue, so its latency hides behind the whole epilogue).  The K loop reads it once per tile as the C operand of
+// the tile's first MFMAs (bias_c in the kernel), so the accumulators already contain acc + bias when the epilogue runs.
 template <int WTN>
 __device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wbase_n, int lane) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -206,8 +206,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         img[pass][0] = *(const float4*)(rp + rx0);
         img[pass][1] = *(const float4*)(rp + rx1);
       }
-      const float4 b0 = *(const float4*)(bias_lds + (j * 32 + l4 * 8) * 4);
-      const float4 b1 = *(const float4*)(bias_lds + (j * 32 + l4 * 8 + 4) * 4);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -215,10 +213,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const int m = m0 + i * 32 + pass * 16;
         const bool ok = m < d.M && ocol < d.n_store;
-        o[0] = (o[0] + b0.x) * d.s_acc; o[1] = (o[1] + b0.y) * d.s_acc;
-        o[2] = (o[2] + b0.z) * d.s_acc; o[3] = (o[3] + b0.w) * d.s_acc;
-        o[4] = (o[4] + b1.x) * d.s_acc; o[5] = (o[5] + b1.y) * d.s_acc;
-        o[6] = (o[6] + b1.z) * d.s_acc; o[7] = (o[7] + b1.w) * d.s_acc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= d.s_acc;                 // (the bias is already in the accumulator)
         if (EPI & 2) {
           float f[8];
           const u32x4_t r = q[HAS_RES ? s : 0].r1[pass];
@@ -266,12 +262,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           if (js >= TN) continue;                          // compile time
 #pragma unroll
           for (int qd = 0; qd < 2; ++qd) {
-            const float4 ba = *(const float4*)(bias_lds + (js * 32 + 8 * qd + 4 * hsel) * 4);
-            const float4 bg = *(const float4*)(bias_lds + (js * 32 + 16 + 8 * qd + 4 * hsel) * 4);
-            const f32x4_t g = {acc[i][js][4 * (qd + 2)] + bg.x, acc[i][js][4 * (qd + 2) + 1] + bg.y,
-                               acc[i][js][4 * (qd + 2) + 2] + bg.z, acc[i][js][4 * (qd + 2) + 3] + bg.w};
-            const f32x4_t a = {acc[i][js][4 * qd] + ba.x, acc[i][js][4 * qd + 1] + ba.y, acc[i][js][4 * qd + 2] + ba.z,
-                               acc[i][js][4 * qd + 3] + ba.w};
+            const f32x4_t g = {acc[i][js][4 * (qd + 2)], acc[i][js][4 * (qd + 2) + 1], acc[i][js][4 * (qd + 2) + 2],
+                               acc[i][js][4 * (qd + 2) + 3]};
+            const f32x4_t a = {acc[i][js][4 * qd], acc[i][js][4 * qd + 1], acc[i][js][4 * qd + 2], acc[i][js][4 * qd + 3]};
             const f32x4_t o = a * gelu_erf4(g);
             const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
             *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
@@ -496,6 +489,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
     pp_bias_store<WTN>(bias_lds, b, lane);
   }
+  // The first MFMAs of a tile start from the BIAS instead of zero: in the result layout a lane's 16 accumulators of a
+  // 32-column sub-tile are columns 8q + 4 hsel + r (q, r = 0..3), so the C operand is four ds_read_b128 from the strip.
+  // The epilogue then has no bias reads or adds at all (it was 12-17 % of its instructions, and the epilogue is what
+  // limits the K = 320 layers).
+  auto bias_c = [&](int n) {
+    f32x16 c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *(const float4*)(bias_lds + (n * 32 + 8 * q + 4 * hsel) * 4);
+      c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+    }
+    return c;
+  };
   // ---- prologue: 3 half-steps in flight
   int is_tile = my_first;
   next_tile(is_tile);
@@ -542,13 +548,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       const int i0 = h * HM;
       PP_SETPRIO(1);
       if (MAY_BE_FIRST && j == 0) {
-        f32x16 zero;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+        for (int n = 0; n < TN; ++n) {
+          const f32x16 bc = bias_c(n);
 #pragma unroll
-        for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], zero, 0, 0, 0);
+          for (int i = i0; i < i0 + HM; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], bc, 0, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int i = i0; i < i0 + HM; ++i)
@@ -628,14 +633,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
       PP_SETPRIO(1);
       if (MAY_BE_FIRST && j == 0 && ks == 0) {
-        f32x16 zero;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+        for (int n = 0; n < TN; ++n) {
+          const f32x16 bc = bias_c(n);
 #pragma unroll
-        for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], zero, 0, 0, 0);
+          for (int i = i0; i < i0 + HM; ++i)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], bc, 0, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int i = i0; i < i0 + HM; ++i)
