@@ -6,25 +6,37 @@ ControlNet forward + UNet forward (batch 2) + CFG combine + Euler update
 (/root/reference/src/ctrlv/pipelines/pipeline_video_control.py:298-343), on synthetic seeded inputs and random-init
 weights of the SVD-XT architecture, inputs resident in HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: clips shard one-per-rank, weights replicated, NO collective inside the loop (weak scaling); a barrier +
-torch.cuda.synchronize() brackets the timed region and the elapsed time is the MAX over ranks.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE
+in the environment), or started plainly -- then this process, WITHOUT touching the GPU, starts the N rank processes
+itself and relays rank 0's JSON line.  Clips shard one-per-rank, weights replicated, NO collective inside the loop (weak
+scaling); a barrier + torch.cuda.synchronize() brackets the timed region and the elapsed time is the MAX over ranks.
+`n_gpus` in the output is the world size the process group reports.
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel family, HIP-event timed on the
-launch stream during the last timed step), `rooflines` (every family, incl. the attention-MFMA and GroupNorm-HBM
-fractions north_star asks for) and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline / rooflines   per kernel family (HIP events on the launch stream during one instrumented eager step), incl.
+                         the attention-MFMA and GroupNorm-HBM fractions north_star asks for; `traffic` = PMC HBM bytes
+                         per launch from the committed rocprofv3 --pmc summary, or null when that summary was not
+                         collected from the library that is running (build-id stamp) or the shape differs;
+  cpu_baseline           the CPU oracle timed on this host in the same run on a BOUNDED sample of the same workload:
+                         B = 1 (no CFG), `--cpu-frames` frames at the FULL latent resolution, full SVD widths;
+                         converted to steps/s by the frame count (per-frame work is identical; see cpu_baseline());
+  parity                 the HIP models' output on that same sample (same weights, same inputs) against the oracle's.
+`--cpu-full-step` times one complete no-CFG step (25 frames, ~109 TFLOP, minutes) instead of the bounded sample.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 PEAK_MFMA_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 PEAK_HBM_GBS = 8000.0               # 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -44,14 +56,63 @@ def parse():
     ap.add_argument("--hip-graph", type=int, default=int(os.environ.get("CTRLV_HIP_GRAPH", "1")),
                     help="replay the two model forwards from a captured HIP graph (default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-only", action="store_true", help="debug: only time the CPU oracle sample")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle (0 = min(cores, 32))")
-    ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--cpu-latent", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle (0 = calibrate)")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the bounded CPU sample (full latent size)")
+    ap.add_argument("--cpu-full-step", action="store_true",
+                    help="CPU baseline = one complete no-CFG step (all frames; ~109 TFLOP, several minutes)")
+    ap.add_argument("--cpu-timeout", type=int, default=0, help="seconds (0 = 240 for the sample, 1800 for a full step)")
+    ap.add_argument("--cpu-baseline-child", default="", help=argparse.SUPPRESS)      # internal: exchange directory
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work: ranks rendezvous over gloo and run the barrier / MAX-reduce bracket only "
+                         "(checks the N > 1 launch path on a machine without GPUs; prints value = null)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
 
+def log(*a):
+    print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------- multi-GPU launch
+def launch_ranks(args):
+    """`--gpus N` without a torchrun environment: start N rank processes (one per GPU) from this process, which has
+    made no HIP call, and relay rank 0's output.  Children are ordinary subprocesses (never an exec of a process that
+    initialised the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is drained by a thread; the parent polls so that one dead rank ends the others (which would
+    # otherwise wait at a barrier forever) -- by PID, never by pattern
+    import threading
+    chunks = []
+    th = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    th.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    if failed is not None or any(rcs):
+        log(f"rank exit codes {rcs}")
+        sys.exit(failed or next(rc for rc in rcs if rc))
+
+
+# ---------------------------------------------------------------------------------------------------- GPU side
 def build_models(device, workload, frames):
     from ctrlv_amd.models import ControlNetModel, UNetSpatioTemporalConditionModel
     from ctrlv_amd.utils import build_on_device, random_init_
@@ -67,6 +128,7 @@ def build_models(device, workload, frames):
 def make_stepper(unet, ctrl, device, args, clip_index):
     """Synthetic inputs of SURVEY.md 8(d): seeded N(0,1) latents * init_noise_sigma, image latents / control latents /
     CLIP embedding with a zero unconditional half, added ids [6, 127, 0.02], guidance linspace(1, 3, F)."""
+    import torch
     from ctrlv_amd.distributed import clip_generator
     from ctrlv_amd.pipelines.pipeline_utils import DenoiseStepper
     from ctrlv_amd.schedulers import EulerDiscreteScheduler
@@ -92,122 +154,202 @@ def make_stepper(unet, ctrl, device, args, clip_index):
 def run_step(st, i):
     k = i % 25
     if k == 0 and i > 0:                       # wrapped around the 25-step schedule: restart the clip
-        st.set_latents(st._init_latents, 0)
+        st.set_latents(st._init_latents, 0)    # (set_latents copies: the initial latents are never overwritten)
     st.step(k)
 
 
-def cpu_baseline(args):
-    """The CPU oracle (full SVD widths, fp32, all host cores) on a bounded sample: ONE ControlNet + UNet forward at
-    B=1 (no CFG), `cpu_frames` frames, `cpu_latent`^2 latent.  Converted to the metric's unit by algorithmic FLOPs:
-    steps/s-equivalent = (sample TFLOP / seconds) / (218.52 TFLOP per full step)."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_sample_inputs(F, h, w, seed=0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    q = lambda x: x.to(torch.bfloat16).float()   # noqa: E731  (bf16-representable: both sides see identical inputs)
+    return dict(sample=q(torch.randn(1, F, 8, h, w, generator=g)), cond=q(torch.randn(1, F, 4, h, w, generator=g)),
+                ehs=q(torch.randn(1, 1, 1024, generator=g)), ids=torch.tensor([[6.0, 127.0, 0.02]]),
+                t=torch.tensor(1.6377))
+
+
+def cpu_baseline_child(xdir):
+    """Child process: time the CPU oracle (ctrlv_ref, plain PyTorch fp32) on the sample described by <xdir>/job.json with
+    the weights in <xdir>/{unet,controlnet}.safetensors (the GPU run's own bf16 weights, up-cast), write the outputs
+    and the timing back.  The oracle is the checker / reported baseline here, never the measured product path."""
+    import torch
+    from safetensors.torch import load_file
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctrlv_ref as R
-    cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    F, L = args.cpu_frames, args.cpu_latent
+    job = json.load(open(os.path.join(xdir, "job.json")))
+    F, h, w = job["frames"], job["h"], job["w"]
+    threads = job["threads"]
+    if not threads:                          # calibrate: large-GEMM throughput at a few thread counts
+        total = os.cpu_count() or 1
+        a, b = torch.randn(4096, 4096), torch.randn(4096, 4096)
+        best = (0.0, 1)
+        for thr in sorted({min(total, n) for n in (16, 32, 64, 128)}):
+            torch.set_num_threads(thr)
+            a @ b
+            t0 = time.perf_counter()
+            a @ b
+            gf = 2 * 4096 ** 3 / (time.perf_counter() - t0) / 1e9
+            if gf > best[0] * 1.1:
+                best = (gf, thr)
+        threads = best[1]
+    torch.set_num_threads(threads)
     with torch.no_grad():
         with torch.device("meta"):
             unet = R.UNetSpatioTemporalConditionModel(num_frames=F)
-            ctrl = R.ControlNetModel(num_frames=F) if args.workload == "box2video" else None
-        src = torch.rand(1 << 24) * 2 - 1
-        for m in (unet, ctrl):
+            ctrl = R.ControlNetModel(num_frames=F) if job["workload"] == "box2video" else None
+        for m, name in ((unet, "unet"), (ctrl, "controlnet")):
             if m is None:
                 continue
-            m.to_empty(device="cpu")
-            for name, p in m.named_parameters():
-                n = p.numel()
-                flat = p.view(-1)
-                for o in range(0, n, src.numel()):
-                    k = min(src.numel(), n - o)
-                    flat[o:o + k].copy_(src[:k])
-                if name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "norm3.weight", "norm_in.weight",
-                                  "conv_norm_out.weight")):
-                    p.fill_(1.0)
-                elif name.endswith("mix_factor"):
-                    p.fill_(0.5)
-                elif p.dim() > 1:
-                    p.mul_(1.0 / p[0].numel() ** 0.5)
-                else:
-                    p.mul_(0.02)
+            sd = {k: v.float() for k, v in load_file(os.path.join(xdir, name + ".safetensors")).items()}
+            m.load_state_dict(sd, assign=True)
             m.eval()
-        g = torch.Generator().manual_seed(0)
-        sample = torch.randn(1, F, 8, L, L, generator=g)
-        cond = torch.randn(1, F, 4, L, L, generator=g)
-        ehs = torch.randn(1, 1, 1024, generator=g)
-        ids = torch.tensor([[6.0, 127.0, 0.02]])
-        t = torch.tensor(1.6377)
+        inp = cpu_sample_inputs(F, h, w)
 
-        def fwd():
+        def fwd(x):
             down = mid = None
             if ctrl is not None:
-                down, mid = ctrl(sample, t, ehs, ids, control_cond=cond)
-            return unet(sample, t, ehs, ids, down, mid)[0]
+                down, mid = ctrl(x["sample"], x["t"], x["ehs"], x["ids"], control_cond=x["cond"])
+            return unet(x["sample"], x["t"], x["ehs"], x["ids"], down, mid)[0]
 
-        fwd()                                   # warm-up (page-in, thread pool)
-        times = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            out = fwd()
-            times.append(time.perf_counter() - t0)
-        assert torch.isfinite(out).all()
-    sec = min(times)
-    # algorithmic FLOPs of the sample: everything scales with pixels*frames except spatial attention (quadratic in S)
-    full = ALG_TFLOP_PER_STEP[args.workload]
-    attn_full = 43.41 if args.workload == "box2video" else 31.01
-    px = (F * L * L) / (50.0 * 72 * 128)
-    tf = (full - attn_full) * px + attn_full * px * (L * L) / (72.0 * 128)
+        fwd(cpu_sample_inputs(F, 8, 8))          # thread-pool / allocator warm-up on a tiny latent
+        t0 = time.perf_counter()
+        out = fwd(inp)
+        sec = time.perf_counter() - t0
+    torch.save(out, os.path.join(xdir, "out.pt"))
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
+    except Exception:       # noqa: BLE001
         model = "unknown"
-    return {"value": round(tf / sec / full, 6), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (plain PyTorch fp32, {cores} threads, {model}) ControlNet+UNet forward, full SVD widths, "
-                      f"B=1 no CFG, {F} frames, {L}x{L} latent = {tf:.3f} TFLOP in {sec:.2f} s "
-                      f"({tf / sec * 1e3:.0f} GFLOP/s); scaled to 218.52 TFLOP/step"}
+    json.dump({"seconds": sec, "threads": threads, "cpu": model, "host_threads": os.cpu_count()},
+              open(os.path.join(xdir, "result.json"), "w"))
 
 
-def cpu_baseline_child(args):
-    """Runs the CPU-oracle timing in a child process (own thread pool, hard time limit) so that a pathological host
-    (e.g. 256 hardware threads oversubscribing small ops) cannot stall the benchmark; retries with fewer threads."""
-    import subprocess
-    total = os.cpu_count() or 1
-    for thr in ([args.cpu_threads] if args.cpu_threads else [min(total, 32), 8]):
-        env = dict(os.environ, OMP_NUM_THREADS=str(thr), MKL_NUM_THREADS=str(thr))
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(thr),
-               "--cpu-frames", str(args.cpu_frames), "--cpu-latent", str(args.cpu_latent), "--workload", args.workload]
+def cpu_baseline(args, unet, ctrl, device):
+    """cpu_baseline + parity legs.
+
+    Sample: B = 1 (no CFG), F = --cpu-frames frames at the FULL latent resolution and full SVD widths, i.e. the benchmark
+    workload with fewer frames -- spatial attention (quadratic in the 9216 tokens), convs, GEMMs and norms all run at
+    their real per-frame size.  Conversion to the metric's unit: one benchmark step is 2 x 25 = 50 frame-images, the
+    sample is F of them, every kernel's work is per frame (the only cross-frame operators, the 3-tap temporal conv and
+    the F x F temporal attention, are <= 7 % of the FLOPs and linear / negligible in F), so
+        steps/s = 1 / (seconds * 50 / F).
+    With --cpu-full-step the sample is the complete 25-frame no-CFG forward pair and the factor is exactly 2 (CFG).
+    The oracle runs in a child process (own thread pool, hard time limit) on the SAME weights as the GPU models (the
+    bf16 parameters are handed over through a tmpfs directory) and the SAME inputs; the HIP output on that sample is
+    compared with the oracle's -> `parity`."""
+    import torch
+    from safetensors.torch import save_file
+    F = args.frames if args.cpu_full_step else args.cpu_frames
+    h, w = args.height // 8, args.width // 8
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    xdir = tempfile.mkdtemp(prefix="ctrlv_bench_", dir=base)
+    try:
+        for m, name in ((unet, "unet"), (ctrl, "controlnet")):
+            if m is not None:
+                save_file({k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()},
+                          os.path.join(xdir, name + ".safetensors"))
+        json.dump({"frames": F, "h": h, "w": w, "threads": args.cpu_threads, "workload": args.workload},
+                  open(os.path.join(xdir, "job.json"), "w"))
+        timeout = args.cpu_timeout or (1800 if args.cpu_full_step else 240)
+        env = dict(os.environ)
+        env.pop("OMP_NUM_THREADS", None)
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-            for ln in reversed(r.stdout.strip().splitlines()):
-                if ln.startswith("{"):
-                    res = json.loads(ln)
-                    res["host_cores"] = total
-                    return res
-            log(f"cpu baseline child ({thr} threads) produced no result: {r.stderr[-300:]}")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", xdir], env=env,
+                               capture_output=True, text=True, timeout=timeout)
         except subprocess.TimeoutExpired:
-            log(f"cpu baseline child with {thr} threads exceeded 240 s")
-    return {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "CPU oracle timing failed on this host"}
+            return ({"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
+                     "sample": f"CPU oracle sample ({F} frames at {h}x{w}) exceeded {timeout} s on this host"}, None)
+        if r.returncode != 0 or not os.path.exists(os.path.join(xdir, "result.json")):
+            return ({"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
+                     "sample": "CPU oracle child failed: " + r.stderr[-300:]}, None)
+        res = json.load(open(os.path.join(xdir, "result.json")))
+        ref = torch.load(os.path.join(xdir, "out.pt"))
+    finally:
+        shutil.rmtree(xdir, ignore_errors=True)
+    sec = res["seconds"]
+    frames_per_step = 2 * args.frames
+    value = 1.0 / (sec * frames_per_step / F)
+    cpu = {"value": round(value, 6), "unit": "steps/s", "cores": res["threads"], "kind": "port",
+           "host_threads": res["host_threads"], "sample_seconds": round(sec, 2),
+           "scaled_by": f"{frames_per_step}/{F} frame-images per step / per sample",
+           "sample": f"oracle (plain PyTorch fp32, {res['threads']} threads of {res['cpu']}) "
+                     f"{'ControlNet + ' if ctrl is not None else ''}UNet forward, full SVD widths, B=1 no CFG, {F} of the "
+                     f"step's {frames_per_step} frame-images at the full {h}x{w} latent, measured {sec:.1f} s"
+                     + ("; the complete no-CFG step" if args.cpu_full_step else "")}
+    # ---- parity of the HIP path on the same sample
+    inp = cpu_sample_inputs(F, h, w)
+    bf = torch.bfloat16
+    dv = lambda x: x.to(device, bf)   # noqa: E731
+    with torch.no_grad():
+        down = mid = None
+        if ctrl is not None:
+            down, mid = ctrl(dv(inp["sample"]), inp["t"].to(device), dv(inp["ehs"]), inp["ids"].to(device),
+                             control_cond=dv(inp["cond"]), return_dict=False)
+        got = unet(dv(inp["sample"]), inp["t"].to(device), dv(inp["ehs"]), inp["ids"].to(device), down, mid,
+                   return_dict=False)[0].float().cpu()
+    ref = ref.float()
+    rms = ref.pow(2).mean().sqrt().item()
+    parity = {"rel_l2": round(((got - ref).norm() / ref.norm()).item(), 6),
+              "max_abs": round((got - ref).abs().max().item(), 6), "ref_rms": round(rms, 6),
+              "tolerance_rel_l2": 1.5e-2,
+              "what": f"HIP UNet output (bf16 storage) vs the fp32 CPU oracle, same weights / inputs, {F} frames at {h}x{w}"}
+    parity["ok"] = bool(parity["rel_l2"] < parity["tolerance_rel_l2"])
+    return cpu, parity
 
 
-def log(*a):
-    print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
+def launcher_selftest(args, D):
+    """The rank bracket of main() with the GPU work removed (gloo): rendezvous, barrier, K no-op steps, MAX-reduce."""
+    import torch.distributed as dist
+    rank, world, _ = D.init("gloo" if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    world = D.world_size()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
+    clip = D.shard_clips(world, rank, world)[0]
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    seen = [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(seen, clip)
+    else:
+        seen = [clip]
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work)", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                          "launcher_selftest": True, "ranks_seen": sorted(seen)}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
-    if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args)))
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.cpu_baseline_child)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+        return
+    import torch
     from ctrlv_amd import distributed as D
+    if args.launcher_selftest:
+        launcher_selftest(args, D)
+        return
+    from ctrlv_amd import _lib
     from ctrlv_amd import profiler
     rank, world, local = D.init("nccl" if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    world = D.world_size()                       # what the process group reports, not what the command line asked for
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     unet, ctrl = build_models(device, args.workload, args.frames)
-    st = make_stepper(unet, ctrl, device, args, clip_index=rank)       # one clip per rank (weak scaling)
-    log(f"rank {rank}/{world}: models built on {device}, hip_graph={args.hip_graph}")
+    clip = D.shard_clips(world, rank, world)[0]                        # one clip per rank (weak scaling)
+    st = make_stepper(unet, ctrl, device, args, clip_index=clip)
+    log(f"rank {rank}/{world}: models built on {device}, hip_graph={args.hip_graph}, lib build {_lib.build_id()}")
 
     i = 0
     for _ in range(max(args.warmup, 2 if args.hip_graph else 1)):      # graph mode: 1 eager + 1 capture step
@@ -246,23 +388,34 @@ def main():
         return
     fams = timer.summary() if timer is not None else {}
     # HBM traffic per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections
-    # applied by tools/pmc_summary.py) committed under profiles/; null when no summary is present
-    pmc = {}
+    # applied by tools/pmc_summary.py) committed under profiles/.  Only valid for the library it was collected from:
+    # the summary carries that library's build id (hash of csrc/ + include/) and is ignored when it differs.
+    pmc, pmc_note = {}, None
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_summary.json")))
-        if cands and args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25):
+        default_shape = args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25)
+        if not cands:
+            pmc_note = "no PMC summary under profiles/"
+        elif not default_shape:
+            pmc_note = "PMC summary is for the default box2video 25x576x1024 shape only"
+        else:
             raw = json.load(open(cands[-1]))
-            alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
-                     "groupnorm": ["gn_stats_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
-                     "residual_add": ["axpby_kernel"], "gemm_linear": ["gemm_linear"],
-                     "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"]}
-            for fam, keys in alias.items():
-                if all(k in raw for k in keys):
-                    pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
-            pmc["_source"] = os.path.relpath(cands[-1], ROOT)
+            if raw.get("_build_id") != _lib.build_id():
+                pmc_note = (f"{os.path.relpath(cands[-1], ROOT)} was collected from library build "
+                            f"{raw.get('_build_id', 'unstamped')}, running {_lib.build_id()}: traffic = null")
+            else:
+                alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
+                         "groupnorm": ["gn_stats_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
+                         "residual_add": ["axpby_kernel"], "gemm_linear": ["gemm_linear"],
+                         "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"]}
+                for fam, keys in alias.items():
+                    keys = [k for k in keys if k in raw]
+                    if keys:
+                        pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
+                pmc["_source"] = os.path.relpath(cands[-1], ROOT)
     except Exception as ex:       # noqa: BLE001
-        log(f"no PMC traffic summary: {ex}")
+        pmc_note = f"PMC summary unreadable: {ex}"
     rooflines = {}
     for fam, d in fams.items():
         sec = d["ms"] * 1e-3
@@ -283,12 +436,13 @@ def main():
     roofline = dict(rooflines[dominant], kernel=dominant) if dominant else None
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps * world / elapsed
-    alg = ALG_TFLOP_PER_STEP[args.workload]
-    if (args.height, args.width, args.frames) != (576, 1024, 25):      # table above is for the BASELINE shape only
-        alg = round(sum(d["flops"] for d in fams.values()) / 1e12, 2)
+    executed = round(sum(d["flops"] for d in fams.values()) / 1e12, 2)
+    default_shape = (args.height, args.width, args.frames) == (576, 1024, 25)
+    alg = ALG_TFLOP_PER_STEP[args.workload] if default_shape else None      # Appendix B table: BASELINE shape only
+    shape = f"{args.frames}f {args.height}x{args.width}"
     line = {
-        "metric": "denoising steps/sec, SVD+ControlNet 25f 576x1024" if args.workload == "box2video"
-        else "denoising steps/sec, SVD UNet-only 25f 576x1024",
+        "metric": (f"denoising steps/sec, SVD+ControlNet {shape}" if args.workload == "box2video"
+                   else f"denoising steps/sec, SVD UNet-only {shape}"),
         "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
@@ -296,19 +450,25 @@ def main():
                                f"{args.frames} frames, latent {args.height // 8}x{args.width // 8}, 25-step Karras Euler "
                                "schedule, random-init SVD-XT weights", "clips_per_gpu": 1, "parallelism": f"clip-shard x{world}",
                    "hip_graph": bool(args.hip_graph)},
-        "step_mfma_frac": round(alg / (ms_per_step * 1e-3) / PEAK_MFMA_BF16_TFLOPS, 4),
-        "algorithmic_tflop_per_step": alg,
-        "executed_tflop_per_step": round(sum(d["flops"] for d in fams.values()) / 1e12, 2),
+        # whole-step MFMA fraction on the FLOPs the kernels execute (the dead 1-key cross-attention work of the
+        # reference, 8.4 TFLOP at the default shape, is not executed and not counted); the reference-algorithm figure
+        # is reported next to it
+        "step_mfma_frac": round(executed / (ms_per_step * 1e-3) / PEAK_MFMA_BF16_TFLOPS, 4),
+        "executed_tflop_per_step": executed,
+        "reference_algorithm_tflop_per_step": alg,
+        "step_mfma_frac_reference_algorithm": (round(alg / (ms_per_step * 1e-3) / PEAK_MFMA_BF16_TFLOPS, 4)
+                                               if alg else None),
         "kernel_ms_per_step": round(sum(d["ms"] for d in fams.values()), 2),
         "finite": finite,
+        "lib_build_id": _lib.build_id(),
         "roofline": roofline, "rooflines": rooflines,
-        "traffic_source": pmc.get("_source"),
+        "traffic_source": pmc.get("_source"), "traffic_note": pmc_note,
     }
     if world == 1 and not args.no_cpu_baseline:
-        del st, unet, ctrl
+        del st
         torch.cuda.empty_cache()
-        log("timing the CPU oracle baseline (bounded sample) ...")
-        line["cpu_baseline"] = cpu_baseline_child(args)
+        log("timing the CPU oracle baseline (bounded sample, same weights) and checking the HIP output against it ...")
+        line["cpu_baseline"], line["parity"] = cpu_baseline(args, unet, ctrl, device)
     print(json.dumps(line))
 
 

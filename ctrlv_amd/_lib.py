@@ -29,6 +29,7 @@ class GemmDesc(ctypes.Structure):
 # name -> (restype, argtypes); lists every symbol include/ctrlv_hip.h declares (tests/test_abi.py checks this)
 SIGNATURES = {
     "ctrlv_abi_version": (c_int, []),
+    "ctrlv_build_id": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
@@ -50,10 +51,34 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2
 
 
 class CtrlvHipError(RuntimeError):
     pass
+
+
+def source_build_id():
+    """sha256 prefix over ctrlv_amd/csrc/*.{hip,h} and include/*.h (sorted by name): the id `__graft_entry__.build()`
+    stamps into the library.  None when the sources are not next to the package (an installed binary-only copy)."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    if not os.path.isdir(csrc) or not os.path.isdir(inc):
+        return None
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id(lib=None):
+    buf = ctypes.create_string_buffer(128)
+    (lib or load()).ctrlv_build_id(buf, 128)
+    return buf.value.decode()
 
 
 def load():
@@ -70,6 +95,14 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header / library out of sync
         fn.restype, fn.argtypes = res, args
+    if lib.ctrlv_abi_version() != ABI_VERSION:
+        raise CtrlvHipError(f"{path}: ABI version {lib.ctrlv_abi_version()}, this host layer needs {ABI_VERSION}")
+    # a shipped .so must come from the sources it sits next to (it is git-ignored and travels prebuilt); variant
+    # libraries selected through CTRLV_HIP_LIB (tools/ab_build.py A/B builds) are exempt
+    want = source_build_id()
+    if want is not None and "CTRLV_HIP_LIB" not in os.environ and build_id(lib) != want:
+        raise CtrlvHipError(f"{path} is stale: built from sources {build_id(lib)}, tree is {want}; rebuild with "
+                            "`python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

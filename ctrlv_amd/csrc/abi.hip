@@ -1,0 +1,59 @@
+// ABI basics of libctrlv_hip.so: version, build id, thread-local error text, per-device property cache.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "common.h"
+
+#ifndef CTRLV_BUILD_ID
+#define CTRLV_BUILD_ID "unstamped"
+#endif
+
+static thread_local char g_err[512] = "";
+void ctrlv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ctrlv_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CTRLV_MAX_DEVICES) dev = 0;
+  return dev;
+}
+
+int ctrlv_num_cu(int dev) {
+  static int cu[CTRLV_MAX_DEVICES] = {};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cu[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cu[dev] = n;
+  }
+  return cu[dev];
+}
+
+extern "C" int ctrlv_last_error(char* buf, size_t n) {
+  if (buf && n) {
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_err);
+}
+
+extern "C" int ctrlv_abi_version(void) { return 2; }
+
+// sha256 prefix of ctrlv_amd/csrc/* + include/*.h at build time (stamped by __graft_entry__.build()): the host layer
+// refuses a library whose id differs from the sources next to it.
+extern "C" int ctrlv_build_id(char* buf, size_t n) {
+  // the "CTRLV_BUILD_ID=" marker lets the build script read the id from the file without dlopen()ing it
+  static const char marker[] = "CTRLV_BUILD_ID=" CTRLV_BUILD_ID;
+  const char* id = marker + 15;
+  if (buf && n) {
+    strncpy(buf, id, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(id);
+}

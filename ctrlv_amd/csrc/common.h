@@ -99,6 +99,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- host side ----
 void ctrlv_set_error(const char* fmt, ...);
+#define CTRLV_MAX_DEVICES 64
+int ctrlv_current_device();   // hipGetDevice clamped to [0, CTRLV_MAX_DEVICES)
+int ctrlv_num_cu(int dev);    // cached hipDeviceAttributeMultiprocessorCount
 #define CTRLV_CHECK_ARG(cond, ...)                  \
   do {                                              \
     if (!(cond)) {                                  \

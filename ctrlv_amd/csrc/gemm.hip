@@ -169,11 +169,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
 template <int BM, int BN, int WM, int WN>
 int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
+  static bool attr_set[CTRLV_MAX_DEVICES] = {};      // per device: the attribute belongs to the device's code object
   auto kfn = gemm_kernel<BM, BN, WM, WN>;
-  if (!attr_set) {
+  const int dev = ctrlv_current_device();
+  if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   hipLaunchKernelGGL(kfn, dim3(tiles), dim3(WM * WN * 64), smem, stream, d);
@@ -182,23 +183,6 @@ int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
 }
 
 }  // namespace
-
-// ---------------------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-void ctrlv_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-extern "C" int ctrlv_last_error(char* buf, size_t n) {
-  if (buf && n) {
-    strncpy(buf, g_err, n - 1);
-    buf[n - 1] = 0;
-  }
-  return (int)strlen(g_err);
-}
-extern "C" int ctrlv_abi_version(void) { return 1; }
 
 extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   CTRLV_CHECK_ARG(dp != nullptr, "ctrlv_gemm: null descriptor");

@@ -732,19 +732,15 @@ template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = f
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
   constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0);
-  static bool attr_set = false;
+  // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
+  static bool attr_set[CTRLV_MAX_DEVICES] = {};
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2>;
-  if (!attr_set) {
+  const int dev = ctrlv_current_device();
+  if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+    attr_set[dev] = true;
   }
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    CTRLV_HIP_TRY(hipGetDevice(&dev));
-    CTRLV_HIP_TRY(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    if (num_cu <= 0) num_cu = 256;
-  }
+  const int num_cu = ctrlv_num_cu(dev);
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
   const int grid = (persistent && tiles > num_cu) ? num_cu : tiles;   // persistent: one 512-thread workgroup per CU
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);

@@ -2,8 +2,9 @@
 // loads/stores (8 bf16 per lane), fp32 math, wave64 shuffle reductions, fp64 final combine of the split statistics.
 //
 // GroupNorm is a split reduction (SURVEY hard part H3: the 5-D temporal norm has only B*32 statistics rows of
-// up to 2.3 M elements each): pass 1 writes per-(image, row-chunk, group) partial (sum, sumsq); pass 2 reduces the
-// partials of its statistics row (deterministic order, fp64) and streams x -> y = silu(x*a_c + b_c).
+// up to 2.3 M elements each): pass 1 writes per-(image, row-chunk, group) partial (mean_c, M2_c = sum (x-mean_c)^2),
+// accumulated relative to a pilot value of the chunk so that mean >> std inputs do not cancel in fp32; pass 2 combines
+// the partials of its statistics row (deterministic order, fp64, Chan's formula) and streams x -> y = silu(x*a_c + b_c).
 // Algorithmic traffic: 2 reads + 1 write of the tensor (the second read of mid-size tensors is served by L2 /
 // Infinity Cache).
 #include "common.h"
@@ -29,9 +30,21 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
-  float sm[8], sq[8];
+  float sm[8], sq[8], piv[8];
+  // pilot value per group: the group's first channel in the chunk's first row.  Sums of (x - pilot) and (x - pilot)^2
+  // keep fp32 accuracy when |mean| >> std (E[x^2] - mean^2 would cancel); every lane of a group uses the same pilot.
+  {
+    const int cpg = s.C / 32;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const int cg = ((c0 + e) / cpg) * cpg;
+      const long prow = (long)n * s.S + r0;
+      const bf16_t pv = (x2 != nullptr && cg >= s.c_split) ? x2[prow * (s.C - s.c_split) + (cg - s.c_split)]
+                                                           : x[prow * (x2 != nullptr ? s.c_split : s.C) + cg];
+      piv[e] = bf16_to_f32(pv);
+      sm[e] = sq[e] = 0.f;
+    }
+  }
   // four rows per trip: four independent 16-byte loads in flight per lane (HBM latency ~1 us; one load per trip left
   // the kernel latency-bound at 3.6 TB/s)
   int r = r0 + rsub;
@@ -44,7 +57,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
       float f[8];
       unpack_bf16x8(v[u], f);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+      for (int e = 0; e < 8; ++e) { const float dl = f[e] - piv[e]; sm[e] += dl; sq[e] += dl * dl; }
     }
   }
   for (; r < r1; r += s.RPP) {
@@ -52,7 +65,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
     float f[8];
     unpack_bf16x8(v, f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+    for (int e = 0; e < 8; ++e) { const float dl = f[e] - piv[e]; sm[e] += dl; sq[e] += dl * dl; }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -71,8 +84,13 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
     const int stat = n / s.imgs_per_stat;
     const int gchunk = (n % s.imgs_per_stat) * s.n_chunks + chunk;
     const long o = (((long)stat * s.imgs_per_stat * s.n_chunks + gchunk) * 32 + tid) * 2;
-    partials[o] = a;
-    partials[o + 1] = b;
+    const int cg = tid * cpg;
+    const long prow = (long)n * s.S + r0;
+    const bf16_t pv = (x2 != nullptr && cg >= s.c_split) ? x2[prow * (s.C - s.c_split) + (cg - s.c_split)]
+                                                         : x[prow * (x2 != nullptr ? s.c_split : s.C) + cg];
+    const float inv_cnt = 1.0f / (float)(cpg * (r1 - r0));
+    partials[o] = bf16_to_f32(pv) + a * inv_cnt;      // chunk mean
+    partials[o + 1] = b - a * a * inv_cnt;             // chunk M2 (about its own mean)
   }
 }
 
@@ -88,11 +106,16 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   // ---- reduce the partials of this statistics row: 8 slices x 32 groups, fp64
   if (tid < 256) {
     const int g = tid & 31, sl = tid >> 5;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0;                        // a = sum n_c*mean_c,  b = sum (M2_c + n_c*mean_c^2), exact in fp64
     const float* p = partials + ((long)stat * tot_chunks) * 64;
+    const int cpg_ = s.C / 32;
     for (int k = sl; k < tot_chunks; k += 8) {
-      a += (double)p[(k * 32 + g) * 2];
-      b += (double)p[(k * 32 + g) * 2 + 1];
+      const int ck = k % s.n_chunks;
+      const int rows = min(s.S, (ck + 1) * s.rows_per_chunk) - ck * s.rows_per_chunk;
+      const double nc = (double)(cpg_ * rows);
+      const double mc = (double)p[(k * 32 + g) * 2];
+      a += nc * mc;
+      b += (double)p[(k * 32 + g) * 2 + 1] + nc * mc * mc;
     }
     dred[sl][g][0] = a;
     dred[sl][g][1] = b;

@@ -29,6 +29,15 @@ def init(backend=None):
     return rank, world, local
 
 
+def world_size():
+    """World size as the process group reports it (1 without a group)."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def shard_clips(num_clips, rank, world):
     """Round-robin clip -> rank assignment: rank r owns clips {i : i mod world == r}."""
     if not (0 <= rank < world):
@@ -39,6 +48,32 @@ def shard_clips(num_clips, rank, world):
 def clip_generator(seed, clip_index, device="cpu"):
     """Per-clip RNG so that results do not depend on the number of ranks."""
     return torch.Generator(device=device).manual_seed(int(seed) + int(clip_index))
+
+
+def run_clips(num_clips, sample_fn, seed=0, rank=None, world=None, device="cpu", sync=None):
+    """Batch-shard sampling driver (BASELINE config 4): this rank samples the clips it owns
+    (`shard_clips`), each with its own `clip_generator(seed, clip)` so a clip's result does not depend on the number
+    of ranks, with NO collective in the data path; a barrier brackets the region and the elapsed wall time is the MAX
+    over ranks.
+
+    sample_fn(clip_index, generator) -> anything (typically `pipeline(..., generator=generator).frames`).
+    `sync` is called before each clock read (torch.cuda.synchronize on GPUs).
+    Returns (results: {clip_index: value} for the owned clips, elapsed_seconds_max_over_ranks)."""
+    import time
+    if rank is None or world is None:
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    mine = shard_clips(num_clips, rank, world)
+    barrier()
+    if sync is not None:
+        sync()
+    t0 = time.perf_counter()
+    results = {}
+    for clip in mine:
+        results[clip] = sample_fn(clip, clip_generator(seed, clip, device))
+    if sync is not None:
+        sync()
+    barrier()
+    return results, max_over_ranks(time.perf_counter() - t0)
 
 
 def barrier():

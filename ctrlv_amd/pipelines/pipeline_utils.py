@@ -150,15 +150,120 @@ class _ProgressBar:
         self.n += n
 
 
+def _load_vae(path, **kw):
+    try:
+        from diffusers import AutoencoderKLTemporalDecoder
+    except ImportError as e:
+        raise EnvironmentError(
+            "loading `vae/` needs diffusers' AutoencoderKLTemporalDecoder (the VAE stays a caller-side PyTorch-ROCm "
+            "module); pass `vae=...` or `component_loaders={'vae': fn}` to from_pretrained") from e
+    return AutoencoderKLTemporalDecoder.from_pretrained(path, **kw)
+
+
+def _load_image_encoder(path, **kw):
+    from transformers import CLIPVisionModelWithProjection
+    return CLIPVisionModelWithProjection.from_pretrained(path, **kw)
+
+
+def _load_feature_extractor(path, **kw):
+    from transformers import CLIPImageProcessor
+    return CLIPImageProcessor.from_pretrained(path)
+
+
+def resolve_pretrained_dir(name_or_path):
+    """A local diffusers-layout directory for `name_or_path`: the path itself, or -- for a hub id such as
+    "stabilityai/stable-video-diffusion-img2vid-xt" -- a copy under $CTRLV_MODEL_ROOT/<id> or the local Hugging Face
+    cache (no download: there is no network path in ctrlv_amd).  None if nothing is found."""
+    import os
+    p = str(name_or_path)
+    if os.path.isdir(p):
+        return p
+    root = os.environ.get("CTRLV_MODEL_ROOT")
+    if root:
+        for cand in (os.path.join(root, p), os.path.join(root, p.split("/")[-1])):
+            if os.path.isdir(cand):
+                return cand
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(p, local_files_only=True)
+    except Exception:       # noqa: BLE001  (not cached / hub library absent)
+        return None
+
+
 class SVDPipelineBase:
     """Component registry + the inherited helpers + the HIP denoising loop."""
 
     _component_names = ("vae", "image_encoder", "unet", "controlnet", "scheduler", "feature_extractor")
+    # HIP-graph replay of the two model forwards is the default execution mode of the loop (first step eager, second
+    # step captured, the rest replayed; a new pipeline call = new shapes = new capture).  `pipe.use_hip_graph = False`
+    # or CTRLV_HIP_GRAPH=0 selects eager launches.
+    use_hip_graph = os.environ.get("CTRLV_HIP_GRAPH", "1") != "0"
 
     def register_modules(self, **kw):
         for k, v in kw.items():
             setattr(self, k, v)
         self._components = list(kw)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, variant=None, component_loaders=None,
+                        **kwargs):
+        """Build the pipeline from a diffusers-layout directory (`model_index.json`, `unet/`, `controlnet/`, `vae/`,
+        `image_encoder/`, `feature_extractor/`, `scheduler/scheduler_config.json`) with component overrides, as the
+        reference's tools do: `StableVideoControlPipeline.from_pretrained(id, controlnet=ctrlnet, unet=unet)`
+        (tools/eval_video_controlnet.py:116-118, tools/eval_overall.py:203-217) and with every module passed in
+        (tools/train_video_controlnet.py:344-353,543-552).
+
+        * Components given as keyword arguments are used as they are.
+        * `unet` / `controlnet` otherwise load through the HIP models' own `from_pretrained(dir, subfolder=...)`.
+        * `scheduler` loads `scheduler/scheduler_config.json` (SVD defaults when the directory has none).
+        * `vae`, `image_encoder`, `feature_extractor` are PyTorch-ROCm modules outside the hot path; they load through
+          `component_loaders[name](subfolder_path, torch_dtype=..., variant=...)`, by default diffusers'
+          AutoencoderKLTemporalDecoder and transformers' CLIPVisionModelWithProjection / CLIPImageProcessor.
+        * A hub id resolves to a local copy only ($CTRLV_MODEL_ROOT or the local HF cache); nothing is downloaded.
+        `revision`, `use_safetensors`, `local_files_only`, `cache_dir` and similar hub keywords are accepted and ignored.
+        """
+        import inspect
+        import json
+        names = [n for n in inspect.signature(cls.__init__).parameters if n != "self"]
+        given = {n: kwargs.pop(n) for n in list(kwargs) if n in names}
+        loaders = {"vae": _load_vae, "image_encoder": _load_image_encoder, "feature_extractor": _load_feature_extractor}
+        loaders.update(component_loaders or {})
+        missing = [n for n in names if n not in given]
+        root = resolve_pretrained_dir(pretrained_model_name_or_path) if missing else None
+        if missing and root is None and missing != ["scheduler"]:
+            raise EnvironmentError(
+                f"{cls.__name__}.from_pretrained: '{pretrained_model_name_or_path}' is not a local directory (and not in "
+                f"$CTRLV_MODEL_ROOT / the local Hugging Face cache) but the components {missing} were not passed in; "
+                "ctrlv_amd never downloads")
+        if root is not None and os.path.isfile(os.path.join(root, "model_index.json")):
+            with open(os.path.join(root, "model_index.json")) as f:
+                index = json.load(f)
+        else:
+            index = {}
+        comps = dict(given)
+        for n in missing:
+            sub = os.path.join(root, n) if root is not None else None
+            if n == "scheduler":
+                from ..schedulers import EulerDiscreteScheduler
+                comps[n] = (EulerDiscreteScheduler.from_pretrained(root, subfolder="scheduler")
+                            if sub and os.path.isdir(sub) else EulerDiscreteScheduler())
+                continue
+            if not os.path.isdir(sub):
+                raise EnvironmentError(f"{cls.__name__}.from_pretrained: no '{n}/' under {root} and no `{n}=` override"
+                                       + (f" (model_index.json lists {index[n]})" if n in index else ""))
+            if n in ("unet", "controlnet"):
+                from ..models import ControlNetModel, UNetSpatioTemporalConditionModel
+                mcls = UNetSpatioTemporalConditionModel if n == "unet" else ControlNetModel
+                comps[n] = mcls.from_pretrained(root, subfolder=n, variant=variant, torch_dtype=torch_dtype)
+            else:
+                comps[n] = loaders[n](sub, torch_dtype=torch_dtype, variant=variant)
+        pipe = cls(**comps)
+        if torch_dtype is not None:
+            for n in ("vae", "image_encoder"):
+                m = comps.get(n)
+                if n in missing and isinstance(m, torch.nn.Module):
+                    m.to(torch_dtype)
+        return pipe
 
     # ---- device / dtype plumbing -----------------------------------------------------------------------------
     def to(self, *args, **kwargs):
@@ -190,15 +295,22 @@ class SVDPipelineBase:
     def save_pretrained(self, save_directory, safe_serialization=True, **kw):
         """Writes the HIP models in diffusers layout (`unet/`, `controlnet/`), as pipeline.save_pretrained does
         at tools/train_video_controlnet.py:553; VAE / CLIP are the caller's modules and keep their own savers."""
-        import os
         for name in ("unet", "controlnet"):
             m = getattr(self, name, None)
             if m is not None:
                 m.save_pretrained(os.path.join(save_directory, name), safe_serialization=safe_serialization)
-        for name in ("vae", "image_encoder"):
+        for name in ("vae", "image_encoder", "feature_extractor", "scheduler"):
             m = getattr(self, name, None)
             if m is not None and hasattr(m, "save_pretrained"):
                 m.save_pretrained(os.path.join(save_directory, name))
+        import json
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.27.2"}
+        for name in self._components:
+            m = getattr(self, name, None)
+            if m is not None:
+                index[name] = [type(m).__module__.split(".")[0], type(m).__name__]
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
 
     # ---- guidance ------------------------------------------------------------------------------------------------
     @property
@@ -312,7 +424,7 @@ class SVDPipelineBase:
         stepper = DenoiseStepper(self.unet, controlnet, self.scheduler, latents, image_latents, image_embeddings,
                                  added_time_ids, cond_em, min_guidance_scale, max_guidance_scale,
                                  control_condition_scale, do_cfg=bool(self.do_classifier_free_guidance),
-                                 use_hip_graph=getattr(self, "use_hip_graph", False))
+                                 use_hip_graph=bool(self.use_hip_graph))
         for i, t in enumerate(self.scheduler.timesteps):
             noise_pred = stepper.step(i)
             if callback_on_step_end is not None:
@@ -367,7 +479,10 @@ class DenoiseStepper:
         self._eager_runs = 0
 
     def set_latents(self, latents, sigma_index):
-        self.latents = latents.to(torch.float32).contiguous()
+        """Copies into the stepper's own fp32 buffer: the caller's tensor is never aliased (the fused Euler kernel
+        updates `self.latents` in place) and the buffer address stays stable for HIP-graph replay."""
+        if latents is not self.latents:
+            self.latents.copy_(latents.to(device=self.latents.device, dtype=torch.float32))
         s = self.scheduler.sigma_at(sigma_index)
         self.scaled.copy_(self.latents / math.sqrt(s ** 2 + 1))
 

@@ -46,6 +46,37 @@ class EulerDiscreteScheduler:
         self.num_inference_steps = None
         self._step_index = None
 
+    # ---- diffusers-style (de)serialisation: scheduler/scheduler_config.json -----------------------------------------
+    @classmethod
+    def from_config(cls, config, **overrides):
+        """Accepts a diffusers scheduler config dict; keys this scheduler does not model (`_class_name`,
+        `trained_betas`, `rescale_betas_zero_snr`, ...) are dropped, unsupported VALUES still raise in __init__."""
+        cfg = {k: v for k, v in dict(config).items() if k in cls._defaults}
+        cfg.update({k: v for k, v in overrides.items() if k in cls._defaults})
+        return cls(**cfg)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, **kwargs):
+        import json
+        import os
+        root = str(pretrained_model_name_or_path)
+        if subfolder:
+            root = os.path.join(root, subfolder)
+        path = os.path.join(root, "scheduler_config.json")
+        if not os.path.isfile(path):
+            raise EnvironmentError(f"{path} not found (ctrlv_amd loads schedulers from a local directory only)")
+        with open(path) as f:
+            return cls.from_config(json.load(f), **kwargs)
+
+    def save_pretrained(self, save_directory, **_):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"_class_name": "EulerDiscreteScheduler", "_diffusers_version": "0.27.2"}
+        cfg.update(self.config)
+        with open(os.path.join(save_directory, "scheduler_config.json"), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True)
+
     @property
     def init_noise_sigma(self):
         max_sigma = float(self.sigmas.max())

@@ -33,6 +33,9 @@ enum {
 
 /* Library ABI version (bumped on any signature change). */
 int ctrlv_abi_version(void);
+/* Copies the build id (hash of the kernel sources + this header the library was compiled from) into buf; returns its
+ * length.  The Python host layer compares it with the sources it sits next to and refuses a stale library. */
+int ctrlv_build_id(char* buf, size_t n);
 /* Copies the last error message of the calling thread into buf (NUL terminated); returns its length. */
 int ctrlv_last_error(char* buf, size_t n);
 
@@ -90,7 +93,8 @@ int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
  * conv_norm_out (unet_spatio_temporal_condition.py:161-162).
  *   x  : [n_img*S, C] bf16, optionally the channel-concat of (x [.., c_split], x2 [.., C-c_split]) (torch.cat dim=1)
  *   statistics are taken per (img / imgs_per_stat, group): imgs_per_stat = 1 (4-D) or F (5-D)
- *   stats pass writes fp32 partial sums into `partials` [n_stat, n_chunks, 32, 2]; apply pass reduces them in fp64.
+ *   stats pass writes per-chunk fp32 (mean, M2 = sum (x - mean)^2) into `partials` [n_stat, n_chunks, 32, 2]
+ *   (accumulated about a pilot value, so |mean| >> std does not cancel); apply pass combines them in fp64.
  * ctrlv_groupnorm_chunks() returns n_chunks for a shape so the caller can size `partials`.
  * ------------------------------------------------------------------------------------------------------------------ */
 int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat);

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .blocks import (CrossAttnDownBlockSpatioTemporal, CrossAttnUpBlockSpatioTemporal, DownBlockSpatioTemporal,
-                     TimestepEmbedding, Timesteps, UNetMidBlockSpatioTemporal, UpBlockSpatioTemporal)
+                     TimestepEmbedding, Timesteps, UNetMidBlockSpatioTemporal, UpBlockSpatioTemporal, store)
 
 SVD_CONFIG = dict(
     sample_size=96, in_channels=8, out_channels=4,
@@ -59,10 +59,10 @@ class _EncoderMixin:
             timesteps = timesteps[None].to(sample.device)
         batch_size = sample.shape[0]
         timesteps = timesteps.expand(batch_size)
-        t_emb = self.time_proj(timesteps).to(dtype=sample.dtype)
-        emb = self.time_embedding(t_emb)
+        t_emb = store(self.time_proj(timesteps).to(dtype=sample.dtype))
+        emb = store(self.time_embedding(t_emb))
         time_embeds = self.add_time_proj(added_time_ids.flatten())
-        time_embeds = time_embeds.reshape((batch_size, -1)).to(emb.dtype)
+        time_embeds = store(time_embeds.reshape((batch_size, -1)).to(emb.dtype))
         return emb + self.add_embedding(time_embeds)
 
     def _down(self, sample, emb, encoder_hidden_states, image_only_indicator):
@@ -137,15 +137,15 @@ class UNetSpatioTemporalConditionModel(nn.Module, _EncoderMixin):
         sample = sample.flatten(0, 1)                                                        # :89
         emb = emb.repeat_interleave(num_frames, dim=0)                                       # :92
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)   # :94
-        sample = self.conv_in(sample)                                                        # :97
+        sample = store(self.conv_in(sample))                                                 # :97
         image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
         sample, down_block_res_samples = self._down(sample, emb, encoder_hidden_states, image_only_indicator)
         if is_controlnet:                                                                    # :119-127
-            down_block_res_samples = tuple(s + r for s, r in zip(down_block_res_samples,
-                                                                 down_block_additional_residuals))
+            down_block_res_samples = tuple(store(s + r) for s, r in zip(down_block_res_samples,
+                                                                        down_block_additional_residuals))
         sample = self.mid_block(sample, emb, encoder_hidden_states, image_only_indicator)   # :130-135
         if is_controlnet:
-            sample = sample + mid_block_additional_residuals                                 # :136-137
+            sample = store(sample + mid_block_additional_residuals)                          # :136-137
         for blk in self.up_blocks:                                                           # :140-158
             res_samples = down_block_res_samples[-len(blk.resnets):]
             down_block_res_samples = down_block_res_samples[: -len(blk.resnets)]
@@ -153,7 +153,7 @@ class UNetSpatioTemporalConditionModel(nn.Module, _EncoderMixin):
                 sample = blk(sample, res_samples, emb, encoder_hidden_states, image_only_indicator)
             else:
                 sample = blk(sample, res_samples, emb, image_only_indicator)
-        sample = self.conv_out(self.conv_act(self.conv_norm_out(sample)))                    # :161-163
+        sample = store(self.conv_out(store(self.conv_act(self.conv_norm_out(sample)))))      # :161-163
         sample = sample.reshape(batch_size, num_frames, *sample.shape[1:])                   # :166
         return (sample,)
 
@@ -231,14 +231,14 @@ class ControlNetModel(nn.Module, _EncoderMixin):
         control_cond = control_cond.flatten(0, 1)
         emb = emb.repeat_interleave(num_frames, dim=0)
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)
-        sample = self.conv_in(sample) + self.control_conv_in(control_cond)                   # :297-299
+        sample = store(self.conv_in(sample) + self.control_conv_in(control_cond))            # :297-299
         image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
         sample, down_block_res_samples = self._down(sample, emb, encoder_hidden_states, image_only_indicator)
         sample = self.mid_block(sample, emb, encoder_hidden_states, image_only_indicator)   # :322-327
         down = [blk(s) for s, blk in zip(down_block_res_samples, self.controlnet_down_blocks)]   # :331-337
         mid = self.controlnet_mid_block(sample)                                              # :339
-        down = [s * conditioning_scale for s in down]                                        # :343
-        mid = mid * conditioning_scale                                                       # :344
+        down = [store(s * conditioning_scale) for s in down]                                 # :343
+        mid = store(mid * conditioning_scale)                                                # :344
         return (down, mid)
 
 

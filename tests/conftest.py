@@ -17,7 +17,6 @@ def pytest_configure(config):
 def hip_lib():
     """Builds (if stale) and loads libctrlv_hip.so; GPU tests fail loudly if the native library is missing."""
     import __graft_entry__ as g
-    if not os.path.exists(g.LIB):
-        g.build()
+    g.build()             # no-op when the library's build id matches the hash of csrc/ + include/
     from ctrlv_amd import _lib
     return _lib.load()

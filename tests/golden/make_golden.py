@@ -52,7 +52,52 @@ def block_vectors():
     tr = R.TransformerSpatioTemporalModel(1, 64, C, 64)
     R.seeded_init_(tr, 12)
     out["tr_x"], out["tr_ehs"], out["tr_y"] = npy(x), npy(ehs), npy(tr(x, ehs, ind))
+    out.update(block_vectors_q())
     np.savez_compressed(os.path.join(HERE, "block_vectors.npz"), **out)
+
+
+def q_(t):
+    return t.to(torch.bfloat16).float()
+
+
+def q_blocks():
+    """The three block instances of the `q*` fixtures: weights `seeded_init_` then rounded to bf16 (what the HIP path
+    holds), so the vectors isolate arithmetic / activation-storage differences from weight rounding."""
+    rb = R.seeded_init_(R.SpatioTemporalResBlock(64, 128, 256, eps=1e-6), 21)          # with a 1x1 shortcut
+    rc = R.seeded_init_(R.SpatioTemporalResBlock(64 + 128, 64, 256, eps=1e-5), 22)    # skip-concat input (up path)
+    tr = R.seeded_init_(R.TransformerSpatioTemporalModel(2, 64, 128, 64), 23)
+    for m in (rb, rc, tr):
+        for p_ in m.parameters():
+            p_.copy_(q_(p_))
+    return rb, rc, tr
+
+
+def block_vectors_q():
+    """Batch-2 (CFG-shaped) block fixtures on bf16-rounded weights and inputs, B = 2 clips x F = 3 frames x 8 x 8.
+    `*_y` = fp32 arithmetic; `*_ys` = fp32 arithmetic with bf16 rounding at the HIP path's storage points
+    (ctrlv_ref.storage_rounding)."""
+    g = torch.Generator().manual_seed(9)
+    B, F, H, W = 2, 3, 8, 8
+    ind = torch.zeros(B, F)
+    rb, rc, tr = q_blocks()
+    x = q_(torch.randn(B * F, 64, H, W, generator=g))
+    skip = q_(torch.randn(B * F, 128, H, W, generator=g) * 1.5)
+    xt = q_(torch.randn(B * F, 128, H, W, generator=g))
+    temb_b = q_(torch.randn(B, 256, generator=g))
+    ehs_b = q_(torch.randn(B, 1, 64, generator=g))
+    temb, ehs = temb_b.repeat_interleave(F, 0), ehs_b.repeat_interleave(F, 0)
+    out = {"q_x": npy(x), "q_skip": npy(skip), "q_xt": npy(xt), "q_temb": npy(temb_b), "q_ehs": npy(ehs_b)}
+    for tag, ctx in (("y", None), ("ys", R.storage_rounding(torch.bfloat16))):
+        if ctx is not None:
+            ctx.__enter__()
+        out["qres_" + tag] = npy(rb(x, temb, ind))
+        out["qcat_" + tag] = npy(rc(torch.cat([x, skip], 1), temb, ind))
+        for order in ("sb", "bs"):
+            tr.time_context_order = order
+            out[f"qtr_{order}_{tag}"] = npy(tr(xt, ehs, ind))
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return out
 
 
 def model_vectors():

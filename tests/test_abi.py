@@ -22,7 +22,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header out of sync"
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ctrlv_abi_version() == 1
+    assert lib.ctrlv_abi_version() == _lib.ABI_VERSION
+    assert _lib.build_id(lib) == _lib.source_build_id() == g.source_build_id()
 
 
 def test_host_side_argument_errors_do_not_need_a_gpu():

@@ -16,10 +16,23 @@ def _free_port():
     return p
 
 
-def _clip_result(seed, clip):
-    from ctrlv_amd.distributed import clip_generator
-    g = clip_generator(seed, clip)
-    return torch.randn(4, generator=g).sum().item()      # stands in for one clip's sampling loop
+def _sample_clip(clip, generator, steps=6):
+    """One clip's sampling loop with the product's host logic -- ctrlv_amd.schedulers.EulerDiscreteScheduler (Karras
+    schedule, scale_model_input, v-prediction Euler step), per-frame guidance, CFG combine
+    (pipeline_video_control.py:287-332) -- around a deterministic stand-in for the two HIP model forwards, which cannot
+    run without a GPU."""
+    from ctrlv_amd.schedulers import EulerDiscreteScheduler
+    sched = EulerDiscreteScheduler()
+    sched.set_timesteps(steps)
+    F = 3
+    latents = torch.randn(1, F, 4, 8, 8, generator=generator) * sched.init_noise_sigma
+    guidance = torch.linspace(1.0, 3.0, F)[None, :, None, None, None]
+    for t in sched.timesteps:
+        x = sched.scale_model_input(torch.cat([latents] * 2), t)
+        v = torch.tanh(0.3 * x) * torch.tensor([0.5, 1.0])[:, None, None, None, None]      # (uncond, cond) "model"
+        v_u, v_c = v.chunk(2)
+        latents = sched.step(v_u + guidance * (v_c - v_u), t, latents).prev_sample
+    return latents
 
 
 def _worker(rank, world, port, out):
@@ -27,13 +40,11 @@ def _worker(rank, world, port, out):
                       MASTER_PORT=str(port))
     from ctrlv_amd import distributed as D
     r, w, _ = D.init("gloo")
-    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
-    mine = D.shard_clips(7, r, w)
-    res = {c: _clip_result(1234, c) for c in mine}
-    D.barrier()
-    t = D.max_over_ranks(1.0 + rank)                      # slowest rank defines the elapsed time
-    n = D.sum_over_ranks(len(mine))
-    out.put((rank, mine, res, t, n))
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo" and D.world_size() == world and D.rank() == rank
+    res, elapsed = D.run_clips(7, _sample_clip, seed=1234)          # the product's batch-shard driver
+    t = D.max_over_ranks(1.0 + rank)                                # slowest rank defines the elapsed time
+    n = D.sum_over_ranks(len(res))
+    out.put((rank, sorted(res), {c: v.numpy().tobytes() for c, v in res.items()}, t, n, elapsed))
     dist.destroy_process_group()
 
 
@@ -48,12 +59,40 @@ def test_clip_sharding_over_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    got.sort()
+    got.sort(key=lambda g: g[0])
     assert got[0][1] == [0, 2, 4, 6] and got[1][1] == [1, 3, 5]
     assert all(g[3] == 2.0 for g in got) and all(g[4] == 7 for g in got)
+    assert got[0][5] == got[1][5] > 0                               # both ranks report the same (max) elapsed time
     merged = {**got[0][2], **got[1][2]}
-    single = {c: _clip_result(1234, c) for c in range(7)}     # what a 1-rank run computes
-    assert merged == single
+    from ctrlv_amd import distributed as D
+    single, _ = D.run_clips(7, _sample_clip, seed=1234, rank=0, world=1)   # what a 1-rank run computes
+    assert sorted(merged) == list(range(7))
+    assert all(merged[c] == single[c].numpy().tobytes() for c in range(7))   # bit-identical per clip, any world size
+    assert len({merged[c] for c in range(7)}) == 7                          # ... and the clips differ from each other
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment starts the two rank processes itself (the parent makes
+    no GPU call) and relays rank 0's JSON; `n_gpus` is the world size the process group reports.  Launcher self-test
+    mode (`--launcher-selftest`: gloo, no models) -- the only part of the N > 1 path that can run without GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--launcher-selftest"], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["launcher_selftest"] is True and out["value"] is None
+    assert out["ranks_seen"] == [0, 1]
+    # a torchrun-style environment whose world size disagrees with --gpus is an error, not a silent 1-GPU run
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=120, env=env1)
+    assert r.returncode != 0 and "process group has 1 ranks" in (r.stderr + r.stdout)
 
 
 def test_shard_helpers_single_process():

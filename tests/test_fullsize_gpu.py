@@ -15,15 +15,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.parity_utils import parity_err, rel_l2  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 N_IMG, FR, H, W = 50, 25, 72, 128          # CFG batch 2 x 25 frames, latent 72 x 128
 S0 = H * W
-
-
-def rel_l2(a, b):
-    a, b = a.float(), b.float()
-    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
 def g(seed):
@@ -58,7 +55,7 @@ def test_conv3x3_l0_fullsize(ops):
         ref = F.conv2d(x[n0:n0 + 5].float(), wt.to(torch.bfloat16).float(), b, padding=1)
         ref = ref + temb[n0 // FR][None, :, None, None]
         got = out[n0 * S0:(n0 + 5) * S0].reshape(5, H, W, c).permute(0, 3, 1, 2)
-        err.append(rel_l2(got, ref))
+        err.append(parity_err(got, ref))
     assert max(err) < 3e-3, err
 
 
@@ -77,7 +74,7 @@ def test_temporal_conv_l0_fullsize(ops):
         xin = x[bi].permute(3, 0, 1, 2).unsqueeze(0).float()      # (1, c, f, y, x)
         ref = F.conv3d(xin, wt.to(torch.bfloat16).float(), b, padding=(1, 0, 0))[0]       # (c, f, y, x)
         ref = 0.5 * ref.permute(1, 2, 3, 0).reshape(FR * S0, c) + res[bi * FR * S0:(bi + 1) * FR * S0].float()
-        assert rel_l2(out[bi * FR * S0:(bi + 1) * FR * S0], ref) < 3e-3
+        assert parity_err(out[bi * FR * S0:(bi + 1) * FR * S0], ref) < 3e-3
 
 
 def test_geglu_and_residual_linear_l0_fullsize(ops):
@@ -101,8 +98,8 @@ def test_geglu_and_residual_linear_l0_fullsize(ops):
         sl = slice(m0, m0 + 46080)
         proj = a[sl].float() @ w1r.T + b1
         ref_h = proj[:, :4 * c] * F.gelu(proj[:, 4 * c:])
-        e1.append(rel_l2(hid[sl], ref_h))
-        e2.append(rel_l2(out[sl], hid[sl].float() @ w2r.T + b2 + res[sl].float()))
+        e1.append(parity_err(hid[sl], ref_h))
+        e2.append(parity_err(out[sl], hid[sl].float() @ w2r.T + b2 + res[sl].float()))
     assert max(e1) < 3e-3 and max(e2) < 3e-3, (e1, e2)
 
 
@@ -118,7 +115,7 @@ def test_attention_spatial_l0_fullsize(ops):
         s = (q @ k.transpose(-1, -2)) / 8.0                                   # (1, 5, 9216, 9216) fp32 = 1.7 GB
         ref = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(S0, c)
         del s
-        assert rel_l2(out[i * S0:(i + 1) * S0], ref) < 5e-3
+        assert parity_err(out[i * S0:(i + 1) * S0], ref) < 5e-3
 
 
 def test_groupnorm_temporal_l0_fullsize(ops):
@@ -133,7 +130,7 @@ def test_groupnorm_temporal_l0_fullsize(ops):
     for bi in range(2):
         xin = x[bi * FR * S0:(bi + 1) * FR * S0].float().reshape(1, FR * S0, c).permute(0, 2, 1)   # (1, c, f*s)
         ref = F.silu(F.group_norm(xin, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(FR * S0, c)
-        assert rel_l2(y[bi * FR * S0:(bi + 1) * FR * S0], ref) < 3e-3
+        assert parity_err(y[bi * FR * S0:(bi + 1) * FR * S0], ref) < 3e-3
 
 
 # ------------------------------------------------------------------------------------------------ whole step
@@ -189,8 +186,8 @@ def test_fullsize_step_properties(models):
     assert not torch.equal(both, full)                                # ... and the quirk is observable at B = 2
     # the ControlNet branch is linear in conditioning_scale (scale is folded into the zero-conv epilogue)
     _, down2, mid2 = fwd(slice(0, 2), scale=2.0)
-    assert rel_l2(mid2, 2.0 * mid1.float()) < 4e-3
-    assert max(rel_l2(d2, 2.0 * d1.float()) for d1, d2 in zip(down1, down2)) < 4e-3
+    assert parity_err(mid2, 2.0 * mid1.float()) < 4e-3
+    assert max(parity_err(d2, 2.0 * d1.float()) for d1, d2 in zip(down1, down2)) < 4e-3
     assert len(down1) == 12 and down1[0].shape == (N_IMG, 320, H, W) and mid1.shape == (N_IMG, 1280, 9, 16)
     # residuals matter (non-zero zero-convs) ...
     plain, _, _ = fwd(slice(0, 2), use_ctrl=False)

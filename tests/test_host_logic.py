@@ -201,6 +201,58 @@ def test_pipeline_input_checks_and_helpers():
     assert not pipe.do_classifier_free_guidance
 
 
+def test_pipeline_from_pretrained_resolution_rules(tmp_path, monkeypatch):
+    """from_pretrained as the reference's tools call it (tools/eval_video_controlnet.py:116-118,
+    tools/train_video_controlnet.py:344-353): overrides win, unet/controlnet/scheduler load from the directory, the
+    PyTorch-side components go through (overridable) loaders, a hub id resolves to a local copy or fails loudly."""
+    from ctrlv_amd.pipelines import StableVideoControlPipeline, VideoDiffusionPipeline
+    from ctrlv_amd.schedulers import EulerDiscreteScheduler
+    from tests.fakes import FakeCLIP, FakeVAE, fake_feature_extractor
+    pipe = _pipeline()
+    pipe.vae, pipe.image_encoder, pipe.feature_extractor = FakeVAE(), FakeCLIP(64), fake_feature_extractor
+    ck = tmp_path / "stabilityai" / "stable-video-diffusion-img2vid-xt"
+    pipe.save_pretrained(str(ck))
+    assert (ck / "model_index.json").is_file() and (ck / "scheduler" / "scheduler_config.json").is_file()
+    sched = EulerDiscreteScheduler.from_pretrained(str(ck), subfolder="scheduler")
+    assert sched.config["sigma_max"] == 700.0 and sched.config["prediction_type"] == "v_prediction"
+    assert EulerDiscreteScheduler.from_config({"_class_name": "EulerDiscreteScheduler", "sigma_max": 500.0,
+                                               "trained_betas": None}).config["sigma_max"] == 500.0
+    with pytest.raises(NotImplementedError):
+        EulerDiscreteScheduler.from_config({"prediction_type": "epsilon"})
+    for n in ("vae", "image_encoder", "feature_extractor"):
+        (ck / n).mkdir(exist_ok=True)
+    seen = []
+    loaders = {"vae": lambda p, **k: seen.append(("vae", p, k)) or FakeVAE(),
+               "image_encoder": lambda p, **k: seen.append(("image_encoder", p, k)) or FakeCLIP(64),
+               "feature_extractor": lambda p, **k: fake_feature_extractor}
+    # (1) everything from the directory
+    p1 = StableVideoControlPipeline.from_pretrained(str(ck), component_loaders=loaders, variant=None, revision=None)
+    assert [s_[0] for s_ in seen] == ["vae", "image_encoder"] and seen[0][1] == str(ck / "vae")
+    assert sorted(p1.unet.state_dict()) == sorted(pipe.unet.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(p1.controlnet.state_dict().values(),
+                                                 pipe.controlnet.state_dict().values()))
+    # (2) the eval tools: hub id + model overrides; the id resolves through $CTRLV_MODEL_ROOT
+    monkeypatch.setenv("CTRLV_MODEL_ROOT", str(tmp_path))
+    p2 = StableVideoControlPipeline.from_pretrained("stabilityai/stable-video-diffusion-img2vid-xt",
+                                                    controlnet=pipe.controlnet, unet=pipe.unet,
+                                                    component_loaders=loaders)
+    assert p2.unet is pipe.unet and p2.controlnet is pipe.controlnet and isinstance(p2.vae, FakeVAE)
+    p2.to("cpu"); p2.set_progress_bar_config(disable=True)
+    # (3) the training tool: every module passed in -> no directory needed at all (scheduler = SVD defaults)
+    monkeypatch.delenv("CTRLV_MODEL_ROOT")
+    p3 = StableVideoControlPipeline.from_pretrained("no/such-model", unet=pipe.unet, controlnet=pipe.controlnet,
+                                                    vae=pipe.vae, image_encoder=pipe.image_encoder,
+                                                    feature_extractor=fake_feature_extractor, revision=None,
+                                                    variant=None, torch_dtype=torch.float32)
+    assert isinstance(p3.scheduler, EulerDiscreteScheduler) and p3.scheduler.config["sigma_max"] == 700.0
+    # (4) UNet-only pipeline takes no controlnet; a missing component without a directory fails loudly
+    p4 = VideoDiffusionPipeline.from_pretrained(str(ck), unet=pipe.unet, component_loaders=loaders)
+    assert not hasattr(p4, "controlnet") and p4.unet is pipe.unet
+    with pytest.raises(EnvironmentError, match="never downloads"):
+        StableVideoControlPipeline.from_pretrained("no/such-model", unet=pipe.unet, controlnet=pipe.controlnet)
+    assert StableVideoControlPipeline.use_hip_graph      # graph replay is the default loop mode
+
+
 def test_image_processor_and_tensor2vid():
     from ctrlv_amd.pipelines.pipeline_utils import VaeImageProcessor, _resize_with_antialiasing, tensor2vid
     ip = VaeImageProcessor(8)

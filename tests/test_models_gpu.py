@@ -1,30 +1,46 @@
 """GPU parity of the HIP UNet / ControlNet against the CPU oracle (same seeded bf16-rounded weights, same inputs).
 
-Tolerance: the HIP path stores activations in bf16 (fp32 accumulation / statistics), the oracle runs fp32.  Through
-the 38 (UNet) + 17 (ControlNet) sequential blocks the bf16 storage rounding (2^-9 relative per store) accumulates as
-a random walk; the asserted bound on the relative L2 error of the final tensors is 1.5e-2, and the per-op bound of
-tests/test_ops_gpu.py (3e-3) is the gate that localises a real defect.  north_star's "1e-3 relative bf16 tolerance"
-is met per kernel in fp32-output mode (test_gemm_plain_epilogue: 1e-4).
+Three comparisons per case (tests/parity_utils.run_parity), every bound rel-L2 AND element-wise (`parity_err`):
+
+  storage  HIP vs the fp32 oracle with bf16 rounding at exactly the HIP path's activation-storage points
+           (ctrlv_ref.storage_rounding).  This is the arithmetic check: what remains is accumulation
+           order and flipped roundings that re-amplify through 55 blocks.  Bound TOL_STORAGE.
+  fp32     HIP vs the plain fp32 oracle.  Dominated by bf16 activation storage (each block contributes 2-3e-3, see
+           tests/test_oracle.py::test_golden_block_vectors_bf16_weights_and_storage_rounding).  Bound TOL_FP32.
+  yardstick  the same network executed by PyTorch itself in bf16 on the GPU (rocBLAS / MIOpen / SDPA) vs the fp32
+           oracle: HIP's error must not exceed it by more than 10 %.
+
+north_star's "1e-3 relative bf16 tolerance" holds per kernel (tests/test_ops_gpu.py: 1e-4 with fp32 output) and per
+block against the storage-rounded oracle (tests/test_blocks_gpu.py: 2e-3); through the whole network bf16 storage
+itself costs ~1e-2 whoever executes it, which the yardstick demonstrates.
 """
 import pytest
 import torch
 
-from tests.parity_utils import make_inputs, make_pair, rel_l2, run_tiny_parity
+from tests.parity_utils import make_inputs, make_pair, run_parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = 1.5e-2
+TOL_FP32 = 1.5e-2
+TOL_STORAGE = 6e-3
+
+
+def check_tables(err):
+    assert max(err["storage"].values()) < TOL_STORAGE, err
+    assert max(err["fp32"].values()) < TOL_FP32, err
+    for k, v in err["torch_bf16"].items():
+        assert err["fp32_l2"][k] <= 1.1 * v + 1e-4, (k, err["fp32_l2"][k], v)
 
 
 @pytest.mark.parametrize("order", ["sb", "bs"])
 def test_tiny_unet_controlnet_parity(hip_lib, order):
-    err = run_tiny_parity(DEV, B=2, F=3, h=16, w=16, time_context_order=order, verbose=True)
-    assert max(err.values()) < TOL, err
+    import ctrlv_ref as R
+    check_tables(run_parity(dict(R.TINY_CONFIG), DEV, B=2, F=3, h=16, w=16, time_context_order=order, verbose=True))
 
 
 def test_tiny_parity_batch1_ragged(hip_lib):
-    err = run_tiny_parity(DEV, B=1, F=5, h=24, w=8, verbose=True)
-    assert max(err.values()) < TOL, err
+    import ctrlv_ref as R
+    check_tables(run_parity(dict(R.TINY_CONFIG), DEV, B=1, F=5, h=24, w=8, verbose=True))
 
 
 @torch.no_grad()

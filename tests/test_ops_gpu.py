@@ -12,13 +12,10 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.parity_utils import parity_err, rel_l2  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-def rel_l2(a, b):
-    a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
 def bf(x):
@@ -70,29 +67,29 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
         with pytest.raises(ValueError):
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, tile=tile)
         ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd)
-        assert rel_l2(out, lin) < 3e-3
+        assert parity_err(out, lin) < 3e-3
         return
     # bias + scale + R1 + R2  (AlphaBlender-folded FF output)
     ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7, tile=tile)
-    assert rel_l2(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float()) < 3e-3
+    assert parity_err(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float()) < 3e-3
     # bias + R1 + V (vmode 1), and the diffusers-0.27.2 context-order quirk map (vmode 2)
     ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, V=Vd, vmode=1, vdiv=13, vmod=7, tile=tile)
-    assert rel_l2(out, lin + R1.float() + V[vidx]) < 3e-3
+    assert parity_err(out, lin + R1.float() + V[vidx]) < 3e-3
     ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, V=Vd, vmode=2, vdiv=50, vS=10, vmod=7, tile=tile)
-    assert rel_l2(out, lin + R1.float() + V[vidx2]) < 3e-3
+    assert parity_err(out, lin + R1.float() + V[vidx2]) < 3e-3
     # bias + V only, bias only, nothing
     ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, V=Vd, vmode=1, vdiv=13, vmod=7, tile=tile)
-    assert rel_l2(out, lin + V[vidx]) < 3e-3
+    assert parity_err(out, lin + V[vidx]) < 3e-3
     ops.gemm(Ad, Wd, out, N=N, cin=K, tile=tile)
-    assert rel_l2(out, lin - bias) < 3e-3
+    assert parity_err(out, lin - bias) < 3e-3
     if tile <= 4:
         # all operands at once, SiLU, fp32 output
         ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7, V=Vd, vmode=1, vdiv=13,
                  vmod=7, tile=tile)
-        assert rel_l2(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float() + V[vidx]) < 3e-3
+        assert parity_err(out, 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float() + V[vidx]) < 3e-3
         out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
         ops.gemm(Ad, Wd, out32, N=N, cin=K, bias=bd, V=Vd, vmode=2, vdiv=50, vS=10, vmod=7, act=1, out_f32=True, tile=tile)
-        assert rel_l2(out32, F.silu(lin + V[vidx2])) < 1e-4
+        assert parity_err(out32, F.silu(lin + V[vidx2])) < 1e-4
     else:
         with pytest.raises(ValueError):      # explicit ping-pong tile with an operand set it does not serve
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
@@ -111,7 +108,7 @@ def test_gemm_geglu(ops, tile):
     ref = proj[:, :4 * C] * F.gelu(proj[:, 4 * C:])
     out = torch.empty(M, 4 * C, dtype=torch.bfloat16, device=DEV)
     ops.gemm(A.to(DEV), Wp.to(DEV), out, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, tile=tile)
-    assert rel_l2(out, ref) < 3e-3
+    assert parity_err(out, ref) < 3e-3
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
@@ -131,7 +128,7 @@ def test_gemm_conv3x3(ops, tile, stride, up):
     out = torch.empty(n * Ho * Wo, cout, dtype=torch.bfloat16, device=DEV)
     ops.gemm(rows_from_nchw(x).to(DEV), Wp.to(DEV), out, N=cout, cin=cin, taps=9, mode=1,
              conv=(H, W, Ho, Wo, stride, up), bias=b.to(DEV), tile=tile)
-    assert rel_l2(nchw_from_rows(out.cpu(), n, Ho, Wo), ref) < 3e-3
+    assert parity_err(nchw_from_rows(out.cpu(), n, Ho, Wo), ref) < 3e-3
 
 
 @pytest.mark.parametrize("tile", [1, 4, 5, 6])
@@ -147,7 +144,7 @@ def test_gemm_temporal_conv(ops, tile):
     ops.gemm(rows.to(DEV), packing.pack_conv_temporal(wt).to(DEV), out, N=C, cin=C, taps=3, mode=2,
              temporal=(Fr, H * W), bias=b.to(DEV), tile=tile)
     got = out.cpu().reshape(B, Fr, H, W, C).permute(0, 4, 1, 2, 3)
-    assert rel_l2(got, ref) < 3e-3
+    assert parity_err(got, ref) < 3e-3
 
 
 @pytest.mark.parametrize("tile", [0, 5, 6])
@@ -159,7 +156,7 @@ def test_gemm_concat_split(ops, tile):
     ref = torch.cat([a1, a2], 1).float() @ bf(wt).float().T
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     ops.gemm(a1.to(DEV), packing.pack_linear(wt).to(DEV), out, N=N, cin=C1 + C2, A2=a2.to(DEV), c_split=C1, tile=tile)
-    assert rel_l2(out, ref) < 3e-3
+    assert parity_err(out, ref) < 3e-3
     # 3x3 conv over a channel concat (the up-block skip-concat path reads both tensors in place)
     n, H, W = 2, 6, 8
     x1, x2 = bf(torch.randn(n, C1, H, W, generator=g(4))), bf(torch.randn(n, C2, H, W, generator=g(5)))
@@ -174,7 +171,7 @@ def test_gemm_concat_split(ops, tile):
         with pytest.raises(ValueError):
             ops.gemm(rows_from_nchw(x1).to(DEV), packing.pack_conv3x3(wc).to(DEV), outc, tile=tile, **ckw)
     ops.gemm(rows_from_nchw(x1).to(DEV), packing.pack_conv3x3(wc).to(DEV), outc, tile=0, **ckw)
-    assert rel_l2(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
+    assert parity_err(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
 @pytest.mark.parametrize("tile", [5, 6, 7, 8])
@@ -190,7 +187,7 @@ def test_gemm_persistent_many_tiles(ops, tile):
     out = torch.empty(n * H * W, cout, dtype=torch.bfloat16, device=DEV)
     ops.gemm(rows_from_nchw(x).to(DEV), packing.pack_conv3x3(wt).to(DEV), out, N=cout, cin=cin, taps=9, mode=1,
              conv=(H, W, H, W, 1, 0), bias=b.to(DEV), tile=tile)
-    assert rel_l2(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
+    assert parity_err(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
     # shortest K the ping-pong tiles take (4 half-steps per tile: the ring always holds pieces of two tiles at once)
     M = 86400
     A = bf(torch.randn(M, 128, generator=g(4)))
@@ -198,7 +195,7 @@ def test_gemm_persistent_many_tiles(ops, tile):
     R1 = bf(torch.randn(M, 640, generator=g(6)))
     outl = torch.empty(M, 640, dtype=torch.bfloat16, device=DEV)
     ops.gemm(A.to(DEV), packing.pack_linear(wl).to(DEV), outl, N=640, cin=128, R1=R1.to(DEV), tile=tile)
-    assert rel_l2(outl, A.float() @ bf(wl).float().T + R1.float()) < 3e-3
+    assert parity_err(outl, A.float() @ bf(wl).float().T + R1.float()) < 3e-3
 
 
 def test_gemm_small_m_and_padding(ops):
@@ -211,7 +208,7 @@ def test_gemm_small_m_and_padding(ops):
     assert Wp.shape[0] == 32
     out = torch.zeros(2, 4, dtype=torch.bfloat16, device=DEV)
     ops.gemm(A.to(DEV), Wp.to(DEV), out, N=32, cin=256, bias=bp.to(DEV), n_store=4)
-    assert rel_l2(out, A.float() @ bf(wt).float().T + b) < 3e-3
+    assert parity_err(out, A.float() @ bf(wt).float().T + b) < 3e-3
 
 
 def test_gemm_bad_args_raise(ops):
@@ -239,7 +236,32 @@ def test_groupnorm(ops, C, H, W, n, ips, silu):
     y = torch.empty_like(rows)
     part = torch.empty(n * ops.groupnorm_chunks(n, S, C, ips) * 64, dtype=torch.float32, device=DEV)
     ops.groupnorm(rows, None, n, S, C, ips, gamma.to(DEV), beta.to(DEV), 1e-5, silu, y, part)
-    assert rel_l2(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
+    assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
+
+
+@pytest.mark.parametrize("mean,std", [(30.0, 0.25), (-200.0, 1.0), (1000.0, 4.0)])
+@pytest.mark.parametrize("ips", [1, 3])
+def test_groupnorm_large_mean_small_variance(ops, mean, std, ips):
+    """|mean| >> std: E[x^2] - mean^2 in fp32 would lose the variance (mean^2/var = 1.4e4 .. 6e4 here, and bf16 inputs
+    near 1000 are spaced 4 apart); the statistics pass accumulates about a pilot value per chunk and combines chunks
+    with Chan's formula in fp64.  Reference: fp64 group_norm on the same bf16-rounded inputs.  Per-channel offsets
+    make the group (10 channels at C = 320) itself inhomogeneous."""
+    n, C, H, W = 6, 320, 18, 32
+    S = H * W
+    x = torch.randn(n, C, H, W, generator=g(1)) * std + mean + torch.randn(1, C, 1, 1, generator=g(2)) * std
+    x = bf(x)
+    gamma, beta = torch.randn(C, generator=g(3)), torch.randn(C, generator=g(4))
+    xd = x.double()
+    if ips == 1:
+        ref = F.group_norm(xd, 32, gamma.double(), beta.double(), 1e-6)
+    else:
+        x5 = xd.reshape(n // ips, ips, C, H, W).permute(0, 2, 1, 3, 4)
+        ref = F.group_norm(x5, 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 1, 3, 4).reshape(n, C, H, W)
+    rows = rows_from_nchw(x).to(DEV)
+    y = torch.empty_like(rows)
+    part = torch.empty(n * ops.groupnorm_chunks(n, S, C, ips) * 64, dtype=torch.float32, device=DEV)
+    ops.groupnorm(rows, None, n, S, C, ips, gamma.to(DEV), beta.to(DEV), 1e-6, False, y, part)
+    assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref.float(), f"GN mean {mean} std {std}") < 3e-3
 
 
 def test_groupnorm_concat(ops):
@@ -252,7 +274,7 @@ def test_groupnorm_concat(ops):
     part = torch.empty(n * ops.groupnorm_chunks(n, H * W, C, 1) * 64, dtype=torch.float32, device=DEV)
     ops.groupnorm(rows_from_nchw(x1).to(DEV), rows_from_nchw(x2).to(DEV), n, H * W, C, 1, gamma.to(DEV), beta.to(DEV),
                   1e-6, True, y, part)
-    assert rel_l2(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
+    assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
 
 
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
@@ -262,11 +284,11 @@ def test_layernorm(ops, C):
     gamma, beta = torch.randn(C, generator=g(2)), torch.randn(C, generator=g(3))
     y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
     ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, y)
-    assert rel_l2(y, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < 3e-3
+    assert parity_err(y, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < 3e-3
     V = torch.randn(5, C, generator=g(4))
     ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, y, V=V.to(DEV), vdiv=20, vmod=5)
     vi = (torch.arange(M) // 20) % 5
-    assert rel_l2(y, F.layer_norm(x.float() + V[vi], (C,), gamma, beta, 1e-5)) < 3e-3
+    assert parity_err(y, F.layer_norm(x.float() + V[vi], (C,), gamma, beta, 1e-5)) < 3e-3
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -286,7 +308,7 @@ def test_attention_spatial(ops, n_img, S, C):
     ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(n_img * S, C)
     out = torch.empty(n_img * S, C, dtype=torch.bfloat16, device=DEV)
     ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
-    assert rel_l2(out, ref) < 5e-3
+    assert parity_err(out, ref) < 5e-3
 
 
 @pytest.mark.parametrize("S,kpk", [(320, 300), (1280, 1200)])
@@ -303,7 +325,7 @@ def test_attention_spatial_peaked(ops, S, kpk):
     ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(S, C)
     out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
     ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
-    assert rel_l2(out, ref) < 5e-3
+    assert parity_err(out, ref) < 5e-3
 
 
 @pytest.mark.parametrize("S", [448, 1216])
@@ -326,7 +348,7 @@ def test_attention_spatial_large_scores(ops, S, scale):
     out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
     ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
     assert torch.isfinite(out.float()).all()
-    assert rel_l2(out, ref) < 6e-3
+    assert parity_err(out, ref) < 6e-3
 
 
 @pytest.mark.parametrize("B,Fr,S,C", [(2, 25, 10, 128), (1, 3, 7, 64), (2, 32, 5, 320), (1, 1, 3, 64)])
@@ -338,7 +360,7 @@ def test_attention_temporal(ops, B, Fr, S, C):
     ref = _sdpa_ref(q, k, v).reshape(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B * Fr * S, C)
     out = torch.empty(B * Fr * S, C, dtype=torch.bfloat16, device=DEV)
     ops.attention_temporal(qkv.to(DEV), out, B, Fr, S, C)
-    assert rel_l2(out, ref) < 5e-3
+    assert parity_err(out, ref) < 5e-3
 
 
 # ------------------------------------------------------------------------------------------------ element-wise
@@ -370,7 +392,7 @@ def test_im2col_conv_in(ops):
     ops.im2col3x3(x16, n, H, W, col)
     out = torch.empty(n * H * W, 64, dtype=torch.bfloat16, device=DEV)
     ops.gemm(col, packing.pack_conv_in([wa, wb], 16, 192).to(DEV), out, N=64, cin=192)
-    assert rel_l2(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
+    assert parity_err(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
 
 
 def test_axpby_silu_timesteps(ops):
@@ -380,7 +402,7 @@ def test_axpby_silu_timesteps(ops):
     ops.axpby(x.to(DEV), r.to(DEV), 1.0, 1.0, y)
     assert torch.equal(y.cpu(), bf(x.float() + r.float()))
     ops.silu(x.to(DEV), y)
-    assert rel_l2(y, F.silu(x.float())) < 3e-3
+    assert parity_err(y, F.silu(x.float())) < 3e-3
     import ctrlv_ref as R
     t = torch.tensor([1.6377, -0.7, 127.0, 6.0, 0.02])
     out = torch.empty(5, 320, dtype=torch.bfloat16, device=DEV)
@@ -407,5 +429,5 @@ def test_cfg_euler_step(ops, cfg):
     lat_d = lat.to(DEV).contiguous()
     scaled = torch.empty(B, Fr, C, h, w, dtype=torch.bfloat16, device=DEV)
     ops.cfg_euler_step(lat_d, pred.to(DEV), guid.to(DEV), float(sched.sigmas[3]), float(sched.sigmas[4]), scaled)
-    assert rel_l2(lat_d, ref) < 1e-5
-    assert rel_l2(scaled, ref / (float(sched.sigmas[4]) ** 2 + 1) ** 0.5) < 3e-3
+    assert parity_err(lat_d, ref) < 1e-5
+    assert parity_err(scaled, ref / (float(sched.sigmas[4]) ** 2 + 1) ** 0.5) < 3e-3

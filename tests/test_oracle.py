@@ -129,6 +129,31 @@ def test_golden_block_vectors():
     np.testing.assert_allclose(y.numpy(), gold["tr_y"], rtol=1e-4, atol=1e-5)
 
 
+def test_golden_block_vectors_bf16_weights_and_storage_rounding():
+    """The batch-2 block fixtures on bf16-rounded weights (`q*`), in plain fp32 and with bf16 rounding at the HIP
+    path's storage points; the storage-rounded variant differs from fp32 by a few 1e-3 per block (the budget the
+    whole-model tolerance is made of) and the marks are the identity outside `storage_rounding()`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(GOLD, "block_vectors.npz"))
+    with torch.no_grad():
+        new = mg.block_vectors_q()
+    for k, v in new.items():
+        np.testing.assert_allclose(v, gold[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    for k in ("qres", "qcat", "qtr_sb", "qtr_bs"):
+        y, ys = gold[k + "_y"], gold[k + "_ys"]
+        rel = np.linalg.norm(y - ys) / np.linalg.norm(y)
+        assert 5e-4 < rel < 8e-3, (k, rel)
+    assert np.abs(gold["qtr_sb_y"] - gold["qtr_bs_y"]).max() > 1e-2      # H1 quirk is visible at batch 2
+    x = torch.randn(4, 7)
+    assert R.store(x) is x
+    with R.storage_rounding():
+        assert torch.equal(R.store(x), x.to(torch.bfloat16).float())
+    assert R.store(x) is x
+
+
 @pytest.mark.parametrize("order", ["sb", "bs"])
 def test_golden_model_vectors(order):
     gold = np.load(os.path.join(GOLD, "model_vectors.npz"))

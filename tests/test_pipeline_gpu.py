@@ -7,60 +7,15 @@ latents are fp32 on both sides; with a 3-step Karras schedule (sigma 700 -> 15.6
 essentially x0 = c_out * v, so the final latents carry the models' ~1.3e-2 relative error (tests/test_models_gpu.py bound
 1.5e-2) amplified by the v-prediction mix (measured 3.1e-2); the first step, where the schedule is not degenerate,
 agrees to 7e-4."""
-import types
-
 import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.parity_utils import make_pair, rel_l2
+from tests.fakes import FakeCLIP, FakeVAE, fake_feature_extractor
+from tests.parity_utils import make_pair, parity_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-class _Dist:
-    def __init__(self, m):
-        self._m = m
-
-    def mode(self):
-        return self._m
-
-
-class FakeVAE(torch.nn.Module):
-    """Deterministic stand-in for AutoencoderKLTemporalDecoder: 8x average pool + fixed 3->4 channel mix."""
-
-    def __init__(self):
-        super().__init__()
-        g = torch.Generator().manual_seed(5)
-        self.mix = torch.nn.Parameter(torch.randn(4, 3, generator=g) * 0.5, requires_grad=False)
-        self.config = types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215, force_upcast=False)
-
-    @property
-    def dtype(self):
-        return self.mix.dtype
-
-    def encode(self, x):
-        lat = torch.einsum("oc,nchw->nohw", self.mix.to(x.dtype), F.avg_pool2d(x, 8))
-        return types.SimpleNamespace(latent_dist=_Dist(lat))
-
-    def decode(self, z, num_frames=None):
-        img = torch.einsum("oc,nohw->nchw", self.mix.to(z.dtype), z)
-        return types.SimpleNamespace(sample=F.interpolate(img, scale_factor=8.0, mode="nearest"))
-
-
-class FakeCLIP(torch.nn.Module):
-    def __init__(self, dim):
-        super().__init__()
-        g = torch.Generator().manual_seed(6)
-        self.proj = torch.nn.Parameter(torch.randn(dim, 3, generator=g), requires_grad=False)
-
-    def forward(self, pixel_values):
-        return types.SimpleNamespace(image_embeds=pixel_values.mean(dim=(2, 3)) @ self.proj.T.to(pixel_values.dtype))
-
-
-def fake_feature_extractor(images, **kw):
-    return types.SimpleNamespace(pixel_values=images)
 
 
 def _setup(order="sb"):
@@ -108,12 +63,14 @@ def test_box2video_pipeline_matches_oracle_loop(hip_lib):
     R, cfg, ou, oc, pipe, _, vae, clip = _setup()
     image, cond, latents = _inputs()
     ref = _oracle_run(R, ou, oc, vae, clip, image, cond, latents, steps=3)
+    assert pipe.use_hip_graph                      # HIP-graph replay is the default execution mode of the loop
+    pipe.use_hip_graph = False                     # eager launches first ...
     out = pipe(image.to(DEV, torch.bfloat16), cond_images=cond.to(DEV), height=128, width=128, num_frames=3,
                num_inference_steps=3, noise_aug_strength=0.0, latents=latents.to(DEV, torch.bfloat16),
                generator=torch.Generator().manual_seed(0), output_type="latent").frames
     assert out.shape == (1, 3, 4, 16, 16)
-    assert rel_l2(out, ref) < 5e-2
-    # HIP-graph replay (ControlNet on a side stream, concurrent with the UNet down path) gives bit-identical latents
+    assert parity_err(out, ref, 'pipeline latents') < 5e-2
+    # ... then HIP-graph replay (ControlNet on a side stream, concurrent with the UNet down path): bit-identical latents
     pipe.use_hip_graph = True
     out_g = pipe(image.to(DEV, torch.bfloat16), cond_images=cond.to(DEV), height=128, width=128, num_frames=3,
                  num_inference_steps=3, noise_aug_strength=0.0, latents=latents.to(DEV, torch.bfloat16),
@@ -143,13 +100,54 @@ def test_svd_pipeline_unet_only_and_callback(hip_lib):
     out = pipe2(image.to(DEV, torch.bfloat16), height=128, width=128, num_frames=3, num_inference_steps=3,
                 noise_aug_strength=0.0, latents=latents.to(DEV, torch.bfloat16), output_type="latent",
                 callback_on_step_end=cb).frames
-    assert rel_l2(out, ref) < 5e-2
+    assert parity_err(out, ref, 'pipeline latents') < 5e-2
     assert [s[0] for s in seen] == [0, 1, 2] and seen[0][2] == (1, 3, 4, 16, 16)
     # guidance <= 1 disables CFG (single-batch forwards); bbox frames are injected into the image latents
     out1 = pipe2(image.to(DEV, torch.bfloat16), bbox_images=cond.to(DEV), height=128, width=128, num_frames=3,
                  num_inference_steps=2, min_guidance_scale=1.0, max_guidance_scale=1.0,
                  latents=latents.to(DEV, torch.bfloat16), output_type="latent", num_cond_bbox_frames=1).frames
     assert out1.shape == (1, 3, 4, 16, 16) and torch.isfinite(out1.float()).all()
+
+
+@torch.no_grad()
+def test_from_pretrained_like_the_eval_tools(hip_lib, tmp_path):
+    """tools/eval_video_controlnet.py:113-122 after the import swap: models from `<ckpt>/unet`, `<ckpt>/controlnet`,
+    pipeline from a diffusers-layout directory with `controlnet=` / `unet=` overrides, `.to(device)`,
+    `.set_progress_bar_config(disable=True)`, call.  Results equal the directly constructed pipeline bit for bit;
+    a second call with another clip length re-captures the HIP graph."""
+    from ctrlv_amd.models import ControlNetModel, UNetSpatioTemporalConditionModel
+    from ctrlv_amd.pipelines import StableVideoControlPipeline, VideoDiffusionPipeline
+    R, cfg, ou, oc, pipe, _, vae, clip = _setup()
+    image, cond, latents = _inputs()
+    kw = dict(height=128, width=128, num_frames=3, num_inference_steps=3, noise_aug_strength=0.0, output_type="latent")
+    ref = pipe(image.to(DEV, torch.bfloat16), cond_images=cond.to(DEV), latents=latents.to(DEV, torch.bfloat16), **kw).frames
+    pipe.save_pretrained(str(tmp_path / "ckpt"))
+    for n in ("model_index.json", "unet/config.json", "controlnet/config.json", "scheduler/scheduler_config.json"):
+        assert (tmp_path / "ckpt" / n).is_file(), n
+    (tmp_path / "ckpt" / "vae").mkdir(exist_ok=True)
+    (tmp_path / "ckpt" / "image_encoder").mkdir(exist_ok=True)
+    (tmp_path / "ckpt" / "feature_extractor").mkdir(exist_ok=True)
+    loaders = {"vae": lambda p, **k: FakeVAE(), "image_encoder": lambda p, **k: FakeCLIP(cfg["cross_attention_dim"]),
+               "feature_extractor": lambda p, **k: fake_feature_extractor}
+    ctrlnet = ControlNetModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="controlnet")
+    unet = UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="unet")
+    p2 = StableVideoControlPipeline.from_pretrained(str(tmp_path / "ckpt"), controlnet=ctrlnet, unet=unet,
+                                                    component_loaders=loaders)
+    p2 = p2.to(DEV)
+    p2.to(torch.bfloat16)
+    p2.set_progress_bar_config(disable=True)
+    out = p2(image.to(DEV, torch.bfloat16), cond_images=cond.to(DEV), latents=latents.to(DEV, torch.bfloat16), **kw).frames
+    assert torch.equal(out, ref)
+    # every component from the directory (torch_dtype cast), UNet-only pipeline, and a different clip length
+    p3 = VideoDiffusionPipeline.from_pretrained(str(tmp_path / "ckpt"), torch_dtype=torch.bfloat16,
+                                                component_loaders=loaders).to(DEV)
+    image5, _, lat5 = _inputs(F_=5)
+    o3 = p3(image5.to(DEV, torch.bfloat16), height=128, width=128, num_frames=5, num_inference_steps=3,
+            latents=lat5.to(DEV, torch.bfloat16), output_type="latent").frames
+    o3b = p3(image.to(DEV, torch.bfloat16), height=128, width=128, num_frames=3, num_inference_steps=3,
+             latents=latents.to(DEV, torch.bfloat16), output_type="latent").frames
+    assert o3.shape == (1, 5, 4, 16, 16) and o3b.shape == (1, 3, 4, 16, 16)
+    assert torch.isfinite(o3.float()).all() and torch.isfinite(o3b.float()).all()
 
 
 def test_pipeline_rejects_bad_inputs(hip_lib):

@@ -44,9 +44,12 @@ def load(path, counter):
 def main():
     fetch, write, out = sys.argv[1:4]
     fe, wr = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
-    res = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches; FETCH doubled per the gfx950 "
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+    from ctrlv_amd import _lib
+    res = {"_build_id": _lib.source_build_id(),     # bench.py reports `traffic` only for the library this came from
+           "_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches; FETCH doubled per the gfx950 "
                     "calibration for wide coalesced reads; includes Infinity-Cache hits (fabric-side counters)"}
-    for fam in sorted(set(fe) | set(wr)):
+    for fam in sorted(set(fe) | set(wr)):     # noqa: E501
         nf, vf = fe.get(fam, [0, 0.0])
         nw, vw = wr.get(fam, [0, 0.0])
         res[fam] = {
@@ -57,7 +60,7 @@ def main():
         res[fam]["traffic_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch"] + res[fam]["write_bytes_per_launch"]
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:24s} launches {v['launches_fetch_pass']:5d}  fetch {v['fetch_bytes_per_launch'] / 1e6:10.1f} MB  "
                   f"write {v['write_bytes_per_launch'] / 1e6:10.1f} MB per launch")
 
