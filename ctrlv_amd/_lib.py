@@ -33,9 +33,10 @@ SIGNATURES = {
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
-    "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_void_p]),
     "ctrlv_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                      c_void_p, c_float, c_int, c_void_p, c_void_p]),
+                                      c_void_p, c_int, c_void_p, c_void_p]),
     "ctrlv_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -51,7 +52,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CtrlvHipError(RuntimeError):

@@ -3,8 +3,9 @@
 //
 // GroupNorm is a split reduction (SURVEY hard part H3: the 5-D temporal norm has only B*32 statistics rows of
 // up to 2.3 M elements each): pass 1 writes per-(image, row-chunk, group) partial (mean_c, M2_c = sum (x-mean_c)^2),
-// accumulated relative to a pilot value of the chunk so that mean >> std inputs do not cancel in fp32; pass 2 combines
-// the partials of its statistics row (deterministic order, fp64, Chan's formula) and streams x -> y = silu(x*a_c + b_c).
+// accumulated relative to per-channel pilot values so that mean >> std inputs do not cancel in fp32; pass 1b combines
+// the partials of a statistics row (deterministic order, fp64, Chan's formula) into (mean, rstd); pass 2 streams
+// x -> y = silu(x*a_c + b_c).
 // Algorithmic traffic: 2 reads + 1 write of the tensor (the second read of mid-size tensors is served by L2 /
 // Infinity Cache).
 #include "common.h"
@@ -21,9 +22,14 @@ __device__ __forceinline__ uint4 gn_load(const bf16_t* x, const bf16_t* x2, int 
   return *(const uint4*)(x + row * ld + c0);
 }
 
+// Pass 1.  Per (image, row-chunk): every lane accumulates, for its 8 channels, sum (x - K_c) and sum (x - K_c)^2 about a
+// per-CHANNEL pilot K_c = x[first row of the chunk][c] (one extra 16-byte load per lane, the same row for every lane of
+// a column, so all partial sums of a channel share their pilot): with |mean| >> std, E[x^2] - mean^2 would cancel in
+// fp32, the shifted sums do not.  32 threads then turn the channel sums of their group into the chunk's
+// (mean_c, M2_c) with Chan's pairwise update (equal counts per channel).
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
                                 float* __restrict__ partials) {
-  extern __shared__ float red[];  // [RPP][C][2]
+  extern __shared__ float red[];  // [RPP][C][2] sums, then [C] pilots
   const int tid = threadIdx.x;
   const int col = tid % s.CV, rsub = tid / s.CV;
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -31,19 +37,11 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
   float sm[8], sq[8], piv[8];
-  // pilot value per group: the group's first channel in the chunk's first row.  Sums of (x - pilot) and (x - pilot)^2
-  // keep fp32 accuracy when |mean| >> std (E[x^2] - mean^2 would cancel); every lane of a group uses the same pilot.
   {
-    const int cpg = s.C / 32;
+    const uint4 pv = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r0, c0);
+    unpack_bf16x8(pv, piv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int cg = ((c0 + e) / cpg) * cpg;
-      const long prow = (long)n * s.S + r0;
-      const bf16_t pv = (x2 != nullptr && cg >= s.c_split) ? x2[prow * (s.C - s.c_split) + (cg - s.c_split)]
-                                                           : x[prow * (x2 != nullptr ? s.c_split : s.C) + cg];
-      piv[e] = bf16_to_f32(pv);
-      sm[e] = sq[e] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
   }
   // four rows per trip: four independent 16-byte loads in flight per lane (HBM latency ~1 us; one load per trip left
   // the kernel latency-bound at 3.6 TB/s)
@@ -67,80 +65,89 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float dl = f[e] - piv[e]; sm[e] += dl; sq[e] += dl * dl; }
   }
+  float* pil = red + (size_t)s.RPP * s.C * 2;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     red[((rsub * s.C) + c0 + e) * 2 + 0] = sm[e];
     red[((rsub * s.C) + c0 + e) * 2 + 1] = sq[e];
+    if (rsub == 0) pil[c0 + e] = piv[e];
   }
   __syncthreads();
   if (tid < 32) {
     const int cpg = s.C / 32;
-    float a = 0.f, b = 0.f;
-    for (int rs = 0; rs < s.RPP; ++rs)
-      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+    const float nrow = (float)(r1 - r0);
+    float mean = 0.f, m2 = 0.f;          // running (mean, M2) over the channels seen so far, nrow elements each
+    for (int k = 0; k < cpg; ++k) {
+      const int c = tid * cpg + k;
+      float a = 0.f, b = 0.f;
+      for (int rs = 0; rs < s.RPP; ++rs) {
         a += red[(rs * s.C + c) * 2 + 0];
         b += red[(rs * s.C + c) * 2 + 1];
       }
+      const float mc = pil[c] + a / nrow;          // channel mean over the chunk
+      const float m2c = b - a * a / nrow;          // channel M2 about its own mean (no cancellation: a is small)
+      const float dlt = mc - mean;
+      m2 += m2c + dlt * dlt * (nrow * (float)k / (float)(k + 1));
+      mean += dlt / (float)(k + 1);
+    }
     const int stat = n / s.imgs_per_stat;
     const int gchunk = (n % s.imgs_per_stat) * s.n_chunks + chunk;
     const long o = (((long)stat * s.imgs_per_stat * s.n_chunks + gchunk) * 32 + tid) * 2;
-    const int cg = tid * cpg;
-    const long prow = (long)n * s.S + r0;
-    const bf16_t pv = (x2 != nullptr && cg >= s.c_split) ? x2[prow * (s.C - s.c_split) + (cg - s.c_split)]
-                                                         : x[prow * (x2 != nullptr ? s.c_split : s.C) + cg];
-    const float inv_cnt = 1.0f / (float)(cpg * (r1 - r0));
-    partials[o] = bf16_to_f32(pv) + a * inv_cnt;      // chunk mean
-    partials[o + 1] = b - a * a * inv_cnt;             // chunk M2 (about its own mean)
+    partials[o] = mean;                            // chunk mean of the group
+    partials[o + 1] = m2;                          // chunk M2 of the group (about its own mean)
+  }
+}
+
+// Pass 1b.  One workgroup per statistics row: combine its chunk partials (fixed order, fp64) into (mean, rstd) per group,
+// written behind the partials.  Keeps the per-workgroup prologue of the apply pass at 64 floats instead of a walk over
+// up to 25 x 36 chunks (230 KiB from L2 per workgroup at the L0 temporal norm).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnShape s, const float* __restrict__ partials, float eps,
+                                                          float* __restrict__ stats) {
+  __shared__ double dred[8][32][2];
+  const int tid = threadIdx.x, stat = blockIdx.x;
+  const int tot_chunks = s.imgs_per_stat * s.n_chunks;
+  const int g = tid & 31, sl = tid >> 5;
+  double a = 0.0, b = 0.0;                        // a = sum n_c*mean_c,  b = sum (M2_c + n_c*mean_c^2), exact in fp64
+  const float* p = partials + ((long)stat * tot_chunks) * 64;
+  const int cpg = s.C / 32;
+  for (int k = sl; k < tot_chunks; k += 8) {
+    const int ck = k % s.n_chunks;
+    const int rows = min(s.S, (ck + 1) * s.rows_per_chunk) - ck * s.rows_per_chunk;
+    const double nc = (double)(cpg * rows);
+    const double mc = (double)p[(k * 32 + g) * 2];
+    a += nc * mc;
+    b += (double)p[(k * 32 + g) * 2 + 1] + nc * mc * mc;
+  }
+  dred[sl][g][0] = a;
+  dred[sl][g][1] = b;
+  __syncthreads();
+  if (tid < 32) {
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < 8; ++k) { a += dred[k][tid][0]; b += dred[k][tid][1]; }
+    const double cnt = (double)cpg * (double)s.S * (double)s.imgs_per_stat;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)stat * 32 + tid) * 2] = (float)mean;
+    stats[((long)stat * 32 + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
-                                const float* __restrict__ partials, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, int silu, bf16_t* __restrict__ y) {
-  __shared__ double dred[8][32][2];
-  __shared__ float mean_s[32], rstd_s[32];
+                                const float* __restrict__ stats, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int silu, bf16_t* __restrict__ y) {
   const int tid = threadIdx.x;
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int stat = n / s.imgs_per_stat;
-  const int tot_chunks = s.imgs_per_stat * s.n_chunks;
-  // ---- reduce the partials of this statistics row: 8 slices x 32 groups, fp64
-  if (tid < 256) {
-    const int g = tid & 31, sl = tid >> 5;
-    double a = 0.0, b = 0.0;                        // a = sum n_c*mean_c,  b = sum (M2_c + n_c*mean_c^2), exact in fp64
-    const float* p = partials + ((long)stat * tot_chunks) * 64;
-    const int cpg_ = s.C / 32;
-    for (int k = sl; k < tot_chunks; k += 8) {
-      const int ck = k % s.n_chunks;
-      const int rows = min(s.S, (ck + 1) * s.rows_per_chunk) - ck * s.rows_per_chunk;
-      const double nc = (double)(cpg_ * rows);
-      const double mc = (double)p[(k * 32 + g) * 2];
-      a += nc * mc;
-      b += (double)p[(k * 32 + g) * 2 + 1] + nc * mc * mc;
-    }
-    dred[sl][g][0] = a;
-    dred[sl][g][1] = b;
-  }
-  __syncthreads();
-  if (tid < 32) {
-    double a = 0.0, b = 0.0;
-    for (int sl = 0; sl < 8; ++sl) { a += dred[sl][tid][0]; b += dred[sl][tid][1]; }
-    const double cnt = (double)(s.C / 32) * (double)s.S * (double)s.imgs_per_stat;
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  if (tid >= s.CV * s.RPP) return;
   const int col = tid % s.CV, rsub = tid / s.CV;
   const int c0 = col * 8, cpg = s.C / 32;
   float a[8], b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int g = (c0 + e) / cpg;
-    a[e] = rstd_s[g] * gamma[c0 + e];
-    b[e] = beta[c0 + e] - mean_s[g] * a[e];
+    const float mean = stats[((long)stat * 32 + g) * 2], rstd = stats[((long)stat * 32 + g) * 2 + 1];
+    a[e] = rstd * gamma[c0 + e];
+    b[e] = beta[c0 + e] - mean * a[e];
   }
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
@@ -269,30 +276,33 @@ extern "C" int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat
 }
 
 extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split, int n_img, int S, int C,
-                                     int imgs_per_stat, float* partials, ctrlv_stream_t stream) {
+                                     int imgs_per_stat, float eps, float* partials, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials, "groupnorm_stats: null pointer");
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
   const int nt = s.CV * s.RPP;
-  const size_t smem = (size_t)s.RPP * C * 2 * sizeof(float);
+  const size_t smem = ((size_t)s.RPP * C * 2 + C) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)x2, s, partials);
+  CTRLV_LAUNCH_CHECK();
+  // (mean, rstd) per (statistics row, group), behind the chunk partials
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat), dim3(256), 0, (hipStream_t)stream, s, partials,
+                     eps, partials + (size_t)n_img * s.n_chunks * 64);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
 
 extern "C" int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img, int S, int C,
                                      int imgs_per_stat, const float* partials, const float* gamma, const float* beta,
-                                     float eps, int silu, void* y, ctrlv_stream_t stream) {
+                                     int silu, void* y, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_apply: null pointer");
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
-  int nt = s.CV * s.RPP;
-  if (nt < 256) nt = 256;  // the partial reduction uses 256 threads
+  const int nt = s.CV * s.RPP;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (const bf16_t*)x2, s, partials, gamma, beta, eps, silu, (bf16_t*)y);
+                     (const bf16_t*)x2, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (bf16_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -31,6 +31,7 @@ class FwdCtx:
         self.xattn = xattn                # fp32 [B, sum C];   attentions hold their column offset
         self.quirk = time_context_order == "sb"
         self.gn_part = None               # shared fp32 scratch for GroupNorm partial sums
+        self.trace = None                 # debugging aid: list collecting (block, output rows clone, H, W)
 
 
 def _sigmoid(x):
@@ -124,7 +125,7 @@ def _f32(t):
 
 
 def _gn_scratch(ctx, n_img, S, C, ips):
-    need = (n_img // ips) * ips * ops.groupnorm_chunks(n_img, S, C, ips) * 64
+    need = ops.groupnorm_scratch_floats(n_img, S, C, ips)
     if ctx.gn_part is None or ctx.gn_part.numel() < need:
         ctx.gn_part = torch.empty(max(need, 1 << 18), dtype=torch.float32, device=ctx.ws.device)
     return ctx.gn_part
@@ -198,6 +199,8 @@ class SpatioTemporalResBlock(nn.Module):
         ops.gemm(hn, pk["tw2"], out, N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"],
                  s_acc=1.0 - pk["alpha"], R1=xs)
         ws.release(mk)
+        if ctx.trace is not None:
+            ctx.trace.append((self, out.clone(), H, W))
         return out
 
 
@@ -328,6 +331,8 @@ class TransformerSpatioTemporalModel(nn.Module):
                  R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
+        if ctx.trace is not None:
+            ctx.trace.append((self, out.clone(), H, W))
         return out
 
 

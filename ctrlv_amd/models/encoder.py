@@ -211,7 +211,9 @@ class SpatioTemporalEncoderBase(HipModelMixin):
             xattn = torch.empty(B, nx, dtype=torch.float32, device=dev)
             for off, c, wo, bo in pk["xattn_out"]:
                 ops.gemm(v_all[:, off:off + c], wo, xattn[:, off:off + c], N=c, cin=c, bias=bo, out_f32=True)
-        return FwdCtx(ws, B, F, temb, xattn, self.time_context_order)
+        ctx = FwdCtx(ws, B, F, temb, xattn, self.time_context_order)
+        ctx.trace = getattr(self, "_trace", None)        # tests: per-block outputs (error-growth trace)
+        return ctx
 
     def _input_rows(self, ws, planes, N, h, w):
         """NCHW input planes -> channels-last rows -> conv_in (+control_conv_in) as ONE im2col GEMM."""

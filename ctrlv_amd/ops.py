@@ -66,6 +66,11 @@ def groupnorm_chunks(n_img, S, C, imgs_per_stat):
     return rc
 
 
+def groupnorm_scratch_floats(n_img, S, C, imgs_per_stat):
+    """fp32 elements `groupnorm` needs in `partials`: chunk partials + the (mean, rstd) table behind them."""
+    return (n_img * groupnorm_chunks(n_img, S, C, imgs_per_stat) + n_img // imgs_per_stat) * 64
+
+
 def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
     """Two-pass GroupNorm(32)(+SiLU) over channels-last rows; (x | x2) is a channel concat when x2 is given."""
     _need_gpu(x, "x")
@@ -73,10 +78,10 @@ def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, part
     c_split = x.shape[1] if x2 is not None else 0
     st = _stream()
     ev = _prof.begin()
-    check(lib.ctrlv_groupnorm_stats(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), st),
+    check(lib.ctrlv_groupnorm_stats(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, eps, _p(partials), st),
           "ctrlv_groupnorm_stats")
     check(lib.ctrlv_groupnorm_apply(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), _p(gamma),
-                                    _p(beta), eps, 1 if silu else 0, _p(y), st), "ctrlv_groupnorm_apply")
+                                    _p(beta), 1 if silu else 0, _p(y), st), "ctrlv_groupnorm_apply")
     _prof.end(ev, "groupnorm", 0.0, 2.0 * 2 * n_img * S * C)       # algorithmic: 1 read + 1 write, bf16
     return y
 

@@ -93,16 +93,17 @@ int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
  * conv_norm_out (unet_spatio_temporal_condition.py:161-162).
  *   x  : [n_img*S, C] bf16, optionally the channel-concat of (x [.., c_split], x2 [.., C-c_split]) (torch.cat dim=1)
  *   statistics are taken per (img / imgs_per_stat, group): imgs_per_stat = 1 (4-D) or F (5-D)
- *   stats pass writes per-chunk fp32 (mean, M2 = sum (x - mean)^2) into `partials` [n_stat, n_chunks, 32, 2]
- *   (accumulated about a pilot value, so |mean| >> std does not cancel); apply pass combines them in fp64.
- * ctrlv_groupnorm_chunks() returns n_chunks for a shape so the caller can size `partials`.
+ *   stats pass writes per-chunk fp32 (mean, M2 = sum (x - mean)^2) per group (accumulated about per-channel pilot
+ *   values, so |mean| >> std does not cancel), then combines them in fp64 into (mean, rstd) per (statistics row, group),
+ *   stored behind the chunk partials; the apply pass streams y = [silu](x * a_c + b_c).
+ * `partials` must hold (n_img * n_chunks + n_img / imgs_per_stat) * 64 floats, n_chunks = ctrlv_groupnorm_chunks().
  * ------------------------------------------------------------------------------------------------------------------ */
 int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat);
 int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split, int n_img, int S, int C, int imgs_per_stat,
-                          float* partials, ctrlv_stream_t stream);
+                          float eps, float* partials, ctrlv_stream_t stream);
 int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img, int S, int C, int imgs_per_stat,
-                          const float* partials, const float* gamma, const float* beta, float eps, int silu,
-                          void* y, ctrlv_stream_t stream);
+                          const float* partials, const float* gamma, const float* beta, int silu, void* y,
+                          ctrlv_stream_t stream);
 
 /* LayerNorm over the channel axis of [M, C] bf16 rows (BasicTransformerBlock.norm1/3,
  * TemporalBasicTransformerBlock.norm_in/1/3).  If V != NULL, normalises x[m,:] + V[(m / vdiv) % vmod, :]

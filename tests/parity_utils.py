@@ -175,3 +175,47 @@ def run_tiny_parity(device="cuda:0", B=2, F=3, h=16, w=16, time_context_order="s
     """Tiny-config HIP-vs-fp32-oracle errors (smoke() and the model tests)."""
     import ctrlv_ref as R
     return run_parity(dict(R.TINY_CONFIG), device, B, F, h, w, time_context_order, verbose, torch_bf16=False)["fp32"]
+
+
+@torch.no_grad()
+def error_growth_trace(ou, hu, inputs, device, oc=None, hc=None):
+    """Per-block relative L2 error of the HIP model against the fp32 oracle, in execution order: the output of every
+    SpatioTemporalResBlock / TransformerSpatioTemporalModel of the ControlNet (if given) and the UNet.  Returns
+    [(name, rel_l2)].  A wiring / kernel defect shows up as a jump at one block; bf16 storage noise as a slow walk."""
+    import ctrlv_ref as R
+    sample, t, ehs, ids, cond = inputs
+    out = []
+    for o_model, h_model, kind in ((oc, hc, "controlnet"), (ou, hu, "unet")):
+        if o_model is None:
+            continue
+        ref, hooks, names = [], [], {}
+        for name, mod in o_model.named_modules():
+            if isinstance(mod, (R.SpatioTemporalResBlock, R.TransformerSpatioTemporalModel)):
+                names[mod] = name
+                hooks.append(mod.register_forward_hook(lambda m, a, y: ref.append((names[m], y.detach().float()))))
+        hnames = {m: n for n, m in h_model.named_modules()}
+        h_model._trace = []
+        dev = lambda x: x.to(device=device, dtype=torch.bfloat16)   # noqa: E731
+        try:
+            if kind == "controlnet":
+                d_ref, m_ref = o_model(sample, t, ehs, ids, control_cond=cond, conditioning_scale=0.8)
+                d_hip, m_hip = h_model(dev(sample), t.to(device), dev(ehs), ids.to(device), control_cond=dev(cond),
+                                       conditioning_scale=0.8, return_dict=False)
+                res_ref, res_hip = (d_ref, m_ref), (d_hip, m_hip)
+            else:
+                r_ref = res_ref if oc is not None else (None, None)
+                r_hip = res_hip if oc is not None else (None, None)
+                o_model(sample, t, ehs, ids, *r_ref)
+                h_model(dev(sample), t.to(device), dev(ehs), ids.to(device), *r_hip)
+            torch.cuda.synchronize()
+            got = [(hnames[m], rows, H, W) for m, rows, H, W in h_model._trace]
+        finally:
+            h_model._trace = None
+            for h in hooks:
+                h.remove()
+        assert [n for n, _ in ref] == [g[0] for g in got], "block execution order differs between oracle and HIP"
+        for (name, y), (_, rows, H, W) in zip(ref, got):
+            n = y.shape[0]
+            x = rows.float().cpu().reshape(n, H, W, -1).permute(0, 3, 1, 2)
+            out.append((f"{kind}.{name}", rel_l2(x, y)))
+    return out

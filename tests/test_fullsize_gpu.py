@@ -125,7 +125,7 @@ def test_groupnorm_temporal_l0_fullsize(ops):
     gamma = torch.randn(c, generator=g(17), device=DEV)
     beta = torch.randn(c, generator=g(18), device=DEV)
     y = torch.empty_like(x)
-    part = torch.empty(ops.groupnorm_chunks(N_IMG, S0, c, FR) * N_IMG * 64, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.groupnorm_scratch_floats(N_IMG, S0, c, FR), dtype=torch.float32, device=DEV)
     ops.groupnorm(x, None, N_IMG, S0, c, FR, gamma, beta, 1e-5, True, y, part)
     for bi in range(2):
         xin = x[bi * FR * S0:(bi + 1) * FR * S0].float().reshape(1, FR * S0, c).permute(0, 2, 1)   # (1, c, f*s)

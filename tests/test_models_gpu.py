@@ -10,6 +10,15 @@ Three comparisons per case (tests/parity_utils.run_parity), every bound rel-L2 A
   yardstick  the same network executed by PyTorch itself in bf16 on the GPU (rocBLAS / MIOpen / SDPA) vs the fp32
            oracle: HIP's error must not exceed it by more than 10 %.
 
+  storage  (see above) at MODEL level is a second bf16 realisation of the network, not a tighter reference: measured at
+           full width, HIP-vs-storage (1.0-1.5e-2) ~ sqrt(HIP-vs-fp32^2 + storage-vs-fp32^2) -- the two roundings
+           decorrelate after a few blocks (a flipped bf16 rounding re-amplifies through GroupNorm / attention), i.e. the
+           model-level error is rounding noise, not bias.  Per block, where no amplification has happened yet, the
+           storage-rounded oracle IS the tight reference (tests/test_blocks_gpu.py: 2e-3).  Bound here: 2e-2.
+  trace    per-block error growth (parity_utils.error_growth_trace): the rel-L2 error after every res block /
+           transformer in execution order must stay below TOL_FP32 and no single block may add more than TOL_STEP --
+           a wiring or kernel defect is a jump, storage noise a slow walk.
+
 north_star's "1e-3 relative bf16 tolerance" holds per kernel (tests/test_ops_gpu.py: 1e-4 with fp32 output) and per
 block against the storage-rounded oracle (tests/test_blocks_gpu.py: 2e-3); through the whole network bf16 storage
 itself costs ~1e-2 whoever executes it, which the yardstick demonstrates.
@@ -22,7 +31,8 @@ from tests.parity_utils import make_inputs, make_pair, run_parity
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_FP32 = 1.5e-2
-TOL_STORAGE = 6e-3
+TOL_STORAGE = 2e-2
+TOL_STEP = 5e-3
 
 
 def check_tables(err):
@@ -30,6 +40,26 @@ def check_tables(err):
     assert max(err["fp32"].values()) < TOL_FP32, err
     for k, v in err["torch_bf16"].items():
         assert err["fp32_l2"][k] <= 1.1 * v + 1e-4, (k, err["fp32_l2"][k], v)
+
+
+def check_trace(trace):
+    prev = 0.0
+    for name, e in trace:
+        print(f"  {e:.2e}  {name}")
+    for name, e in trace:
+        assert e < TOL_FP32, (name, e)
+        assert e - prev < TOL_STEP, (name, e, prev)
+        prev = max(prev, e)
+
+
+def test_tiny_error_growth_trace(hip_lib):
+    import ctrlv_ref as R
+    from tests.parity_utils import error_growth_trace
+    cfg = dict(R.TINY_CONFIG)
+    ou, oc, hu, hc = make_pair(cfg, DEV)
+    tr = error_growth_trace(ou, hu, make_inputs(cfg, 2, 3, 16, 16), DEV, oc, hc)
+    assert len(tr) == 17 + 38                       # ControlNet: 10 res + 7 transformers; UNet: 22 + 16
+    check_trace(tr)
 
 
 @pytest.mark.parametrize("order", ["sb", "bs"])

@@ -234,7 +234,7 @@ def test_groupnorm(ops, C, H, W, n, ips, silu):
         ref = F.silu(ref)
     rows = rows_from_nchw(x).to(DEV)
     y = torch.empty_like(rows)
-    part = torch.empty(n * ops.groupnorm_chunks(n, S, C, ips) * 64, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.groupnorm_scratch_floats(n, S, C, ips), dtype=torch.float32, device=DEV)
     ops.groupnorm(rows, None, n, S, C, ips, gamma.to(DEV), beta.to(DEV), 1e-5, silu, y, part)
     assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
 
@@ -259,7 +259,7 @@ def test_groupnorm_large_mean_small_variance(ops, mean, std, ips):
         ref = F.group_norm(x5, 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 1, 3, 4).reshape(n, C, H, W)
     rows = rows_from_nchw(x).to(DEV)
     y = torch.empty_like(rows)
-    part = torch.empty(n * ops.groupnorm_chunks(n, S, C, ips) * 64, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.groupnorm_scratch_floats(n, S, C, ips), dtype=torch.float32, device=DEV)
     ops.groupnorm(rows, None, n, S, C, ips, gamma.to(DEV), beta.to(DEV), 1e-6, False, y, part)
     assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref.float(), f"GN mean {mean} std {std}") < 3e-3
 
@@ -271,7 +271,7 @@ def test_groupnorm_concat(ops):
     gamma, beta = torch.randn(C, generator=g(3)), torch.randn(C, generator=g(4))
     ref = F.silu(F.group_norm(torch.cat([x1, x2], 1).float(), 32, gamma, beta, 1e-6))
     y = torch.empty(n * H * W, C, dtype=torch.bfloat16, device=DEV)
-    part = torch.empty(n * ops.groupnorm_chunks(n, H * W, C, 1) * 64, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.groupnorm_scratch_floats(n, H * W, C, 1), dtype=torch.float32, device=DEV)
     ops.groupnorm(rows_from_nchw(x1).to(DEV), rows_from_nchw(x2).to(DEV), n, H * W, C, 1, gamma.to(DEV), beta.to(DEV),
                   1e-6, True, y, part)
     assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref) < 3e-3
