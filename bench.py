@@ -355,8 +355,12 @@ def main():
     for _ in range(max(args.warmup, 2 if args.hip_graph else 1)):      # graph mode: 1 eager + 1 capture step
         run_step(st, i); i += 1
     torch.cuda.synchronize()
-    log(f"warm-up done; workspace peak {unet._ws.peak / 2**30:.1f} GiB (UNet)"
-        + (f" + {ctrl._ws.peak / 2**30:.1f} GiB (ControlNet)" if ctrl is not None else "")
+    def ws_gib(m):
+        if m._plan is not None:
+            return sum(w.numel() for w in m._plan._ws.values()) / 2**30
+        return m._ws.peak / 2**30 if m._ws is not None else 0.0
+    log(f"warm-up done ({unet.executor} executor); workspace {ws_gib(unet):.1f} GiB (UNet)"
+        + (f" + {ws_gib(ctrl):.1f} GiB (ControlNet)" if ctrl is not None else "")
         + f"; torch allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
     D.barrier()
     torch.cuda.synchronize()

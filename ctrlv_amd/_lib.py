@@ -26,6 +26,27 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+CTRLV_MAX_BLOCKS = 8
+
+
+class ModelConfig(ctypes.Structure):
+    """Mirror of `ctrlv_model_config`."""
+    _fields_ = [
+        ("kind", c_int), ("in_channels", c_int), ("out_channels", c_int), ("n_blocks", c_int),
+        ("block_out_channels", c_int * CTRLV_MAX_BLOCKS), ("down_cross_attn", c_int * CTRLV_MAX_BLOCKS),
+        ("up_cross_attn", c_int * CTRLV_MAX_BLOCKS), ("layers_per_block", c_int * CTRLV_MAX_BLOCKS),
+        ("num_attention_heads", c_int * CTRLV_MAX_BLOCKS),
+        ("cross_attention_dim", c_int), ("addition_time_embed_dim", c_int),
+        ("projection_class_embeddings_input_dim", c_int), ("num_frames", c_int), ("time_context_order", c_int),
+    ]
+
+
+class TensorDesc(ctypes.Structure):
+    """Mirror of `ctrlv_tensor_desc`."""
+    _fields_ = [("name", ctypes.c_char_p), ("data", c_void_p), ("dtype", c_int), ("on_device", c_int),
+                ("numel", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); lists every symbol include/ctrlv_hip.h declares (tests/test_abi.py checks this)
 SIGNATURES = {
     "ctrlv_abi_version": (c_int, []),
@@ -49,10 +70,24 @@ SIGNATURES = {
     "ctrlv_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                      c_float, c_void_p, c_void_p]),
+    "ctrlv_plan_create": (c_int, [ctypes.POINTER(ModelConfig), c_int, ctypes.POINTER(c_void_p)]),
+    "ctrlv_plan_load_weights": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_size_t]),
+    "ctrlv_plan_set_time_context_order": (c_int, [c_void_p, c_int]),
+    "ctrlv_plan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
+    "ctrlv_plan_num_down_residuals": (c_int, [c_void_p]),
+    "ctrlv_plan_residual_shape": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(c_int)]),
+    "ctrlv_unet_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                   ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_size_t, c_void_p]),
+    "ctrlv_controlnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                         c_float, ctypes.POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_size_t, c_void_p]),
+    "ctrlv_plan_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CtrlvHipError(RuntimeError):

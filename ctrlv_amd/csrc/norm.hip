@@ -36,13 +36,29 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
-  float sm[8], sq[8], piv[8];
+  // (float2 arithmetic: v_pk_add_f32 / v_pk_fma_f32, two channels per instruction)
+  f32x2_t sm2[4], sq2[4], piv2[4];
   {
     const uint4 pv = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r0, c0);
-    unpack_bf16x8(pv, piv);
+    float pf[8];
+    unpack_bf16x8(pv, pf);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
+    for (int e = 0; e < 4; ++e) {
+      piv2[e] = f32x2_t{pf[2 * e], pf[2 * e + 1]};
+      sm2[e] = f32x2_t{0.f, 0.f};
+      sq2[e] = f32x2_t{0.f, 0.f};
+    }
   }
+  auto accum = [&](const uint4& v) {
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2_t dl = f32x2_t{f[2 * e], f[2 * e + 1]} - piv2[e];
+      sm2[e] += dl;
+      sq2[e] += dl * dl;
+    }
+  };
   // four rows per trip: four independent 16-byte loads in flight per lane (HBM latency ~1 us; one load per trip left
   // the kernel latency-bound at 3.6 TB/s)
   int r = r0 + rsub;
@@ -51,44 +67,39 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r + u * s.RPP, c0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float f[8];
-      unpack_bf16x8(v[u], f);
+    for (int u = 0; u < 4; ++u) accum(v[u]);
+  }
+  for (; r < r1; r += s.RPP) accum(gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0));
+  float* pil = red + (size_t)s.RPP * s.C * 2;     // per channel: [mean | M2] after stage A
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float dl = f[e] - piv[e]; sm[e] += dl; sq[e] += dl * dl; }
+  for (int e = 0; e < 4; ++e) {
+    *(float4*)(red + ((rsub * s.C) + c0 + 2 * e) * 2) = make_float4(sm2[e].x, sq2[e].x, sm2[e].y, sq2[e].y);
+    if (rsub == 0) { pil[c0 + 2 * e] = piv2[e].x; pil[c0 + 2 * e + 1] = piv2[e].y; }
+  }
+  __syncthreads();
+  // stage A (all threads, one channel each): sums over the row sub-sets -> channel (mean, M2) in place of the pilot
+  const float nrow = (float)(r1 - r0), inv_nrow = 1.0f / nrow;
+  for (int c = tid; c < s.C; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int rs = 0; rs < s.RPP; ++rs) {
+      const float2 v = *(const float2*)(red + (rs * s.C + c) * 2);
+      a += v.x;
+      b += v.y;
     }
-  }
-  for (; r < r1; r += s.RPP) {
-    const uint4 v = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0);
-    float f[8];
-    unpack_bf16x8(v, f);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float dl = f[e] - piv[e]; sm[e] += dl; sq[e] += dl * dl; }
-  }
-  float* pil = red + (size_t)s.RPP * s.C * 2;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[((rsub * s.C) + c0 + e) * 2 + 0] = sm[e];
-    red[((rsub * s.C) + c0 + e) * 2 + 1] = sq[e];
-    if (rsub == 0) pil[c0 + e] = piv[e];
+    const float mc = pil[c] + a * inv_nrow;          // channel mean over the chunk
+    red[c * 2] = mc;                                 // (row sub-set 0 of this channel was consumed by this thread)
+    red[c * 2 + 1] = b - a * a * inv_nrow;           // channel M2 about its own mean (no cancellation: a is small)
   }
   __syncthreads();
   if (tid < 32) {
     const int cpg = s.C / 32;
-    const float nrow = (float)(r1 - r0);
     float mean = 0.f, m2 = 0.f;          // running (mean, M2) over the channels seen so far, nrow elements each
     for (int k = 0; k < cpg; ++k) {
-      const int c = tid * cpg + k;
-      float a = 0.f, b = 0.f;
-      for (int rs = 0; rs < s.RPP; ++rs) {
-        a += red[(rs * s.C + c) * 2 + 0];
-        b += red[(rs * s.C + c) * 2 + 1];
-      }
-      const float mc = pil[c] + a / nrow;          // channel mean over the chunk
-      const float m2c = b - a * a / nrow;          // channel M2 about its own mean (no cancellation: a is small)
-      const float dlt = mc - mean;
-      m2 += m2c + dlt * dlt * (nrow * (float)k / (float)(k + 1));
-      mean += dlt / (float)(k + 1);
+      const float2 v = *(const float2*)(red + (tid * cpg + k) * 2);
+      const float dlt = v.x - mean;
+      const float rk = 1.0f / (float)(k + 1);
+      m2 += v.y + dlt * dlt * (nrow * (float)k * rk);
+      mean += dlt * rk;
     }
     const int stat = n / s.imgs_per_stat;
     const int gchunk = (n % s.imgs_per_stat) * s.n_chunks + chunk;
@@ -101,29 +112,31 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
 // Pass 1b.  One workgroup per statistics row: combine its chunk partials (fixed order, fp64) into (mean, rstd) per group,
 // written behind the partials.  Keeps the per-workgroup prologue of the apply pass at 64 floats instead of a walk over
 // up to 25 x 36 chunks (230 KiB from L2 per workgroup at the L0 temporal norm).
-__global__ __launch_bounds__(256) void gn_finalize_kernel(GnShape s, const float* __restrict__ partials, float eps,
-                                                          float* __restrict__ stats) {
-  __shared__ double dred[8][32][2];
+constexpr int kFinSlices = 32;          // 1024 threads: 32 slices x 32 groups (the 5-D norms have up to 900 chunks per row)
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(GnShape s, const float* __restrict__ partials, float eps,
+                                                           float* __restrict__ stats) {
+  __shared__ double dred[kFinSlices][32][2];
   const int tid = threadIdx.x, stat = blockIdx.x;
   const int tot_chunks = s.imgs_per_stat * s.n_chunks;
   const int g = tid & 31, sl = tid >> 5;
   double a = 0.0, b = 0.0;                        // a = sum n_c*mean_c,  b = sum (M2_c + n_c*mean_c^2), exact in fp64
   const float* p = partials + ((long)stat * tot_chunks) * 64;
   const int cpg = s.C / 32;
-  for (int k = sl; k < tot_chunks; k += 8) {
+  for (int k = sl; k < tot_chunks; k += kFinSlices) {
     const int ck = k % s.n_chunks;
     const int rows = min(s.S, (ck + 1) * s.rows_per_chunk) - ck * s.rows_per_chunk;
     const double nc = (double)(cpg * rows);
-    const double mc = (double)p[(k * 32 + g) * 2];
+    const float2 pm = *(const float2*)(p + (k * 32 + g) * 2);
+    const double mc = (double)pm.x;
     a += nc * mc;
-    b += (double)p[(k * 32 + g) * 2 + 1] + nc * mc * mc;
+    b += (double)pm.y + nc * mc * mc;
   }
   dred[sl][g][0] = a;
   dred[sl][g][1] = b;
   __syncthreads();
   if (tid < 32) {
     a = 0.0; b = 0.0;
-    for (int k = 0; k < 8; ++k) { a += dred[k][tid][0]; b += dred[k][tid][1]; }
+    for (int k = 0; k < kFinSlices; ++k) { a += dred[k][tid][0]; b += dred[k][tid][1]; }
     const double cnt = (double)cpg * (double)s.S * (double)s.imgs_per_stat;
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
@@ -287,7 +300,7 @@ extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split,
                      (const bf16_t*)x, (const bf16_t*)x2, s, partials);
   CTRLV_LAUNCH_CHECK();
   // (mean, rstd) per (statistics row, group), behind the chunk partials
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat), dim3(256), 0, (hipStream_t)stream, s, partials,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat), dim3(1024), 0, (hipStream_t)stream, s, partials,
                      eps, partials + (size_t)n_img * s.n_chunks * 64);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;

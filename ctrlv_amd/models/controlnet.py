@@ -113,6 +113,36 @@ class ControlNetModel(SpatioTemporalEncoderBase):
         pk["zc"] = [(packing.pack_linear(m.weight), _f32(m.bias)) for m in self.controlnet_down_blocks]
         pk["zc_mid"] = (packing.pack_linear(self.controlnet_mid_block.weight), _f32(self.controlnet_mid_block.bias))
 
+    _plan_kind = "controlnet"
+
+    def _forward_plan(self, sample, timestep, encoder_hidden_states, added_time_ids, control_cond, conditioning_scale,
+                      return_dict):
+        """One call into the C++ execution plan (ctrlv_controlnet_forward)."""
+        plan = self._ensure_plan(sample)
+        B, F, _, h, w = sample.shape
+        N = B * F
+        t32, ehs, ids32 = self._plan_inputs(sample, timestep, encoder_hidden_states, added_time_ids)
+        control = control_cond.to(device=sample.device, dtype=sample.dtype).contiguous()
+        shapes = [plan.residual_shape(i, B, F, h, w) for i in range(plan.n_down + 1)]
+        rows = [torch.empty(M, C, dtype=torch.bfloat16, device=sample.device) for M, C in shapes]
+        plan.controlnet_forward(sample.contiguous(), control, t32, ehs, ids32, float(conditioning_scale), rows[:-1],
+                                rows[-1], lane=getattr(self, "_lane", 0))
+
+        def view(o, level_rows):      # (N, C, H, W) shape, channels-last strides
+            C = o.shape[1]
+            s = level_rows // N
+            hh = h
+            while hh * (w * hh // h) != s:     # recover (H, W) of the level from its pixel count
+                hh //= 2
+            o = o.view(N, hh, s // hh, C).permute(0, 3, 1, 2)
+            return o if sample.dtype == torch.bfloat16 else o.to(sample.dtype)
+
+        outs = [view(o, M) for o, (M, _) in zip(rows, shapes)]
+        down, mid = outs[:-1], outs[-1]
+        if not return_dict:
+            return (down, mid)
+        return ControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid)
+
     @torch.no_grad()
     def forward(
         self,
@@ -124,8 +154,6 @@ class ControlNetModel(SpatioTemporalEncoderBase):
         conditioning_scale: float = 1.0,
         return_dict: bool = True,
     ) -> Union[ControlNetOutput, Tuple]:
-        ws = self._ensure_ready(sample)
-        pk = self._pk
         if control_cond is None:
             raise ValueError("control_cond is required (controlnet.py:289 flattens it unconditionally)")
         if sample.dim() != 5 or sample.shape[2] != self.config.in_channels:
@@ -136,6 +164,11 @@ class ControlNetModel(SpatioTemporalEncoderBase):
             raise ValueError(f"control_cond must have shape {(B, F, Cin // 2, h, w)}; got {tuple(control_cond.shape)}")
         self._check_hw(h, w, len(self.down_blocks) - 1)
         N = B * F
+        if self._use_plan():
+            return self._forward_plan(sample, timestep, encoder_hidden_states, added_time_ids, control_cond,
+                                      conditioning_scale, return_dict)
+        ws = self._ensure_ready(sample)
+        pk = self._pk
         ctx = self._context(ws, sample, timestep, encoder_hidden_states, added_time_ids)       # :262-294
         x = self._input_rows(ws, [sample.reshape(N, Cin, h, w),                                # :287-299
                                   control_cond.reshape(N, Cin // 2, h, w).to(sample.device)], N, h, w)

@@ -3,10 +3,14 @@
 Reference: the identical prologues of
   src/ctrlv/models/unet_spatio_temporal_condition.py:61-117 and src/ctrlv/models/controlnet.py:261-327.
 """
+import os
+
 import torch
 from torch import nn
 
 from .. import _lib, ops, packing
+from .. import profiler as _prof
+from ..plan import Plan
 from ..workspace import Workspace
 from .blocks import (CrossAttnDownBlockSpatioTemporal, DownBlockSpatioTemporal, Downsample2D, FwdCtx,
                      SpatioTemporalResBlock, TransformerSpatioTemporalModel, Upsample2D, _f32, _TimestepEmbedding)
@@ -32,6 +36,11 @@ class SpatioTemporalEncoderBase(HipModelMixin):
     """conv_in + time/added-id embeddings + down blocks + mid block, and the HIP execution plumbing."""
 
     time_context_order = "sb"     # diffusers 0.27.2 ordering quirk of the temporal cross-attention context (H1)
+    # Who walks the layer list: "plan" = the C++ execution plan behind ctrlv_unet_forward / ctrlv_controlnet_forward
+    # (one ctypes call per forward; default), "python" = the per-op executor of models/blocks.py (same kernels, same
+    # descriptors, bit-identical results; used automatically for the per-kernel timer and the per-block trace).
+    executor = os.environ.get("CTRLV_EXECUTOR", "plan")
+    _plan_kind = "unet"
 
     def _build_encoder(self, in_channels, down_block_types, block_out_channels, addition_time_embed_dim,
                        projection_class_embeddings_input_dim, layers_per_block, cross_attention_dim,
@@ -59,15 +68,70 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         self._packed = False
         self._ws = None
         self._wss = {}
+        self._plan = None
 
     # ------------------------------------------------------------------------------------------- packing
     def _apply(self, fn, *a, **k):          # .to() / .cuda() / .half() invalidate the packed weights
         self._packed = False
+        self._plan = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = False
+        self._plan = None
         return super().load_state_dict(*a, **k)
+
+    def __setattr__(self, name, value):
+        if name == "_packed" and value is False:       # whoever invalidates the Python packing invalidates the plan
+            object.__setattr__(self, "_plan", None)
+        super().__setattr__(name, value)
+
+    # ------------------------------------------------------------------------------------------- C++ plan
+    def _use_plan(self):
+        return (self.executor == "plan" and getattr(self, "_trace", None) is None and _prof._active is None)
+
+    def _ensure_plan(self, sample):
+        """The C++ execution plan of this model (csrc/plan.hip): created and loaded with the current parameters on first
+        use, rebuilt after .to() / load_state_dict()."""
+        _lib.load()                               # raises if the HIP library is missing: no fallback
+        if not sample.is_cuda:
+            raise _lib.CtrlvHipError("ctrlv_amd models run on a HIP device only; there is no CPU forward "
+                                     f"(got a {sample.device} input)")
+        if self.device != sample.device:
+            raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
+        if self._plan is None:
+            plan = Plan(self._plan_kind, self.config, sample.device, self.time_context_order)
+            plan.load_state_dict(self.state_dict())
+            object.__setattr__(self, "_plan", plan)
+            self._plan_order = self.time_context_order
+        if self._plan_order != self.time_context_order:
+            self._plan.set_time_context_order(self.time_context_order)
+            self._plan_order = self.time_context_order
+        return self._plan
+
+    def _plan_inputs(self, sample, timestep, encoder_hidden_states, added_time_ids):
+        """Argument checks of _context() + the plain device buffers the C ABI takes (fp32 timestep / added ids,
+        encoder states in the sample's dtype)."""
+        dev = sample.device
+        B = sample.shape[0]
+        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[1] != 1:
+            raise ValueError("encoder_hidden_states must have shape (batch, 1, cross_attention_dim): the path is "
+                             "specialised for the single CLIP image token "
+                             f"(unet_spatio_temporal_condition.py:93-94); got {tuple(encoder_hidden_states.shape)}")
+        if encoder_hidden_states.shape[0] != B or added_time_ids.shape[0] != B:
+            raise ValueError("encoder_hidden_states / added_time_ids batch size does not match sample")
+        n_ids = added_time_ids.shape[1]
+        add_dim = self.config.addition_time_embed_dim
+        if add_dim * n_ids != self.add_embedding.linear_1.in_features:
+            raise ValueError(f"Model expects an added time embedding vector of length "
+                             f"{self.add_embedding.linear_1.in_features}, but a vector of {add_dim * n_ids} was created.")
+        t = timestep if torch.is_tensor(timestep) else torch.tensor(float(timestep))
+        t32 = t.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if t32.numel() not in (1, B):
+            raise ValueError(f"timestep must be a scalar or have {B} entries, got {t32.numel()}")
+        ids32 = added_time_ids.to(device=dev, dtype=torch.float32).contiguous()
+        ehs = encoder_hidden_states.to(device=dev, dtype=sample.dtype).contiguous()
+        return t32, ehs, ids32
 
     def _extra_input_convs(self):
         return []

@@ -128,8 +128,29 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
         rp = r.permute(0, 2, 3, 1)
         if r.dtype == torch.bfloat16 and rp.is_contiguous():
             return rp.reshape(M, C)
-        rows = ws.alloc((M, C))
+        rows = ws.alloc((M, C)) if ws is not None else torch.empty(M, C, dtype=torch.bfloat16, device=r.device)
         return ops.nchw_to_rows(r.contiguous(), rows, 0)
+
+    def _forward_plan(self, sample, timestep, encoder_hidden_states, added_time_ids, down, mid, return_dict):
+        """One call into the C++ execution plan (ctrlv_unet_forward)."""
+        plan = self._ensure_plan(sample)
+        B, F, _, h, w = sample.shape
+        t32, ehs, ids32 = self._plan_inputs(sample, timestep, encoder_hidden_states, added_time_ids)
+        down_rows = mid_rows = None
+        if down is not None:
+            if len(down) != plan.n_down:
+                raise ValueError(f"expected {plan.n_down} down_block_additional_residuals, got {len(down)}")
+            down_rows = []
+            for i, r in enumerate(list(down) + [mid]):
+                M, C = plan.residual_shape(i, B, F, h, w)
+                down_rows.append(self._residual_rows(None, r, M, C))
+            mid_rows = down_rows.pop()
+        out = torch.empty(B, F, self.config.out_channels, h, w, dtype=sample.dtype, device=sample.device)
+        plan.unet_forward(sample.contiguous(), t32, ehs, ids32, down_rows, mid_rows, out,
+                          residual_event=getattr(self, "_residual_event", None), lane=getattr(self, "_lane", 0))
+        if not return_dict:
+            return (out,)
+        return UNetSpatioTemporalConditionOutput(sample=out)
 
     @torch.no_grad()
     def forward(
@@ -142,8 +163,6 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
         mid_block_additional_residuals: Optional[torch.Tensor] = None,
         return_dict: bool = True,
     ) -> Union[UNetSpatioTemporalConditionOutput, Tuple]:
-        ws = self._ensure_ready(sample)
-        pk = self._pk
         # unet_spatio_temporal_condition.py:61
         is_controlnet = mid_block_additional_residuals is not None and down_block_additional_residuals is not None
         if sample.dim() != 5 or sample.shape[2] != self.config.in_channels:
@@ -152,6 +171,12 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
         B, F, Cin, h, w = sample.shape
         self._check_hw(h, w, len(self.down_blocks) - 1)
         N = B * F
+        if self._use_plan():
+            return self._forward_plan(sample, timestep, encoder_hidden_states, added_time_ids,
+                                      down_block_additional_residuals if is_controlnet else None,
+                                      mid_block_additional_residuals if is_controlnet else None, return_dict)
+        ws = self._ensure_ready(sample)
+        pk = self._pk
         ctx = self._context(ws, sample, timestep, encoder_hidden_states, added_time_ids)       # :64-94
         x = self._input_rows(ws, [sample.reshape(N, Cin, h, w)], N, h, w)                      # :89,97
         x, H, W, taps = self._run_down_mid(ctx, x, h, w)                                       # :101-117,130-135
@@ -159,9 +184,9 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
             if len(down_block_additional_residuals) != len(taps):
                 raise ValueError(f"expected {len(taps)} down_block_additional_residuals, got "
                                  f"{len(down_block_additional_residuals)}")
-            fence = getattr(self, "_residual_fence", None)     # DenoiseStepper: the ControlNet ran on a side stream
-            if fence is not None:
-                fence()
+            ev = getattr(self, "_residual_event", None)        # DenoiseStepper: the ControlNet ran on a side stream
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
             mk = ws.mark()
             for (s, sh, sw), r in zip(taps, down_block_additional_residuals):
                 ops.axpby(s, self._residual_rows(ws, r, s.shape[0], s.shape[1]), 1.0, 1.0, s)

@@ -523,7 +523,11 @@ class DenoiseStepper:
                             added_time_ids=self.added_time_ids[a:b], control_cond=self.cond_em[a:b],
                             conditioning_scale=self.control_scale, return_dict=False)
                 self.unet._lane = k
-                self.unet._residual_fence = (lambda su=su, sc=sc: su.wait_stream(sc)) if sc is not su else None
+                ev = None
+                if sc is not su:      # the UNet waits for the ControlNet right before it reads the residuals
+                    ev = torch.cuda.Event()
+                    ev.record(sc)
+                self.unet._residual_event = ev
                 with torch.cuda.stream(su):
                     outs.append(self.unet(sample=self.lmi[a:b], timestep=t,
                                           encoder_hidden_states=self.image_embeddings[a:b],
@@ -533,7 +537,7 @@ class DenoiseStepper:
                 if su is not main:
                     main.wait_stream(su)                                          # join
         finally:
-            self.unet._residual_fence = None
+            self.unet._residual_event = None
             self.unet._lane = 0
             if self.controlnet is not None:
                 self.controlnet._lane = 0

@@ -148,6 +148,84 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
                          int B, int F, int CHW, float sigma, float sigma_next, void* scaled_next,
                          ctrlv_stream_t stream);
 
+/* ==================================================================================================================
+ * Plan-level entry points: one call = one model forward.  (SURVEY.md 8b "what a C-ABI replacement must export".)
+ *
+ * A plan is the execution plan of ONE model instance -- the reference's `UNetSpatioTemporalConditionModel`
+ * (src/ctrlv/models/unet_spatio_temporal_condition.py:13-171) or `ControlNetModel` (src/ctrlv/models/controlnet.py:20-351):
+ * its module graph (built from the diffusers-style config), its weights packed once into the kernels' layouts, and the
+ * walk over the layer list that issues the kernels above.  A host in any language runs a forward with
+ *     ctrlv_plan_create -> ctrlv_plan_load_weights -> ctrlv_plan_workspace_bytes -> ctrlv_{unet,controlnet}_forward.
+ * Ownership: packed weights are library-owned device memory (allocated by load_weights, freed by destroy); every
+ * input / output / workspace buffer is the caller's; a forward allocates nothing, never synchronises the host and
+ * enqueues everything on the caller's stream (HIP-graph capturable).  A plan is re-entrant across plans, not
+ * thread-safe on one plan.
+ * ================================================================================================================== */
+#define CTRLV_MAX_BLOCKS 8
+typedef struct ctrlv_model_config {
+  int32_t kind;                 /* 0 = UNetSpatioTemporalConditionModel, 1 = ControlNetModel */
+  int32_t in_channels;          /* 8 (4 noisy + 4 image latents); ControlNet: control_cond has in_channels / 2 */
+  int32_t out_channels;         /* UNet: 4 */
+  int32_t n_blocks;             /* len(down_block_types) == len(up_block_types) */
+  int32_t block_out_channels[CTRLV_MAX_BLOCKS];
+  int32_t down_cross_attn[CTRLV_MAX_BLOCKS]; /* 1: CrossAttnDownBlockSpatioTemporal, 0: DownBlockSpatioTemporal */
+  int32_t up_cross_attn[CTRLV_MAX_BLOCKS];   /* 1: CrossAttnUpBlockSpatioTemporal, 0: UpBlockSpatioTemporal (UNet) */
+  int32_t layers_per_block[CTRLV_MAX_BLOCKS];
+  int32_t num_attention_heads[CTRLV_MAX_BLOCKS];   /* head_dim = channels / heads must be 64 */
+  int32_t cross_attention_dim;                     /* 1024 */
+  int32_t addition_time_embed_dim;                 /* 256 */
+  int32_t projection_class_embeddings_input_dim;   /* 768 */
+  int32_t num_frames;                              /* frames the frame-embedding table is prepared for (others work) */
+  int32_t time_context_order;   /* 0: "sb" = diffusers 0.27.2 temporal-context ordering quirk, 1: "bs" */
+} ctrlv_model_config;
+
+typedef struct ctrlv_tensor_desc {
+  const char* name;             /* diffusers state-dict key, e.g. "down_blocks.0.resnets.0.spatial_res_block.conv1.weight" */
+  const void* data;             /* contiguous, row-major, in the PyTorch parameter layout */
+  int32_t dtype;                /* 0 fp32, 1 fp16, 2 bf16 */
+  int32_t on_device;            /* 1: device pointer (of the plan's device), 0: host pointer */
+  int64_t numel;
+} ctrlv_tensor_desc;
+
+typedef struct ctrlv_plan ctrlv_plan;
+
+int ctrlv_plan_create(const ctrlv_model_config* cfg, int device, ctrlv_plan** out);
+/* All parameters of the model by their diffusers key names (extra names are ignored, a missing one is an error).
+ * Packs into the kernel layouts: K-contiguous bf16 weights [N32][K64], q|k|v fused, GEGLU rows interleaved in 16-row
+ * (value, gate) blocks, every time_emb_proj and every cross-attention to_v concatenated into one GEMM each.
+ * May be called again (e.g. after an optimizer step); synchronises the device. */
+int ctrlv_plan_load_weights(ctrlv_plan* plan, const ctrlv_tensor_desc* tensors, size_t n);
+/* Switch the temporal cross-attention context order of an existing plan (0 "sb" / 1 "bs", see the config). */
+int ctrlv_plan_set_time_context_order(ctrlv_plan* plan, int order);
+/* Bytes of workspace one forward of (B clips, F frames, H x W latent) needs; 0 on error (see ctrlv_last_error). */
+size_t ctrlv_plan_workspace_bytes(ctrlv_plan* plan, int B, int F, int H, int W);
+/* Number of residual tensors the ControlNet produces / the UNet consumes on the down path (12 for SVD), and the
+ * rows / channels of residual i at (B, F, H, W): i in [0, n) = down residuals, i == n = the mid residual. */
+int ctrlv_plan_num_down_residuals(ctrlv_plan* plan);
+int ctrlv_plan_residual_shape(ctrlv_plan* plan, int i, int B, int F, int H, int W, int64_t* rows, int32_t* channels);
+
+/* UNetSpatioTemporalConditionModel.forward (unet_spatio_temporal_condition.py:31-171).
+ *   sample   (B, F, in_channels, H, W) contiguous, dtype 0/1/2       timestep  device fp32 [1] or [B] (n_timestep)
+ *   ehs      (B, 1, cross_attention_dim) contiguous, dtype as sample  added_time_ids device fp32 (B, n_ids)
+ *   down_res n pointers (or NULL) to channels-last bf16 rows [B*F*h_i*w_i, C_i] -- the layout
+ *            ctrlv_controlnet_forward writes; mid_res likewise (both or neither, :61); they are ADDED to the skip
+ *            tensors / the mid block output (:119-127,136-137) and not modified.
+ *   residual_event: optional hipEvent_t the stream waits on right before it reads the residuals (so a ControlNet
+ *            running on another stream overlaps the UNet's down / mid blocks); NULL = none.
+ *   out      (B, F, out_channels, H, W) contiguous, dtype as sample. */
+int ctrlv_unet_forward(ctrlv_plan* plan, const void* sample, int dtype, const float* timestep, int n_timestep,
+                       const void* ehs, const float* added_time_ids, int n_ids, const void* const* down_res,
+                       const void* mid_res, void* residual_event, void* out, int B, int F, int H, int W,
+                       void* workspace, size_t workspace_bytes, ctrlv_stream_t stream);
+/* ControlNetModel.forward (controlnet.py:226-351): control_cond (B, F, in_channels/2, H, W) dtype as sample;
+ * writes out_down[i] / out_mid as channels-last bf16 rows (shapes: ctrlv_plan_residual_shape), already multiplied by
+ * conditioning_scale (:343-344, folded into the zero-conv epilogue). */
+int ctrlv_controlnet_forward(ctrlv_plan* plan, const void* sample, const void* control_cond, int dtype,
+                             const float* timestep, int n_timestep, const void* ehs, const float* added_time_ids,
+                             int n_ids, float conditioning_scale, void* const* out_down, void* out_mid, int B, int F,
+                             int H, int W, void* workspace, size_t workspace_bytes, ctrlv_stream_t stream);
+int ctrlv_plan_destroy(ctrlv_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif
