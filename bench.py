@@ -410,7 +410,7 @@ def main():
                             f"{raw.get('_build_id', 'unstamped')}, running {_lib.build_id()}: traffic = null")
             else:
                 alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
-                         "groupnorm": ["gn_stats_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
+                         "groupnorm": ["gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
                          "residual_add": ["axpby_kernel"], "gemm_linear": ["gemm_linear"],
                          "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"]}
                 for fam, keys in alias.items():

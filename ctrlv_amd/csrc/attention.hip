@@ -275,6 +275,13 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 // carries four independent accumulator chains.  The spatial kernel is bound by instruction issue around the MFMAs
 // (SQ counters: MFMA busy 36 %, LDS and VMEM waits negligible; no-traffic diagnostic build only +10 %), so fewer
 // instructions per MFMA is what moves it.  ~200 VGPRs => 2 waves per SIMD.
+// PIPE (default): the two 32-row blocks of a wave run SKEWED by half a tile inside one instruction stream --
+//     K.Q^T(rb0) | K.Q^T(rb1) + softmax(rb0) | P.V(rb0) + softmax(rb1) | P.V(rb1)
+// so that the wave's own softmax VALU work (64 v_exp + ~90 other per 64-key tile) issues in the shadow of its own MFMAs
+// instead of after them: the un-skewed order is [16 MFMA][~190 VALU][16 MFMA] per tile, and with only two waves per
+// SIMD the matrix pipe idles whenever both are in their VALU phase (MFMA busy 36-40 %).  sched_group_barrier pins the
+// MFMA : VALU interleave (the machine scheduler otherwise clusters the MFMAs again).
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
@@ -384,7 +391,89 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
       }
     return rs2.x + rs2.y;
   };
-  auto tile = [&](int t, auto masked_tag) {
+  // ---- skewed schedule: one row block's scores / softmax / P.V, callable piecewise
+  auto scores_rb = [&](const char* kst, f32x16 (&sa)[2], int rb, int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sa[kt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
+        sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sa[kt], 0, 0, 0);
+      }
+    }
+    if (MASKED) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = t * 64 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
+          if (key >= S) sa[kt][e] = -INFINITY;
+        }
+    }
+  };
+  auto rescale_rb = [&](const char* kst, f32x16 (&sa)[2], int rb, int t, auto masked_tag) -> float {   // slow path
+    scores_rb(kst, sa, rb, t, masked_tag);
+    float mx = sa[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[kt][e]);
+    mx = half_max(mx) * kScaleLog2;
+    const float m_new = fmaxf(m_run[rb], mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+    m_run[rb] = m_new;
+    l_run[rb] *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
+    return exp_sum(sa, m_run[rb]);
+  };
+  auto pv_rb = [&](const char* vst, f32x16 (&sa)[2], int rb) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = pack_p(sa[kt], s);
+        const int kb = kt * 32 + 16 * s + vkey;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+          oacc[rb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[rb][dt], 0, 0, 0);
+        }
+      }
+  };
+  // 8 x (1 MFMA, NV VALU) -- masks: 0x008 MFMA, 0x002 VALU (incl. transcendental), 0x100 DS read
+#define ATTN_INTERLEAVE(NV)                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);             \
+  }
+  auto tile_pipe = [&](int t, auto masked_tag) {
+    const char* kst = smem + (t & 1) * 16384;
+    const char* vst = kst + 8192;
+    f32x16 s0[2], s1[2];
+    scores_rb(kst, s0, 0, t, masked_tag);                         // phase 1: 8 MFMA
+    // phase 2: K.Q^T of row block 1 in the shadow of row block 0's softmax
+    scores_rb(kst, s1, 1, t, masked_tag);
+    float rs0 = exp_sum(s0, m_run[0]);
+    ATTN_INTERLEAVE(10)
+    if (!__all(rs0 <= kSumLimit)) rs0 = rescale_rb(kst, s0, 0, t, masked_tag);
+    l_run[0] += rs0;
+    // phase 3: P.V of row block 0 in the shadow of row block 1's softmax
+    pv_rb(vst, s0, 0);
+    float rs1 = exp_sum(s1, m_run[1]);
+    ATTN_INTERLEAVE(12)
+    if (!__all(rs1 <= kSumLimit)) rs1 = rescale_rb(kst, s1, 1, t, masked_tag);
+    l_run[1] += rs1;
+    pv_rb(vst, s1, 1);                                            // phase 4: 8 MFMA
+  };
+#undef ATTN_INTERLEAVE
+  auto tile_flat = [&](int t, auto masked_tag) {
     const char* kst = smem + (t & 1) * 16384;
     const char* vst = kst + 8192;
     f32x16 sacc[2][2];
@@ -429,6 +518,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
         }
       }
     }
+  };
+  auto tile = [&](int t, auto masked_tag) {
+    if constexpr (PIPE) tile_pipe(t, masked_tag); else tile_flat(t, masked_tag);
   };
 
   const int nt = (S + 63) / 64;
@@ -593,8 +685,17 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
   const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
-    hipLaunchKernelGGL(attn_spatial64_kernel, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, S, C);
+    static int pipe = -1;                       // CTRLV_ATTN_PIPE=0 selects the un-skewed schedule (A/B, tests)
+    if (pipe < 0) {
+      const char* e = getenv("CTRLV_ATTN_PIPE");
+      pipe = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (pipe)
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
+                         (bf16_t*)out, S, C);
+    else
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
+                         (bf16_t*)out, S, C);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }

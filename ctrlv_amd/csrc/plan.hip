@@ -79,7 +79,8 @@ struct Norm { float* g = nullptr; float* b = nullptr; };
 
 struct ResBlock {
   int cin = 0, cout = 0;
-  float eps = 1e-6f, alpha = 0.5f;
+  float eps = 1e-6f;
+  double alpha = 0.5;     // sigmoid(mix_factor), kept in double: 1 - alpha is formed in double like the Python executor does
   Norm n1, n2, tn1, tn2;
   Linear c1, c2, tc1, tc2, sc;
   bool has_sc = false;
@@ -89,7 +90,7 @@ struct ResBlock {
 struct FeedFwd { Linear proj, out; };
 struct Transformer {
   int C = 0;
-  float alpha = 0.5f;
+  double alpha = 0.5;
   Norm gn, s_ln1, s_ln3, t_lnin, t_ln1, t_ln3;
   Linear pin, pout, s_qkv, s_o, t_qkv, t_o, tpe1, tpe2;
   FeedFwd s_ff, t_ffin, t_ff;
@@ -297,7 +298,7 @@ struct Loader {
     TRY(pack_v(mod + ".weight", C, nm.g, 0, 0, 0));
     return pack_v(mod + ".bias", C, nm.b, 0, 0, 0);
   }
-  int mix_alpha(const std::string& name, float* alpha) {             // sigmoid(mix_factor): AlphaBlender, scalar
+  int mix_alpha(const std::string& name, double* alpha) {             // sigmoid(mix_factor): AlphaBlender, scalar
     const ctrlv_tensor_desc* t;
     TRY(find(name, &t, 1));
     unsigned char raw[4] = {0, 0, 0, 0};
@@ -308,7 +309,7 @@ struct Loader {
     if (t->dtype == 0) memcpy(&v, raw, 4);
     else if (t->dtype == 1) { _Float16 h; memcpy(&h, raw, 2); v = (float)h; }
     else { uint32_t u = ((uint32_t)raw[1] << 24) | ((uint32_t)raw[0] << 16); memcpy(&v, &u, 4); }
-    *alpha = (float)(1.0 / (1.0 + exp(-(double)v)));
+    *alpha = 1.0 / (1.0 + exp(-(double)v));
     return CTRLV_OK;
   }
   int ff(const std::string& mod, int C, int C_out, FeedFwd& f) {     // FeedForward: GEGLU(C -> 8C) then Linear(4C -> C_out)
@@ -489,7 +490,7 @@ int run_res(Ctx& c, const ResBlock& r, const bf16_t* x, const bf16_t* x2, int c1
   {   // AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
     ctrlv_gemm_desc d = gd(hn, cout, r.tc2, out, cout, (int)M, cout, cout, cout);
     d.taps = 3; d.mode = 2; d.F = F; d.S = S;
-    d.s_acc = 1.0f - r.alpha; d.R1 = xs; d.ldr1 = cout;
+    d.s_acc = (float)(1.0 - r.alpha); d.R1 = xs; d.ldr1 = cout;
     TRY(gemm(c, d));
   }
   c.release(mk);
@@ -608,7 +609,8 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
   bf16_t* h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
-    d.s_acc = 1.0f - t.alpha; d.R1 = g1; d.ldr1 = C; d.s1 = 1.0f - t.alpha; d.R2 = h2; d.ldr2 = C; d.s2 = t.alpha;
+    d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
+    d.s2 = (float)t.alpha;
     TRY(gemm(c, d));
   }
   {

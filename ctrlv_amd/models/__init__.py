@@ -2,3 +2,4 @@
 from .controlnet import ControlNetModel, ControlNetOutput  # noqa: F401
 from .unet_spatio_temporal_condition import (UNetSpatioTemporalConditionModel,  # noqa: F401
                                              UNetSpatioTemporalConditionOutput)
+from .autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder  # noqa: F401,E402  (PyTorch-ROCm module)

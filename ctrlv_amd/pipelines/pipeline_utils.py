@@ -151,12 +151,12 @@ class _ProgressBar:
 
 
 def _load_vae(path, **kw):
+    """diffusers' AutoencoderKLTemporalDecoder when diffusers is installed, else ctrlv_amd's own PyTorch-ROCm module of
+    the same architecture and state-dict layout (models/autoencoder_kl_temporal_decoder.py)."""
     try:
         from diffusers import AutoencoderKLTemporalDecoder
-    except ImportError as e:
-        raise EnvironmentError(
-            "loading `vae/` needs diffusers' AutoencoderKLTemporalDecoder (the VAE stays a caller-side PyTorch-ROCm "
-            "module); pass `vae=...` or `component_loaders={'vae': fn}` to from_pretrained") from e
+    except ImportError:
+        from ..models.autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
     return AutoencoderKLTemporalDecoder.from_pretrained(path, **kw)
 
 

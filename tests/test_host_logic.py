@@ -253,6 +253,56 @@ def test_pipeline_from_pretrained_resolution_rules(tmp_path, monkeypatch):
     assert StableVideoControlPipeline.use_hip_graph      # graph replay is the default loop mode
 
 
+def test_vae_temporal_decoder_module(tmp_path):
+    """ctrlv_amd's PyTorch-side AutoencoderKLTemporalDecoder (outside the hot path): diffusers state-dict key
+    layout, the known parameter count of the (Stable-Diffusion-identical) encoder, shapes of encode / decode in the way
+    the pipelines call them (pipeline_video_control.py:71-101,235,346), save / load round trip, frame mixing."""
+    from ctrlv_amd.models import AutoencoderKLTemporalDecoder
+    with torch.device("meta"):
+        full = AutoencoderKLTemporalDecoder()
+    n_enc = sum(p.numel() for p in full.encoder.parameters())
+    assert n_enc == 34_163_592                                   # SD VAE encoder (128/256/512/512, 2 layers per block)
+    assert sum(p.numel() for p in full.quant_conv.parameters()) == 72
+    keys = set(full.state_dict())
+    for k in ("encoder.conv_in.weight", "encoder.down_blocks.0.resnets.1.norm2.bias",
+              "encoder.down_blocks.1.resnets.0.conv_shortcut.weight", "encoder.down_blocks.2.downsamplers.0.conv.weight",
+              "encoder.mid_block.attentions.0.to_q.bias", "encoder.mid_block.attentions.0.group_norm.weight",
+              "encoder.mid_block.resnets.1.conv2.weight", "encoder.conv_norm_out.weight", "quant_conv.weight",
+              "decoder.conv_in.weight", "decoder.mid_block.resnets.0.spatial_res_block.conv1.weight",
+              "decoder.mid_block.resnets.1.temporal_res_block.conv2.bias", "decoder.mid_block.resnets.0.time_mixer.mix_factor",
+              "decoder.mid_block.attentions.0.to_out.0.weight", "decoder.up_blocks.0.resnets.2.spatial_res_block.norm1.weight",
+              "decoder.up_blocks.2.resnets.0.spatial_res_block.conv_shortcut.weight",
+              "decoder.up_blocks.2.upsamplers.0.conv.weight", "decoder.conv_norm_out.bias", "decoder.conv_out.weight",
+              "decoder.time_conv_out.weight"):
+        assert k in keys, k
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in keys
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in keys
+    assert full.state_dict()["decoder.time_conv_out.weight"].shape == (3, 3, 3, 1, 1)
+    assert full.config.scaling_factor == 0.18215 and len(full.config.block_out_channels) == 4
+    torch.manual_seed(0)
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=(32, 64, 64, 64), layers_per_block=1).eval()
+    with torch.no_grad():
+        x = torch.rand(3, 3, 64, 64) * 2 - 1
+        dist = vae.encode(x).latent_dist
+        z = dist.mode()
+        assert z.shape == (3, 4, 8, 8) and torch.equal(z, vae.encode(x).latent_dist.mode())
+        g = torch.Generator().manual_seed(1)
+        assert dist.sample(g).shape == z.shape and not torch.equal(dist.sample(g), z)
+        y = vae.decode(z, num_frames=3).sample
+        assert y.shape == (3, 3, 64, 64) and torch.isfinite(y).all()
+        # the temporal path mixes frames: decoding frame 0 together with other frames differs from decoding it alone,
+        # once the mixers are opened (merge_factor 0.0 -> alpha = 0.5 at init already)
+        y1 = vae.decode(z[:1], num_frames=1).sample
+        assert (y[:1] - y1).abs().max() > 1e-6
+        with pytest.raises(ValueError, match="multiple of num_frames"):
+            vae.decode(z, num_frames=2)
+        vae.save_pretrained(str(tmp_path / "vae"))
+        v2 = AutoencoderKLTemporalDecoder.from_pretrained(str(tmp_path / "vae"))
+        assert torch.equal(v2.decode(z, num_frames=3).sample, y)
+    from ctrlv_amd.pipelines.pipeline_utils import _load_vae
+    assert type(_load_vae(str(tmp_path / "vae"))).__name__ == "AutoencoderKLTemporalDecoder"     # no diffusers here
+
+
 def test_image_processor_and_tensor2vid():
     from ctrlv_amd.pipelines.pipeline_utils import VaeImageProcessor, _resize_with_antialiasing, tensor2vid
     ip = VaeImageProcessor(8)

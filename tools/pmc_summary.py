@@ -20,7 +20,7 @@ def family(name):
         return {"0": "gemm_linear", "1": "gemm_conv3x3", "2": "gemm_conv_temporal"}[m.group(1)]
     if "attn_spatial" in name:      # 32- and 64-rows-per-wave variants
         return "attn_spatial_kernel"
-    for k in ("gemm_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_apply_kernel",
+    for k in ("gemm_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel",
               "ln_kernel", "axpby_kernel", "im2col3x3_kernel", "cfg_euler_kernel"):
         if k in name:
             return k
