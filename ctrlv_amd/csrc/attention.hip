@@ -275,12 +275,17 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 // carries four independent accumulator chains.  The spatial kernel is bound by instruction issue around the MFMAs
 // (SQ counters: MFMA busy 36 %, LDS and VMEM waits negligible; no-traffic diagnostic build only +10 %), so fewer
 // instructions per MFMA is what moves it.  ~200 VGPRs => 2 waves per SIMD.
-// PIPE (default): the two 32-row blocks of a wave run SKEWED by half a tile inside one instruction stream --
+// PIPE (experiment, off by default; CTRLV_ATTN_PIPE=1): the two 32-row blocks of a wave run SKEWED by half a tile inside
+// one instruction stream --
 //     K.Q^T(rb0) | K.Q^T(rb1) + softmax(rb0) | P.V(rb0) + softmax(rb1) | P.V(rb1)
 // so that the wave's own softmax VALU work (64 v_exp + ~90 other per 64-key tile) issues in the shadow of its own MFMAs
 // instead of after them: the un-skewed order is [16 MFMA][~190 VALU][16 MFMA] per tile, and with only two waves per
 // SIMD the matrix pipe idles whenever both are in their VALU phase (MFMA busy 36-40 %).  sched_group_barrier pins the
 // MFMA : VALU interleave (the machine scheduler otherwise clusters the MFMAs again).
+// MEASURED on MI355X (tools/attn_bench.py, S = 9216): 5.87 ms against 5.56 ms for the un-skewed order -- the forced
+// interleave costs ~120 more instructions per tile (K fragments read twice, hazard s_nops between transcendental and
+// dependent VALU, per-block slow-path tests) and the two waves of a SIMD already overlap each other's phases to the same
+// degree.  Kept as a documented negative result and A/B handle.
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               int S, int C) {
@@ -685,10 +690,10 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
   const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
-    static int pipe = -1;                       // CTRLV_ATTN_PIPE=0 selects the un-skewed schedule (A/B, tests)
+    static int pipe = -1;                       // CTRLV_ATTN_PIPE=1 selects the skewed schedule (A/B; measured slower)
     if (pipe < 0) {
       const char* e = getenv("CTRLV_ATTN_PIPE");
-      pipe = (e && e[0] == '0') ? 0 : 1;
+      pipe = (e && e[0] == '1') ? 1 : 0;
     }
     if (pipe)
       hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,

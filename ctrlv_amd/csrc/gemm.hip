@@ -228,15 +228,6 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     if (!big) tile = 1;
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
-    // small-M layers (L3 / mid block: M = 7200; the 320x512 working size: M = 8000 / 2000): when the 256-wide tiling
-    // fills less than ~2/3 of the CUs in its only round, the 192-wide tile gives 4/3 as many, 3/4 as long, tiles --
-    // as long as those still fit one round
-    if (tile == 5 && getenv("CTRLV_NO_TILE9") == nullptr) {
-      const int ncu = ctrlv_num_cu(ctrlv_current_device());
-      const int tm = (d.M + 255) / 256;
-      const int t256 = tm * ((d.N + 255) / 256), t192 = tm * ((d.N + 191) / 192);
-      if (t256 * 3 < ncu * 2 && t192 <= ncu && d.N >= 384) tile = 9;
-    }
   }
   if (tile >= 5) {
     // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
@@ -256,8 +247,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 5:
     case 7: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 6:
-    case 8:
-    case 9: return ctrlv_gemm_launch_pp(d, tile, stream);
+    case 8: return ctrlv_gemm_launch_pp(d, tile, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

@@ -29,18 +29,15 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
 }
 
 // tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
-// workgroup per output tile instead of one persistent workgroup per CU; tile 9: 256x192 (waves 4x2) for the small-M
-// layers whose 256-wide tiling leaves CUs idle (M = 7200 x N = 1280: 145 tiles on 256 CUs -> 203 narrower ones).
+// workgroup per output tile instead of one persistent workgroup per CU.
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
-  const bool persistent = tile <= 6 || tile == 9;
+  const bool persistent = tile <= 6;
   if (d.mode == 1) return ctrlv_gemm_launch_pp_conv(d, tile, persistent, stream);
   if (d.mode == 2) return ctrlv_gemm_launch_pp_temporal(d, tile, persistent, stream);
   if (d.geglu) {
-    if (tile == 9) return launch_one<192, 4, 2, 0, true, 0>(d, persistent, stream);
     if (tile == 5 || tile == 7) return launch_one<256, 2, 4, 0, true, 0>(d, persistent, stream);
     return launch_one<320, 4, 2, 0, true, 0>(d, persistent, stream);
   }
-  if (tile == 9) return launch_epi<192, 4, 2, 0>(d, persistent, stream);
   if (tile == 5 || tile == 7) return launch_epi<256, 2, 4, 0>(d, persistent, stream);
   return launch_epi<320, 4, 2, 0>(d, persistent, stream);
 }

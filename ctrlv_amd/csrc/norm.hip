@@ -8,6 +8,8 @@
 // x -> y = silu(x*a_c + b_c).
 // Algorithmic traffic: 2 reads + 1 write of the tensor (the second read of mid-size tensors is served by L2 /
 // Infinity Cache).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -197,7 +199,15 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
   // many images are in the batch: a clip's statistics are bit-identical whether it is normalised alone or in a batch
   // (clip independence, tests/test_fullsize_gpu.py).  ~1000-2000 workgroups at the cfg3 batch of 50 images:
   // 256-row chunks at S = 9216, 64 at S = 2304, 32 below.
-  s->rows_per_chunk = S >= 4096 ? 256 : (S >= 1024 ? 64 : 32);
+  {
+    static int rpc_big = 0;              // A/B handle: CTRLV_GN_ROWS=<rows per chunk at S >= 4096> (default 256)
+    if (rpc_big == 0) {
+      const char* e = getenv("CTRLV_GN_ROWS");
+      rpc_big = e ? atoi(e) : 256;
+      if (rpc_big < 32 || rpc_big > 1024) rpc_big = 256;
+    }
+    s->rows_per_chunk = S >= 4096 ? rpc_big : (S >= 1024 ? 64 : 32);
+  }
   if (s->rows_per_chunk > S) s->rows_per_chunk = S;
   s->n_chunks = (S + s->rows_per_chunk - 1) / s->rows_per_chunk;
   return CTRLV_OK;

@@ -195,6 +195,41 @@ def test_fullsize_step_properties(models):
 
 
 @torch.no_grad()
+def test_reference_default_size_320x512_step(models):
+    """A whole Box2Video step at the reference's default working size (25 frames, latent 40 x 64, CFG batch 2): the small-M
+    levels (M = 8000 / 2000 rows) take other tile / grid paths than the 576x1024 shapes.  Properties: finite, the C++
+    plan and the per-op executor agree bit for bit, run-to-run identical, clips independent under the fixed order."""
+    unet, ctrl = models
+    h, w = 40, 64
+    sample = randn(2, FR, 8, h, w, seed=400)
+    cond = randn(2, FR, 4, h, w, seed=401)
+    ehs = randn(2, 1, 1024, seed=402)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=DEV, dtype=torch.bfloat16)
+    t = torch.tensor(0.25 * math.log(20.0), device=DEV)
+
+    def fwd(sl):
+        down, mid = ctrl(sample[sl], timestep=t, encoder_hidden_states=ehs[sl], added_time_ids=ids[sl],
+                         control_cond=cond[sl], return_dict=False)
+        return unet(sample=sample[sl], timestep=t, encoder_hidden_states=ehs[sl], added_time_ids=ids[sl],
+                    down_block_additional_residuals=down, mid_block_additional_residuals=mid,
+                    return_dict=False)[0].clone()
+
+    res = {}
+    for ex in ("plan", "python"):
+        unet.executor = ctrl.executor = ex
+        res[ex] = fwd(slice(0, 2))
+    unet.executor = ctrl.executor = "plan"
+    assert res["plan"].shape == (2, FR, 4, h, w) and torch.isfinite(res["plan"].float()).all()
+    assert torch.equal(res["plan"], res["python"]) and torch.equal(res["plan"], fwd(slice(0, 2)))
+    unet.time_context_order = ctrl.time_context_order = "bs"
+    try:
+        both = fwd(slice(0, 2))
+        assert torch.equal(both[0:1], fwd(slice(0, 1))) and torch.equal(both[1:2], fwd(slice(1, 2)))
+    finally:
+        unet.time_context_order = ctrl.time_context_order = "sb"
+
+
+@torch.no_grad()
 def test_fullsize_zero_controlnet_is_noop(models):
     from ctrlv_amd.utils import random_init_
     unet, ctrl = models

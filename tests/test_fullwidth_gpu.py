@@ -44,6 +44,15 @@ def test_fullwidth_ragged_latent(full_pair):
     assert max(err["storage"].values()) < 2e-2 and max(err["fp32"].values()) < 1.5e-2, err
 
 
+def test_fullwidth_reference_default_latent_40x64(full_pair):
+    """The reference's own default working size, 320x512 (latent 40 x 64 -> 20x32 -> 10x16 -> 5x8; SURVEY finding 5,
+    src/ctrlv/datasets/kitti_abstract.py:86-90), at production widths against the oracle (2 frames, CFG batch)."""
+    cfg, pair = full_pair
+    err = run_parity(cfg, DEV, B=2, F=2, h=40, w=64, time_context_order="sb", verbose=True, pair=pair,
+                     with_unet_no_ctrl=False)
+    check_tables(err)
+
+
 def test_fullwidth_error_growth_trace(full_pair):
     """Error after each of the 55 blocks at production widths (CFG batch 2): slow walk, no jump."""
     from tests.parity_utils import error_growth_trace, make_inputs, set_context_order

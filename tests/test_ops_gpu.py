@@ -42,7 +42,7 @@ def g(seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ gather-GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
     """Every epilogue operand combination the models use.  Tiles 1-4 (2-stage kernels) take any combination incl. SiLU
@@ -95,7 +95,7 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_geglu(ops, tile):
     from ctrlv_amd import packing
     M, C = 333, 320       # 8C = 2560: 8 tiles of 320 / 10 of 256; the ragged 333 rows span two 256-row tiles
@@ -111,7 +111,7 @@ def test_gemm_geglu(ops, tile):
     assert parity_err(out, ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
 def test_gemm_conv3x3(ops, tile, stride, up):
     from ctrlv_amd import packing
@@ -131,7 +131,7 @@ def test_gemm_conv3x3(ops, tile, stride, up):
     assert parity_err(nchw_from_rows(out.cpu(), n, Ho, Wo), ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 4, 5, 6, 9])
+@pytest.mark.parametrize("tile", [1, 4, 5, 6])
 def test_gemm_temporal_conv(ops, tile):
     from ctrlv_amd import packing
     B, Fr, C, H, W = 2, 5, 64, 4, 6
@@ -174,7 +174,7 @@ def test_gemm_concat_split(ops, tile):
     assert parity_err(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [5, 6, 7, 8])
 def test_gemm_persistent_many_tiles(ops, tile):
     """More output tiles than CUs: every persistent workgroup walks several tiles and the LDS-DMA ring runs through the
     tile boundaries (ragged last M tile, conv halo rows, 2 N tiles for the 256-wide tile)."""
