@@ -70,6 +70,12 @@ SIGNATURES = {
     "ctrlv_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                      c_float, c_void_p, c_void_p]),
+    "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p]),
+    "ctrlv_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "ctrlv_dot_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "ctrlv_groupnorm_bwd_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
+    "ctrlv_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctrlv_plan_create": (c_int, [ctypes.POINTER(ModelConfig), c_int, ctypes.POINTER(c_void_p)]),
     "ctrlv_plan_load_weights": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_size_t]),
     "ctrlv_plan_set_time_context_order": (c_int, [c_void_p, c_int]),
@@ -87,7 +93,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CtrlvHipError(RuntimeError):

@@ -57,28 +57,42 @@ __device__ __forceinline__ float silu_f(float x) {
 // between dependent packed-fp32 instructions that the compiler otherwise pads with s_nop.)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// Every fused multiply-add below is EXPLICIT (and contraction is off for the rest): the value of gelu must not depend on
+// which kernel inlines this function -- the scalar 2-stage GEMM epilogue and the packed ping-pong epilogue serve the same
+// layer at different batch sizes, and "contract where profitable" gave them different roundings in rare elements.
+__device__ __forceinline__ f32x4_t fma4(f32x4_t a, f32x4_t b, f32x4_t c) {
+  f32x4_t r;
+  r.x = __builtin_fmaf(a.x, b.x, c.x); r.y = __builtin_fmaf(a.y, b.y, c.y);
+  r.z = __builtin_fmaf(a.z, b.z, c.z); r.w = __builtin_fmaf(a.w, b.w, c.w);
+  return r;
+}
+__device__ __forceinline__ f32x4_t splat4(float v) { return f32x4_t{v, v, v, v}; }
 __device__ __forceinline__ f32x4_t gelu_phi4(f32x4_t x) {
+#pragma clang fp contract(off)
   f32x4_t xc;
   xc.x = __builtin_amdgcn_fmed3f(x.x, -5.0f, 5.0f);
   xc.y = __builtin_amdgcn_fmed3f(x.y, -5.0f, 5.0f);
   xc.z = __builtin_amdgcn_fmed3f(x.z, -5.0f, 5.0f);
   xc.w = __builtin_amdgcn_fmed3f(x.w, -5.0f, 5.0f);
-  const f32x4_t t = xc * xc * 0.08f - 1.0f;
-  f32x4_t p = t * 7.353763795e-04f + (-1.676730928e-03f);
-  p = p * t + 1.374596148e-03f;
-  p = p * t + (-2.526916796e-03f);
-  p = p * t + 6.766527425e-03f;
-  p = p * t + (-1.130712498e-02f);
-  p = p * t + 1.623608917e-02f;
-  p = p * t + (-2.321312763e-02f);
-  p = p * t + 3.147675842e-02f;
-  p = p * t + (-4.045128077e-02f);
-  p = p * t + 5.151792988e-02f;
-  p = p * t + (-7.029590756e-02f);
-  p = p * t + 1.413638145e-01f;
-  return xc * p + 0.5f;                     // Phi(x)
+  const f32x4_t t = fma4(xc * xc, splat4(0.08f), splat4(-1.0f));
+  f32x4_t p = fma4(t, splat4(7.353763795e-04f), splat4(-1.676730928e-03f));
+  p = fma4(p, t, splat4(1.374596148e-03f));
+  p = fma4(p, t, splat4(-2.526916796e-03f));
+  p = fma4(p, t, splat4(6.766527425e-03f));
+  p = fma4(p, t, splat4(-1.130712498e-02f));
+  p = fma4(p, t, splat4(1.623608917e-02f));
+  p = fma4(p, t, splat4(-2.321312763e-02f));
+  p = fma4(p, t, splat4(3.147675842e-02f));
+  p = fma4(p, t, splat4(-4.045128077e-02f));
+  p = fma4(p, t, splat4(5.151792988e-02f));
+  p = fma4(p, t, splat4(-7.029590756e-02f));
+  p = fma4(p, t, splat4(1.413638145e-01f));
+  return fma4(xc, p, splat4(0.5f));          // Phi(x)
 }
-__device__ __forceinline__ f32x4_t gelu_erf4(f32x4_t x) { return x * gelu_phi4(x); }
+__device__ __forceinline__ f32x4_t gelu_erf4(f32x4_t x) {
+#pragma clang fp contract(off)
+  return x * gelu_phi4(x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
   f32x4_t v = {x, x, x, x};
   return gelu_erf4(v).x;

@@ -49,17 +49,28 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
+          // The same operation sequence as the ping-pong kernels' epilogue (v_pk_mul_f32, then one v_pk_fma_f32 per
+          // residual): t = acc * s_acc ROUNDED, then fma(s, R, t).  Left to the contraction heuristics the compiler
+          // formed fma(acc, s_acc, s1 * R) here -- one fp32 ulp apart, which after the bf16 store made a layer served by
+          // this kernel (small M) and by the ping-pong kernel (large M) differ in an occasional last bit.
+          {
+#pragma clang fp contract(off)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] *= d.s_acc;
+            for (int e = 0; e < 4; ++e) o[e] = o[e] * d.s_acc;
+          }
           if (d.R1) {
             const uint2 rv = *(const uint2*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ncol);
-            o[0] += d.s1 * __uint_as_float(rv.x << 16); o[1] += d.s1 * __uint_as_float(rv.x & 0xffff0000u);
-            o[2] += d.s1 * __uint_as_float(rv.y << 16); o[3] += d.s1 * __uint_as_float(rv.y & 0xffff0000u);
+            o[0] = __builtin_fmaf(d.s1, __uint_as_float(rv.x << 16), o[0]);
+            o[1] = __builtin_fmaf(d.s1, __uint_as_float(rv.x & 0xffff0000u), o[1]);
+            o[2] = __builtin_fmaf(d.s1, __uint_as_float(rv.y << 16), o[2]);
+            o[3] = __builtin_fmaf(d.s1, __uint_as_float(rv.y & 0xffff0000u), o[3]);
           }
           if (d.R2) {
             const uint2 rv = *(const uint2*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ncol);
-            o[0] += d.s2 * __uint_as_float(rv.x << 16); o[1] += d.s2 * __uint_as_float(rv.x & 0xffff0000u);
-            o[2] += d.s2 * __uint_as_float(rv.y << 16); o[3] += d.s2 * __uint_as_float(rv.y & 0xffff0000u);
+            o[0] = __builtin_fmaf(d.s2, __uint_as_float(rv.x << 16), o[0]);
+            o[1] = __builtin_fmaf(d.s2, __uint_as_float(rv.x & 0xffff0000u), o[1]);
+            o[2] = __builtin_fmaf(d.s2, __uint_as_float(rv.y << 16), o[2]);
+            o[3] = __builtin_fmaf(d.s2, __uint_as_float(rv.y & 0xffff0000u), o[3]);
           }
           if (vrow) {
             const float4 vv = *(const float4*)(vrow + ncol);

@@ -213,21 +213,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const int m = m0 + i * 32 + pass * 16;
         const bool ok = m < d.M && ocol < d.n_store;
+        // Fixed operation sequence -- t = acc * s_acc (rounded), then ONE fma per residual -- shared with the 2-stage
+        // kernel (gemm_epilogue.h).  Left to the contraction heuristics, the SLP vectoriser paired fma(s_acc, acc, s1*R)
+        // in one half of a v_pk_fma_f32 with fma(s1, R, s_acc*acc) in the other: legal, but a layer then differed in an
+        // occasional last bit depending on which kernel (i.e. which batch size) served it.
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] *= d.s_acc;                 // (the bias is already in the accumulator)
+          for (int e = 0; e < 8; ++e) o[e] = o[e] * d.s_acc;         // (the bias is already in the accumulator)
+        }
         if (EPI & 2) {
           float f[8];
           const u32x4_t r = q[HAS_RES ? s : 0].r1[pass];
           unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += d.s1 * f[e];
+          for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
         }
         if (EPI & 4) {
           float f[8];
           const u32x4_t r = q[HAS_RES ? s : 0].r2[pass];
           unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += d.s2 * f[e];
+          for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
         }
         if (EPI & 1) {
 #pragma unroll

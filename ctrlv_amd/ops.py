@@ -23,6 +23,50 @@ def _need_gpu(t, name="tensor"):
         raise _lib.CtrlvHipError(f"ctrlv_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
 
 
+def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=None, temporal=None):
+    """dW[N, taps*cin] (fp32, packed tap-major K order) += dY^T . gather(A) for the forward GEMM of the same geometry."""
+    _need_gpu(A, "A")
+    d = GemmDesc()
+    d.A, d.A2 = _p(A), _p(A2)
+    d.M, d.N, d.Cin, d.taps, d.mode = dY.shape[0], N, cin, taps, mode
+    d.lda = A.stride(0)
+    d.lda2 = A2.stride(0) if A2 is not None else 0
+    d.c_split = c_split
+    if conv is not None:
+        d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
+    if temporal is not None:
+        d.F, d.S = temporal
+    check(_lib.load().ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _stream()), "ctrlv_gemm_wgrad")
+    return dW
+
+
+def colsum(x, out, vmode=0, vdiv=1, vmod=1, scale=1.0):
+    """out[idx(m), :N] += scale * sum_m x[m, :]  (fp32, atomics): bias gradients (vmode 0) / per-clip row-vector gradients."""
+    _need_gpu(x, "x")
+    check(_lib.load().ctrlv_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), vmode, vdiv, vmod, float(scale), _p(out),
+                                   out.stride(0) if out.dim() > 1 else x.shape[1], _stream()), "ctrlv_colsum")
+    return out
+
+
+def dot_diff(dy, p, q, out, scale=1.0):
+    _need_gpu(dy, "dy")
+    check(_lib.load().ctrlv_dot_diff(_p(dy), _p(p), _p(q), dy.numel(), float(scale), _p(out), _stream()), "ctrlv_dot_diff")
+    return out
+
+
+def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, silu, dx, dgamma, dbeta):
+    _need_gpu(x, "x")
+    lib = _lib.load()
+    n = lib.ctrlv_groupnorm_bwd_scratch_floats(n_img, S, C, imgs_per_stat)
+    if n < 0:
+        check(n, "ctrlv_groupnorm_bwd_scratch_floats")
+    scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(lib.ctrlv_groupnorm_bwd(_p(x), _p(dy), n_img, S, C, imgs_per_stat, _p(fwd_partials), _p(gamma), _p(beta),
+                                  1 if silu else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch), _stream()),
+          "ctrlv_groupnorm_bwd")
+    return dx
+
+
 def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
          R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
          act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, _dbg=0):

@@ -148,6 +148,30 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
                          int B, int F, int CHW, float sigma, float sigma_next, void* scaled_next,
                          ctrlv_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward kernels: first slice of the training step (tools/train_video_controlnet.py:451-488 -- ControlNet dgrad +
+ * wgrad, UNet up-path dgrad).  DGRAD of the gather-GEMM family is ctrlv_gemm itself on
+ * role-swapped weights (ctrlv_amd/autograd.py); these are the reductions the forward kernels cannot express.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* dW[n][tap*Cin + c] += sum_m dY[m][n] * A[src(m, tap)][c]  for the forward GEMM described by `fwd` (A, A2/c_split, M, N,
+ * Cin, taps, mode and its geometry are read; W / out / epilogue fields are ignored).  dY: bf16 [M][ldy]; dW: fp32
+ * [N][taps*Cin] in the packed (tap-major) K order, accumulated with atomics -- zero it first. */
+int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float* dW, ctrlv_stream_t stream);
+/* out[idx(m)][n] += scale * x[m][n] summed over rows; idx = 0 (vmode 0: bias gradient) or (m / vdiv) % vmod (vmode 1: the
+ * gradient of a per-clip row-vector operand V).  x bf16 [M][ldx], out fp32 [*][ldo], accumulated with atomics. */
+int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out, int ldo,
+                 ctrlv_stream_t stream);
+/* out[0] += scale * sum_i dy[i] * (p[i] - q[i]) over n bf16 elements: the gradient of a folded AlphaBlender's mixing
+ * weight (out = xs + (1 - a) * h  =>  dL/da = -sum dy * (out - xs) / (1 - a)). */
+int ctrlv_dot_diff(const void* dy, const void* p, const void* q, size_t n, float scale, float* out, ctrlv_stream_t stream);
+/* GroupNorm(32)(+SiLU) backward on channels-last rows.  `fwd_partials` is the buffer ctrlv_groupnorm_stats filled for
+ * the same x (its (mean, rstd) table is reused); dx bf16; dgamma / dbeta fp32 [C], ACCUMULATED; scratch fp32 of
+ * ctrlv_groupnorm_bwd_scratch_floats() elements. */
+int ctrlv_groupnorm_bwd_scratch_floats(int n_img, int S, int C, int imgs_per_stat);
+int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, int imgs_per_stat,
+                        const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,
+                        float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
+
 /* ==================================================================================================================
  * Plan-level entry points: one call = one model forward.  (SURVEY.md 8b "what a C-ABI replacement must export".)
  *
