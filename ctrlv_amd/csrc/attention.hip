@@ -287,8 +287,11 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 // dependent VALU, per-block slow-path tests) and the two waves of a SIMD already overlap each other's phases to the same
 // degree.  Kept as a documented negative result and A/B handle.
 template <bool PIPE>
-__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              int S, int C) {
+#ifndef CTRLV_ATTN_OCC
+#define CTRLV_ATTN_OCC 2
+#endif
+__global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              int S, int C, int phase_delay) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
     }
   };
   auto exp_sum = [&](f32x16 (&sacc)[2], float m) -> float {
+#ifdef CTRLV_ATTN_PACKED
     f32x2_t rs2 = {0.f, 0.f};
     const f32x2_t nm = {-m, -m};
 #pragma unroll
@@ -395,6 +399,25 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
         rs2 += pe;
       }
     return rs2.x + rs2.y;
+#else
+    // SCALAR fp32 on purpose (this file is built with -fno-slp-vectorize): beside MFMAs a v_pk_add_f32 / v_pk_fma_f32
+    // costs about four issue slots, two plain v_fma_f32 cost two (MI355X_MICROARCH.md, "price of one filler beside
+    // MFMAs") -- packing the softmax arithmetic halves the instruction count and doubles its cost.
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    const float nm = -m;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e], kScaleLog2, nm));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 1], kScaleLog2, nm));
+        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 2], kScaleLog2, nm));
+        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 3], kScaleLog2, nm));
+        sacc[kt][e] = p0; sacc[kt][e + 1] = p1; sacc[kt][e + 2] = p2; sacc[kt][e + 3] = p3;
+        r0 += p0; r1 += p1; r2 += p2; r3 += p3;
+      }
+    return (r0 + r1) + (r2 + r3);
+#endif
   };
   // ---- skewed schedule: one row block's scores / softmax / P.V, callable piecewise
   auto scores_rb = [&](const char* kst, f32x16 (&sa)[2], int rb, int t, auto masked_tag) {
@@ -531,6 +554,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
   const int nt = (S + 63) / 64;
   const int nt_full = S / 64;
   issue(0, 0);
+  // Two workgroups share a CU (two waves per SIMD): every wave alternates a matrix phase (16 + 16 MFMAs) and a softmax
+  // VALU phase of about the same length.  Workgroups that start together stay IN phase (both want the matrix pipe, then
+  // both the VALU); delaying every second dispatch "generation" by half a tile puts the co-resident pair in anti-phase.
+  if (phase_delay > 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((lin >> 8) & 1)
+      for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   for (int t = 0; t < nt_full; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -677,6 +708,8 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
 
 }  // namespace
 
+int ctrlv_attention_spatial_pipelined(const void* qkv, void* out, int n_img, int S, int C, hipStream_t stream);  // attention_pipe.hip
+
 extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
@@ -688,6 +721,12 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
     rows = (e && e[0] == '3') ? 32 : (e && e[0] == '6') ? 64 : -1;
   }
   const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
+  static int xpipe = -1;                        // CTRLV_ATTN_X=1: cross-tile pipelined kernel (attention_pipe.hip)
+  if (xpipe < 0) {
+    const char* e = getenv("CTRLV_ATTN_X");
+    xpipe = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (use64 && xpipe) return ctrlv_attention_spatial_pipelined(qkv, out, n_img, S, C, (hipStream_t)stream);
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
     static int pipe = -1;                       // CTRLV_ATTN_PIPE=1 selects the skewed schedule (A/B; measured slower)
@@ -695,12 +734,25 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
       const char* e = getenv("CTRLV_ATTN_PIPE");
       pipe = (e && e[0] == '1') ? 1 : 0;
     }
+    static int delay = -1;                      // CTRLV_ATTN_DELAY=<n>: anti-phase start delay in units of ~1024 cycles
+    if (delay < 0) {
+      const char* e = getenv("CTRLV_ATTN_DELAY");
+      delay = e ? atoi(e) : 0;
+    }
+    // (diagnostic builds -DCTRLV_ATTN_OCC=1 ask for > half of the LDS so that one workgroup owns the CU)
+    constexpr int kSmem64 = CTRLV_ATTN_OCC == 1 ? 98304 : 32768;
+    static bool attr64[CTRLV_MAX_DEVICES] = {};
+    if (kSmem64 > 65536 && !attr64[ctrlv_current_device()]) {
+      CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)attn_spatial64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64));
+      CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)attn_spatial64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64));
+      attr64[ctrlv_current_device()] = true;
+    }
     if (pipe)
-      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
+                         (bf16_t*)out, S, C, delay);
     else
-      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
+                         (bf16_t*)out, S, C, delay);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }

@@ -20,3 +20,13 @@ def hip_lib():
     g.build()             # no-op when the library's build id matches the hash of csrc/ + include/
     from ctrlv_amd import _lib
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _grad_mode_is_per_test():
+    """A test (or a module it imports) that flips torch's global grad mode must not leak it into the next test."""
+    import torch
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    yield
+    torch.set_grad_enabled(prev)

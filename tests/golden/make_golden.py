@@ -18,14 +18,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import ctrlv_ref as R  # noqa: E402
 
-torch.manual_seed(0)
-torch.set_grad_enabled(False)
 
 
 def npy(t):
     return t.detach().float().numpy()
 
 
+@torch.no_grad()
 def scheduler_tables():
     out = {}
     for n in (25, 30, 50):
@@ -38,6 +37,7 @@ def scheduler_tables():
     np.savez_compressed(os.path.join(HERE, "scheduler_tables.npz"), **out)
 
 
+@torch.no_grad()
 def block_vectors():
     g = torch.Generator().manual_seed(7)
     B, F, H, W, C, temb_c = 1, 2, 8, 8, 64, 256
@@ -60,6 +60,7 @@ def q_(t):
     return t.to(torch.bfloat16).float()
 
 
+@torch.no_grad()
 def q_blocks():
     """The three block instances of the `q*` fixtures: weights `seeded_init_` then rounded to bf16 (what the HIP path
     holds), so the vectors isolate arithmetic / activation-storage differences from weight rounding."""
@@ -72,6 +73,7 @@ def q_blocks():
     return rb, rc, tr
 
 
+@torch.no_grad()
 def block_vectors_q():
     """Batch-2 (CFG-shaped) block fixtures on bf16-rounded weights and inputs, B = 2 clips x F = 3 frames x 8 x 8.
     `*_y` = fp32 arithmetic; `*_ys` = fp32 arithmetic with bf16 rounding at the HIP path's storage points
@@ -100,6 +102,7 @@ def block_vectors_q():
     return out
 
 
+@torch.no_grad()
 def model_vectors():
     cfg = dict(R.TINY_CONFIG)
     out = {}
@@ -145,6 +148,7 @@ def model_vectors():
 
 
 if __name__ == "__main__":
+    torch.manual_seed(0)
     scheduler_tables()
     block_vectors()
     model_vectors()

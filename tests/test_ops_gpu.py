@@ -311,6 +311,22 @@ def test_attention_spatial(ops, n_img, S, C):
     assert parity_err(out, ref) < 5e-3
 
 
+def test_attention_spatial_experimental_kernels_still_correct():
+    """The opt-in schedules kept in-tree as documented experiments (CTRLV_ATTN_X=1: cross-tile pipelined kernel of
+    attention_pipe.hip; CTRLV_ATTN_PIPE=1: skewed row blocks) must stay correct: the spatial-attention tests of this file
+    re-run in a child process with each switch set (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for var in ("CTRLV_ATTN_X", "CTRLV_ATTN_PIPE"):
+        env = dict(os.environ, **{var: "1"})
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-x", "-k",
+                            "attention_spatial and not experimental"], env=env, capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert r.returncode == 0, (var, r.stdout[-1500:])
+
+
 @pytest.mark.parametrize("S,kpk", [(320, 300), (1280, 1200)])
 def test_attention_spatial_peaked(ops, S, kpk):
     """Online-softmax rescale path: one key dominates late in the sequence (running max jumps at a later tile); both the

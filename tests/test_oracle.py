@@ -11,6 +11,12 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 torch.set_grad_enabled(False)
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
 def test_param_counts_match_published_svd_sizes():
     with torch.device("meta"):
         u, c = R.UNetSpatioTemporalConditionModel(), R.ControlNetModel()
