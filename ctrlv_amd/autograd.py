@@ -153,6 +153,71 @@ class BlendGemm(torch.autograd.Function):
         return dhn, dw, db, (dY if need[3] else None), dmix, None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x [+ V[(m // vdiv) % vmod]]) over the channel axis (eps 1e-5); V = the frame positional embedding
+    table of TransformerSpatioTemporalModel (fp32 [F, C]) or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, V, vdiv, vmod):
+        y = torch.empty_like(x)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        ops.layernorm(x, g32, b32, 1e-5, y, V=V, vdiv=vdiv, vmod=vmod)
+        ctx.save_for_backward(x, g32, V if V is not None else torch.empty(0, device=x.device))
+        ctx.cfg = (V is not None, vdiv, vmod, gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, V = ctx.saved_tensors
+        has_v, vdiv, vmod, pdt = ctx.cfg
+        C = x.shape[1]
+        dx = torch.empty_like(x)
+        dg = torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(x, dy.contiguous(), g32, 1e-5, dx, dg, db, V=V if has_v else None, vdiv=vdiv, vmod=vmod)
+        dV = None
+        if has_v and ctx.needs_input_grad[3]:
+            dV = torch.zeros_like(V)
+            ops.colsum(dx, dV, vmode=1, vdiv=vdiv, vmod=vmod)
+        return dx, dg.to(pdt), db.to(pdt), dV, None, None
+
+
+class GegluProj(torch.autograd.Function):
+    """u = a * gelu_erf(g), (a | g) = x @ W^T + b   (diffusers GEGLU: `proj` Linear(C -> 2 I), chunk, exact gelu) -- the
+    forward is ONE GEMM with the GEGLU epilogue; the backward recomputes the raw projection (activation recompute instead
+    of storing an [M, 2I] tensor), applies ctrlv_geglu_bwd and reuses the GEMM family for dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        two_i, cin = weight.shape
+        wp, bp = packing.pack_geglu(weight, bias)
+        u = _rows(x.shape[0], two_i // 2, x)
+        ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1)
+        ctx.save_for_backward(x, weight, bias)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        x, weight, bias = ctx.saved_tensors
+        two_i, cin = weight.shape
+        inner = two_i // 2
+        wi = packing.geglu_interleave(weight.detach())                 # rows in the packed (value, gate) block order
+        wp, bp = packing.pack_geglu(weight, bias)
+        raw = _rows(x.shape[0], two_i, x)
+        ops.gemm(x, wp, raw, N=two_i, cin=wp.shape[1], bias=bp)        # activation recompute (no GEGLU epilogue)
+        draw = torch.empty_like(raw)
+        ops.geglu_bwd(raw, du.contiguous(), draw)
+        dx, dwi, dbi = gemm_grads(x, wi, draw, dict(mode=0), 1.0, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  ctx.needs_input_grad[2])
+        # un-interleave the rows: interleaved row ((r >> 4) * 2 + is_gate) * 16 + (r & 15)  <-  original row r (+ inner)
+        idx = torch.arange(two_i, device=x.device)
+        isg, r = (idx >= inner).long(), idx % inner
+        src = ((r >> 4) * 2 + isg) * 16 + (r & 15)
+        dw = dwi[src] if dwi is not None else None
+        db = dbi[src] if dbi is not None else None
+        return dx, dw, db
+
+
 def res_block_train_forward(block, x, temb_tables, B, F, H, W):
     """Training-mode forward of a `ctrlv_amd.models.blocks.SpatioTemporalResBlock` (no skip-concat input) built from the
     autograd functions above; same kernels, same fusion as `block.run` (bit-identical output), but every op records

@@ -282,7 +282,162 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// One wave per row (grid-stride), 8 * NV columns per lane like the forward.  Recomputes mean / rstd of x (+ V row), then
+//   dz = dy * gamma;  dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat));  dgamma += dy * xhat;  dbeta += dy
+// (dgamma / dbeta: per-lane column partials over the wave's rows, one atomic per column per wave at the end).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int M, int C,
+                                                     const float* __restrict__ gamma, float eps, const float* __restrict__ V,
+                                                     int vdiv, int vmod, int ldv, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int CV = C >> 3;
+  float g[NV][8], ag[NV][8], ab[NV][8];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cv = lane + k * 64;
+      g[k][e] = cv < CV ? gamma[cv * 8 + e] : 0.f;
+      ag[k][e] = ab[k][e] = 0.f;
+    }
+  const float inv_c = 1.0f / (float)C;
+  for (long m = (long)blockIdx.x * 4 + wid; m < M; m += (long)gridDim.x * 4) {
+    const float* vrow = V ? V + (long)((m / vdiv) % vmod) * ldv : nullptr;
+    float fx[NV][8], fd[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+        unpack_bf16x8(*(const uint4*)(x + m * C + cv * 8), fx[k]);
+        unpack_bf16x8(*(const uint4*)(dy + m * C + cv * 8), fd[k]);
+        if (vrow) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fx[k][e] += vrow[cv * 8 + e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fx[k][e] = fd[k][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += fx[k][e];
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = fx[k][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_c + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (fx[k][e] - mean) * rstd;        // (columns past C: fd = g = 0 contribute nothing)
+        const float dz = fd[k][e] * g[k][e];
+        fx[k][e] = xh;
+        s1 += dz;
+        s2 += dz * xh;
+        ag[k][e] += fd[k][e] * xh;
+        ab[k][e] += fd[k][e];
+      }
+    const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cv = lane + k * 64;
+      if (cv < CV) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (fd[k][e] * g[k][e] - m1 - fx[k][e] * m2);
+        *(uint4*)(dx + m * C + cv * 8) = pack_bf16x8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int cv = lane + k * 64;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(dgamma + cv * 8 + e, ag[k][e]);
+        atomicAdd(dbeta + cv * 8 + e, ab[k][e]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU backward
+// raw: the projection output [M][2I] in the packed (16-value, 16-gate) column-block order (the forward GEMM without its
+// GEGLU epilogue); du: gradient of u = a * gelu(g), [M][I].  draw (same layout as raw): da = du * gelu(g),
+// dg = du * a * (Phi(g) + g * phi(g)).
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ raw, const bf16_t* __restrict__ du, long M,
+                                                        int I, bf16_t* __restrict__ draw) {
+  const long total = M * (I >> 3);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / (I >> 3);
+    const int j0 = (int)(i % (I >> 3)) * 8;            // 8 consecutive u columns: inside one 16-column block
+    const int blk = j0 >> 4, r0 = j0 & 15;
+    const long base = m * (2L * I) + blk * 32 + r0;
+    float a[8], g[8], d[8], oa[8], og[8];
+    unpack_bf16x8(*(const uint4*)(raw + base), a);
+    unpack_bf16x8(*(const uint4*)(raw + base + 16), g);
+    unpack_bf16x8(*(const uint4*)(du + m * I + j0), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const f32x4_t gv = {g[e], g[e], g[e], g[e]};
+      const float Phi = gelu_phi4(gv).x;
+      const float phi = 0.3989422804014327f * __expf(-0.5f * g[e] * g[e]);
+      oa[e] = d[e] * (g[e] * Phi);
+      og[e] = d[e] * a[e] * (Phi + g[e] * phi);
+    }
+    *(uint4*)(draw + base) = pack_bf16x8(oa);
+    *(uint4*)(draw + base + 16) = pack_bf16x8(og);
+  }
+}
+
 }  // namespace
+
+extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V,
+                                   int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta,
+                                   ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm_bwd: C=%d must be a multiple of 8, <= 2048", C);
+  if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm_bwd: bad row-vector table");
+  const int nv = (C / 8 + 63) / 64;
+  long blocks = ((long)M + 3) / 4;
+  if (blocks > 256 * 4) blocks = 256 * 4;
+  hipStream_t st = (hipStream_t)stream;
+#define LNB_LAUNCH(NV)                                                                                                  \
+  hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, M, C, \
+                     gamma, eps, V, vdiv, vmod, ldv, (bf16_t*)dx, dgamma, dbeta)
+  switch (nv) {
+    case 1: LNB_LAUNCH(1); break;
+    case 2: LNB_LAUNCH(2); break;
+    case 3: LNB_LAUNCH(3); break;
+    default: LNB_LAUNCH(4); break;
+  }
+#undef LNB_LAUNCH
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I, void* draw, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(raw && du && draw, "geglu_bwd: null pointer");
+  CTRLV_CHECK_SHAPE(M > 0 && I > 0 && I % 16 == 0, "geglu_bwd: inner dim %d must be a multiple of 16", I);
+  size_t blocks = (M * (I / 8) + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)raw,
+                     (const bf16_t*)du, (long)M, I, (bf16_t*)draw);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
 
 extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dp && dY && dW, "gemm_wgrad: null pointer");

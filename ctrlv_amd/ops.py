@@ -67,6 +67,21 @@ def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, 
     return dx
 
 
+def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 << 30):
+    _need_gpu(x, "x")
+    M, C = x.shape
+    check(_lib.load().ctrlv_layernorm_bwd(_p(x), _p(dy), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
+                                          V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _stream()),
+          "ctrlv_layernorm_bwd")
+    return dx
+
+
+def geglu_bwd(raw, du, draw):
+    _need_gpu(raw, "raw")
+    check(_lib.load().ctrlv_geglu_bwd(_p(raw), _p(du), du.shape[0], du.shape[1], _p(draw), _stream()), "ctrlv_geglu_bwd")
+    return draw
+
+
 def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
          R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
          act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, _dbg=0):

@@ -114,6 +114,57 @@ def test_groupnorm_backward(ops, C, H, W, n, ips, silu):
     assert parity_err(dg, gamma.grad, "GN dgamma") < 2e-3 and parity_err(db, beta.grad, "GN dbeta") < 2e-3
 
 
+@pytest.mark.parametrize("C,with_v", [(64, False), (320, True), (1280, False)])
+def test_layernorm_backward(ops, C, with_v):
+    from ctrlv_amd.autograd import LayerNormFn
+    M, Fr, S = 600, 3, 25
+    x = bf(torch.randn(M, C, generator=g(1)) * 1.3 + 0.2)
+    dy = bf(torch.randn(M, C, generator=g(2)))
+    gamma = torch.randn(C, generator=g(3), requires_grad=True)
+    beta = torch.randn(C, generator=g(4), requires_grad=True)
+    V = torch.randn(Fr, C, generator=g(5), requires_grad=True) if with_v else None
+    xr = x.float().requires_grad_(True)
+    xin = xr + V[(torch.arange(M) // S) % Fr] if with_v else xr
+    F.layer_norm(xin, (C,), gamma, beta, 1e-5).backward(dy.float())
+    xd = x.to(DEV).requires_grad_(True)
+    gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
+    Vd = V.detach().to(DEV).requires_grad_(True) if with_v else None
+    y = LayerNormFn.apply(xd, gd, bd, Vd, S, Fr if with_v else 1 << 30)
+    y.backward(dy.to(DEV))
+    assert parity_err(xd.grad, xr.grad, "LN dx") < 4e-3
+    assert parity_err(gd.grad, gamma.grad, "LN dgamma") < 2e-3 and parity_err(bd.grad, beta.grad, "LN dbeta") < 2e-3
+    if with_v:
+        assert parity_err(Vd.grad, V.grad, "LN dV (frame embedding)") < 4e-3
+
+
+@pytest.mark.parametrize("C", [64, 320])
+def test_geglu_feedforward_backward(ops, C):
+    """GEGLU projection + output Linear (diffusers FeedForward) through GegluProj / GatherGemm vs torch.autograd."""
+    from ctrlv_amd.autograd import GatherGemm, GegluProj
+    M = 777
+    x = bf(torch.randn(M, C, generator=g(1)))
+    w1 = (bf(torch.randn(8 * C, C, generator=g(2)) / math.sqrt(C))).float().requires_grad_(True)
+    b1 = bf(torch.randn(8 * C, generator=g(3)) * 0.1).float().requires_grad_(True)
+    w2 = (bf(torch.randn(C, 4 * C, generator=g(4)) / math.sqrt(4 * C))).float().requires_grad_(True)
+    b2 = bf(torch.randn(C, generator=g(5)) * 0.1).float().requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    h, gate = F.linear(xr, w1, b1).chunk(2, dim=-1)
+    yr = F.linear(h * F.gelu(gate), w2, b2) + xr
+    dy = bf(yr.detach() + 0.5 * torch.randn(M, C, generator=g(6)))
+    yr.backward(dy.float())
+    xd = x.to(DEV).requires_grad_(True)
+    pd = [t.detach().to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    u = GegluProj.apply(xd, pd[0], pd[1])
+    y = GatherGemm.apply(u, pd[2], pd[3], xd, None, 1.0, dict(mode=0))
+    assert parity_err(y.detach(), yr.detach(), "FF forward") < 4e-3
+    y.backward(dy.to(DEV))
+    errs = {"x": rel_l2(xd.grad, xr.grad)}
+    for name, a, b in zip(("w1", "b1", "w2", "b2"), pd, (w1, b1, w2, b2)):
+        errs[name] = rel_l2(a.grad, b.grad)
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1.5e-2, errs
+
+
 def _oracle_block(cin, cout, seed):
     import ctrlv_ref as R
     rb = R.seeded_init_(R.SpatioTemporalResBlock(cin, cout, 256, eps=1e-6), seed)
