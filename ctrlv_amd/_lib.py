@@ -53,6 +53,7 @@ SIGNATURES = {
     "ctrlv_build_id": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "ctrlv_gemm_st_occupancy": (c_int, []),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p]),

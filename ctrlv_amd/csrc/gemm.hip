@@ -21,6 +21,9 @@
 
 // ping-pong schedule (gemm_pp_kernel.h, gemm_pp_m*.hip): tile 5 = 256x256, tile 6 = 256x320 (7 / 8: non-persistent)
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
+// streamed 4-wave schedule, two workgroups per CU (gemm_st_kernel.h, gemm_st.hip): tile 9 = 256x160, mode 0
+bool ctrlv_gemm_st_supports(const ctrlv_gemm_desc& d);
+int ctrlv_gemm_launch_st(const ctrlv_gemm_desc& d, hipStream_t stream);
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);
 
 namespace {
@@ -225,7 +228,13 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // 1280, GEGLU at K < 1280), 256x256 otherwise (N = 3840 qkv, K = 1280 GEGLU: +7 %); tiny-M per-clip GEMMs stay on
     // 128x128.
     const bool big = d.M >= 1024 && d.N >= 128;
+    // tile 9 (streamed, two 4-wave workgroups per CU: one's epilogue beside the other's K loop) is opt-in
+    // (CTRLV_GEMM_ST=1): isolated it is +4-5 % on the K = 320 GEGLU projections and behind the ping-pong tiles
+    // elsewhere; in the model (graph replay, ControlNet on the side stream) the step time does not move
+    // (profiles/r02_gemm_streamed_ab.txt).
+    static const bool use_st = [] { const char* e = getenv("CTRLV_GEMM_ST"); return e && atoi(e) != 0; }();
     if (!big) tile = 1;
+    else if (use_st && d.geglu && d.Cin <= 320 && d.N % 160 == 0 && d.M >= 16384 && ctrlv_gemm_st_supports(d)) tile = 9;
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
@@ -233,7 +242,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
     const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&
                          (!d.R2 || d.ldr2 % 8 == 0) && (!d.vmode || d.ldv % 8 == 0);
-    if (!wide_ok || !ctrlv_gemm_pp_supports(d)) {
+    if (!wide_ok || !ctrlv_gemm_pp_supports(d) || (tile == 9 && !ctrlv_gemm_st_supports(d))) {
       CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8 and an "
                                      "epilogue of {bias, V, R1, R1+V, R1+R2} without SiLU / fp32 output");
       tile = 1;
@@ -248,6 +257,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 7: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 6:
     case 8: return ctrlv_gemm_launch_pp(d, tile, stream);
+    case 9: return ctrlv_gemm_launch_st(d, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

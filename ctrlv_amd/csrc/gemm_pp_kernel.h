@@ -101,7 +101,7 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
 }
 
-template <int TM, int TN, bool GEGLU, int EPI>
+template <int TM, int TN, bool GEGLU, int EPI, bool PACKED = true>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3, const char* bias_lds) {
@@ -272,7 +272,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
             const f32x4_t g = {acc[i][js][4 * (qd + 2)], acc[i][js][4 * (qd + 2) + 1], acc[i][js][4 * (qd + 2) + 2],
                                acc[i][js][4 * (qd + 2) + 3]};
             const f32x4_t a = {acc[i][js][4 * qd], acc[i][js][4 * qd + 1], acc[i][js][4 * qd + 2], acc[i][js][4 * qd + 3]};
-            const f32x4_t o = a * gelu_erf4(g);
+            f32x4_t o;
+            if constexpr (PACKED) {
+              o = a * gelu_erf4(g);
+            } else {
+#pragma clang fp contract(off)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = a[e] * (g[e] * gelu_phi1(g[e]));
+            }
             const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
             *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
           }

@@ -86,6 +86,9 @@ typedef struct ctrlv_gemm_desc {
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
+/* Diagnostic: resident workgroups per CU of the streamed short-K kernel (tile 9) on the current device; its schedule
+ * relies on two (<= 80 KB LDS, <= 256 registers each).  -1 on a HIP error. */
+int ctrlv_gemm_st_occupancy(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * GroupNorm(32) (+SiLU), channels-last.  Replaces nn.GroupNorm + SiLU of ResnetBlock2D.norm1/norm2,

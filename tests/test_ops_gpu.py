@@ -42,7 +42,7 @@ def g(seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ gather-GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
     """Every epilogue operand combination the models use.  Tiles 1-4 (2-stage kernels) take any combination incl. SiLU
@@ -95,7 +95,7 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_geglu(ops, tile):
     from ctrlv_amd import packing
     M, C = 333, 320       # 8C = 2560: 8 tiles of 320 / 10 of 256; the ragged 333 rows span two 256-row tiles
@@ -196,6 +196,33 @@ def test_gemm_persistent_many_tiles(ops, tile):
     outl = torch.empty(M, 640, dtype=torch.bfloat16, device=DEV)
     ops.gemm(A.to(DEV), packing.pack_linear(wl).to(DEV), outl, N=640, cin=128, R1=R1.to(DEV), tile=tile)
     assert parity_err(outl, A.float() @ bf(wl).float().T + R1.float()) < 3e-3
+
+
+@pytest.mark.parametrize("geglu", [0, 1])
+def test_gemm_streamed_many_tiles_bit_identical(ops, geglu):
+    """Tile 9 (streamed 4-wave schedule, two workgroups per CU, 256 x 160): more tiles than workgroup slots, ragged
+    last M tile, N not a multiple of 160; same summation order and epilogue as the ping-pong tiles => identical bits."""
+    from ctrlv_amd import packing
+    M, K, N = 256 * 140 + 77, 320, 2560 if geglu else 1120      # 141 M-tiles x 16 / 7 N-tiles
+    A = bf(torch.randn(M, K, generator=g(1))).to(DEV)
+    wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    if geglu:
+        Wp, bp = packing.pack_geglu(wt, b)
+        kw = dict(N=N, cin=K, bias=bp.to(DEV), geglu=1)
+        n_out = N // 2
+    else:
+        Wp = packing.pack_linear(wt)
+        R1 = bf(torch.randn(M, N, generator=g(4))).to(DEV)
+        kw = dict(N=N, cin=K, bias=b.to(DEV), R1=R1, s1=0.75, s_acc=1.25)
+        n_out = N
+    outs = []
+    for tile in (9, 5):
+        out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(A, Wp.to(DEV), out, tile=tile, **kw)
+        outs.append(out)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_gemm_small_m_and_padding(ops):

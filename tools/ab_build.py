@@ -16,7 +16,8 @@ procs, objs = [], []
 for s in g.HIP_SOURCES:
     o = os.path.join(out_dir, f"{s}.{name}.o")
     objs.append(o)
-    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c",
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *g.EXTRA_FLAGS.get(s, []),
+                                   *flags, "-c",
                                    os.path.join(g.CSRC, s), "-o", o]))
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out_dir, f"libctrlv_{name}.so")

@@ -19,7 +19,7 @@ def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objs, procs = [], []
     for s in ge.HIP_SOURCES:
-        if not s.startswith("gemm"):
+        if not (s.startswith("gemm") or s == "abi.hip"):
             continue
         o = os.path.join(ROOT, "gpurun_out", s + ".stamp.o")
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -31,12 +31,15 @@ def build():
 
 def main():
     dbg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    force_tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     build()
     from ctrlv_amd import _lib
     lib = ctypes.CDLL(OUT)
     lib.ctrlv_gemm.restype = ctypes.c_int
     lib.ctrlv_gemm.argtypes = [ctypes.POINTER(_lib.GemmDesc), ctypes.c_void_p]
     dev = "cuda:0"
+    torch.zeros(1, device=dev)
+    print("streamed kernel: resident workgroups per CU =", lib.ctrlv_gemm_st_occupancy())
     g = torch.Generator(device=dev).manual_seed(0)
     N0, N1 = 50 * 9216, 50 * 2304
     shapes = [("L0 qkv 320->960", N0, 960, 320, 1, 0, None, 6, 0),
@@ -46,6 +49,8 @@ def main():
               ("L0 conv3x3 320->320", N0, 320, 320, 9, 1, (72, 128, 72, 128, 1, 0), 6, 0),
               ("L1 conv3x3 1920->640", N1, 640, 1920, 9, 1, (36, 64, 36, 64, 1, 0), 6, 0),
               ("L1 geglu 640->5120", N1, 5120, 640, 1, 0, None, 5, 0)]
+    names9 = ["total", "1st half (reads+mfma)", "vmcnt wait", "lgkm+barrier", "2nd half (reads+mfma)", "lgkm wait", "-",
+              "epilogue"]
     names = ["total", "L:ds_read issue", "L:dma issue", "L:vmcnt+lgkm wait", "L:barrier", "C:mfma+dma", "C:barrier",
              "epilogue"]
     for name, M, N, K, taps, mode, geo, tile, r1 in shapes:
@@ -65,7 +70,10 @@ def main():
             d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = geo
         d.ldo, d.n_store, d.ldr1, d.ldr2 = out.shape[1], out.shape[1], N, N
         d.s_acc, d.s1, d.s2 = 1.0, 1.0, 0.0
-        d.geglu, d.tile = geglu, tile
+        if force_tile == 9 and mode != 0:
+            continue
+        d.geglu, d.tile = geglu, force_tile or tile
+        nm = names9 if force_tile == 9 else names
         d.out_f32 = dbg
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(2):
@@ -78,7 +86,7 @@ def main():
         print(f"{name:28s} half-steps/wg {int(s[0, 8]):5d} tiles/wg {int(s[0, 9]):3d}  cycles/wave {tot:10.0f}")
         for i in range(1, 8):
             v = s[:, i].mean().item()
-            print(f"      {names[i]:18s} {v:10.0f}  {100 * v / tot:5.1f}%   per half-step {v / s[0, 8].item():7.0f}")
+            print(f"      {nm[i]:22s} {v:10.0f}  {100 * v / tot:5.1f}%   per half-step {v / s[0, 8].item():7.0f}")
 
 
 if __name__ == "__main__":
