@@ -63,6 +63,11 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctrlv_attention_spatial_lse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ctrlv_attention_bwd_scratch_floats": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "ctrlv_attention_spatial_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_void_p]),
+    "ctrlv_attention_temporal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ctrlv_nchw_to_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ctrlv_rows_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ctrlv_im2col3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -97,7 +102,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CtrlvHipError(RuntimeError):

@@ -62,7 +62,7 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 // default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
 template <int NSLOT>
 __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int S, int C) {
+                                                           float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 3 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -255,6 +255,9 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 
   const float l_tot = half_sum(l_run);
   const float inv = 1.0f / l_tot;
+  // training forward: L = m + log2(l) per row (log2 domain of the scaled scores), [img][head][S] fp32 -- the backward
+  // kernels rebuild P = exp2(s * scale * log2e - L) from it
+  if (lse && qrow < S && hsel == 0) lse[((long)img * gridDim.y + head) * S + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
   if (qrow < S) {
     bf16_t* op = out + (row0 + qrow) * C + head * 64;
 #pragma unroll
@@ -291,7 +294,7 @@ template <bool PIPE>
 #define CTRLV_ATTN_OCC 2
 #endif
 __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              int S, int C, int phase_delay) {
+                                                              float* __restrict__ lse, int S, int C, int phase_delay) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -576,7 +579,10 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
 
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
-    const float inv = 1.0f / half_sum(l_run[rb]);
+    const float l_tot = half_sum(l_run[rb]);
+    const float inv = 1.0f / l_tot;
+    if (lse && qrow[rb] < S && hsel == 0)
+      lse[((long)img * gridDim.y + head) * S + qrow[rb]] = m_run[rb] + __builtin_amdgcn_logf(l_tot);
     if (qrow[rb] < S) {
       bf16_t* op = out + (row0 + qrow[rb]) * C + head * 64;
 #pragma unroll
@@ -710,7 +716,11 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
 
 int ctrlv_attention_spatial_pipelined(const void* qkv, void* out, int n_img, int S, int C, hipStream_t stream);  // attention_pipe.hip
 
+extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream);
 extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
+  return ctrlv_attention_spatial_lse(qkv, out, nullptr, n_img, S, C, stream);
+}
+extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
   CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
@@ -726,7 +736,7 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
     const char* e = getenv("CTRLV_ATTN_X");
     xpipe = (e && e[0] == '1') ? 1 : 0;
   }
-  if (use64 && xpipe) return ctrlv_attention_spatial_pipelined(qkv, out, n_img, S, C, (hipStream_t)stream);
+  if (use64 && xpipe && !lse) return ctrlv_attention_spatial_pipelined(qkv, out, n_img, S, C, (hipStream_t)stream);
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
     static int pipe = -1;                       // CTRLV_ATTN_PIPE=1 selects the skewed schedule (A/B; measured slower)
@@ -749,10 +759,10 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
     }
     if (pipe)
       hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, S, C, delay);
+                         (bf16_t*)out, lse, S, C, delay);
     else
       hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, S, C, delay);
+                         (bf16_t*)out, lse, S, C, delay);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
@@ -766,10 +776,10 @@ extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, in
   }
   if (nslot == 3)
     hipLaunchKernelGGL((attn_spatial_kernel<3>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, S, C);
+                       (bf16_t*)out, lse, S, C);
   else
     hipLaunchKernelGGL((attn_spatial_kernel<2>), grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, S, C);
+                       (bf16_t*)out, lse, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -163,6 +163,35 @@ def attention_spatial(qkv, out, n_img, S, C):
     return out
 
 
+def attention_spatial_lse(qkv, out, lse, n_img, S, C):
+    """Training forward: also writes lse [n_img, C/64, S] fp32 (log2-domain log-sum-exp of the scaled scores)."""
+    _need_gpu(qkv, "qkv")
+    ev = _prof.begin()
+    check(_lib.load().ctrlv_attention_spatial_lse(_p(qkv), _p(out), _p(lse), n_img, S, C, _stream()),
+          "ctrlv_attention_spatial_lse")
+    _prof.end(ev, "attention_spatial", 4.0 * n_img * (C // 64) * S * S * 64, 2.0 * 4 * n_img * S * C)
+    return out
+
+
+def attention_spatial_bwd(qkv, out, dout, lse, dqkv, n_img, S, C):
+    _need_gpu(qkv, "qkv")
+    delta = torch.empty(_lib.load().ctrlv_attention_bwd_scratch_floats(n_img, S, C), dtype=torch.float32, device=qkv.device)
+    ev = _prof.begin()
+    check(_lib.load().ctrlv_attention_spatial_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), n_img, S, C,
+                                                  _stream()), "ctrlv_attention_spatial_bwd")
+    _prof.end(ev, "attention_spatial_bwd", 14.0 * n_img * (C // 64) * S * S * 64, 2.0 * 8 * n_img * S * C)
+    return dqkv
+
+
+def attention_temporal_bwd(qkv, out, dout, dqkv, B, F, S, C):
+    _need_gpu(qkv, "qkv")
+    ev = _prof.begin()
+    check(_lib.load().ctrlv_attention_temporal_bwd(_p(qkv), _p(out), _p(dout), _p(dqkv), B, F, S, C, _stream()),
+          "ctrlv_attention_temporal_bwd")
+    _prof.end(ev, "attention_temporal_bwd", 14.0 * B * S * (C // 64) * F * F * 64, 2.0 * 8 * B * F * S * C)
+    return dqkv
+
+
 def attention_temporal(qkv, out, B, F, S, C):
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()

@@ -123,6 +123,18 @@ int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float
  * ------------------------------------------------------------------------------------------------------------------ */
 int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream);
 int ctrlv_attention_temporal(const void* qkv, void* out, int B, int F, int S, int C, ctrlv_stream_t stream);
+/* Training forward of the spatial core: additionally writes L = m + log2(l) of every softmax row (log2 domain of the
+ * scaled scores), lse [n_img][C/64][S] fp32 (NULL = ctrlv_attention_spatial). */
+int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream);
+/* Backward of the two cores (torch autograd of F.scaled_dot_product_attention, cfg5 training step,
+ * tools/train_video_controlnet.py:451-488).  dout [rows, C] bf16 -> dqkv [rows, 3C] bf16 (dq | dk | dv, every column
+ * written).  spatial: lse from ctrlv_attention_spatial_lse, delta = ctrlv_attention_bwd_scratch_floats() floats of
+ * scratch (receives rowsum(dO * O)).  Deterministic (no atomics). */
+size_t ctrlv_attention_bwd_scratch_floats(int n_img, int S, int C);
+int ctrlv_attention_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                float* delta, int n_img, int S, int C, ctrlv_stream_t stream);
+int ctrlv_attention_temporal_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, int B, int F, int S, int C,
+                                 ctrlv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Element-wise / layout kernels.

@@ -233,3 +233,87 @@ def test_zero_conv_backward(hip_lib):
     ref_w = 0.8 * dy.float().T @ x.detach().float()
     assert parity_err(conv.weight.grad.reshape(C, C), ref_w, "zero-conv wgrad") < 2e-3
     assert parity_err(conv.bias.grad, 0.8 * dy.float().sum(0), "zero-conv bias grad") < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention backward
+def _attn_ref(qkv, dout, n_seq, L, C):
+    """fp32 autograd of F.scaled_dot_product_attention on the bf16-rounded operands; qkv rows [n_seq*L, 3C]."""
+    heads = C // 64
+    x = qkv.float().clone().requires_grad_(True)
+    f = x.reshape(n_seq, L, 3, heads, 64)
+    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    with torch.enable_grad():
+        o = F.scaled_dot_product_attention(q, k, v)
+        out = o.permute(0, 2, 1, 3).reshape(n_seq * L, C)
+        out.backward(dout.float())
+    lse = torch.logsumexp((q @ k.transpose(-1, -2)).detach() * 0.125, dim=-1) * math.log2(math.e)     # [n, heads, L]
+    return out.detach(), x.grad, lse
+
+
+@pytest.mark.parametrize("n_img,S,C", [(2, 200, 128), (1, 1100, 64), (3, 64, 320), (1, 2304, 128)])
+def test_attention_spatial_backward(ops, n_img, S, C):
+    """dq | dk | dv of the spatial core against fp32 autograd; both forward kernels' L (S < 1024: 32 rows per wave,
+    S >= 1024: 64), ragged last key / query tiles.  Tolerance: P and dS are rounded to bf16 before their MFMAs and the
+    outputs are bf16: parity_err <= 1e-2."""
+    qkv = bf(torch.randn(n_img * S, 3 * C, generator=g(1)))
+    dout = bf(torch.randn(n_img * S, C, generator=g(2)))
+    ref_out, ref_grad, ref_lse = _attn_ref(qkv, dout, n_img, S, C)
+    qd, gd = qkv.to(DEV), dout.to(DEV)
+    out = torch.empty(n_img * S, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((n_img, C // 64, S), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention_spatial_lse(qd, out, lse, n_img, S, C)
+    assert parity_err(out, ref_out, "attention out") < 5e-3
+    assert (lse.cpu() - ref_lse).abs().max() < 2e-3
+    dqkv = torch.full((n_img * S, 3 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention_spatial_bwd(qd, out, gd, lse, dqkv, n_img, S, C)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert parity_err(dqkv[:, i * C:(i + 1) * C], ref_grad[:, i * C:(i + 1) * C], name) < 1e-2
+    # deterministic: a second run gives the same bits
+    dqkv2 = torch.empty_like(dqkv)
+    ops.attention_spatial_bwd(qd, out, gd, lse, dqkv2, n_img, S, C)
+    assert torch.equal(dqkv, dqkv2)
+
+
+def test_attention_spatial_backward_peaked(ops):
+    """Large, peaked logits (one key dominates a query; scores of several hundred): P is rebuilt from the saved L.
+    With 3x larger queries the bf16 rounding of dS weighs more (measured max-element error 1.3e-2): bound 2e-2."""
+    S, C = 320, 64
+    qkv = torch.randn(S, 3 * C, generator=g(1))
+    qkv[:, :64] *= 3.0
+    qkv[300, 64:128] = qkv[7, :64] * 4.0
+    qkv = bf(qkv)
+    dout = bf(torch.randn(S, C, generator=g(2)))
+    ref_out, ref_grad, _ = _attn_ref(qkv, dout, 1, S, C)
+    qd, gd = qkv.to(DEV), dout.to(DEV)
+    out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(1, 1, S, dtype=torch.float32, device=DEV)
+    ops.attention_spatial_lse(qd, out, lse, 1, S, C)
+    dqkv = torch.empty(S, 3 * C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_spatial_bwd(qd, out, gd, lse, dqkv, 1, S, C)
+    assert not torch.isnan(dqkv.float()).any()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert parity_err(dqkv[:, i * C:(i + 1) * C], ref_grad[:, i * C:(i + 1) * C], name) < 2e-2
+
+
+@pytest.mark.parametrize("B,Fr,S,C", [(2, 25, 37, 128), (1, 32, 16, 64), (1, 2, 50, 320), (3, 7, 5, 64)])
+def test_attention_temporal_backward(ops, B, Fr, S, C):
+    """Temporal core (rows ordered (b, f, s), attention over the frames of each (b, s)): dqkv against fp32 autograd."""
+    heads = C // 64
+    qkv = bf(torch.randn(B * Fr * S, 3 * C, generator=g(1)))
+    dout = bf(torch.randn(B * Fr * S, C, generator=g(2)))
+    # (b f s) rows -> sequences (b s) of length f
+    perm = qkv.reshape(B, Fr, S, 3 * C).permute(0, 2, 1, 3).reshape(B * S * Fr, 3 * C)
+    dperm = dout.reshape(B, Fr, S, C).permute(0, 2, 1, 3).reshape(B * S * Fr, C)
+    ref_out, ref_grad, _ = _attn_ref(perm, dperm, B * S, Fr, C)
+    ref_out = ref_out.reshape(B, S, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * S, C)
+    ref_grad = ref_grad.reshape(B, S, Fr, 3 * C).permute(0, 2, 1, 3).reshape(B * Fr * S, 3 * C)
+    qd, gd = qkv.to(DEV), dout.to(DEV)
+    out = torch.empty(B * Fr * S, C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_temporal(qd, out, B, Fr, S, C)
+    assert parity_err(out, ref_out, "temporal out") < 5e-3
+    dqkv = torch.full((B * Fr * S, 3 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention_temporal_bwd(qd, out, gd, dqkv, B, Fr, S, C)
+    assert not torch.isnan(dqkv.float()).any()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert parity_err(dqkv[:, i * C:(i + 1) * C], ref_grad[:, i * C:(i + 1) * C], name) < 1e-2
+    assert heads >= 1
