@@ -9,8 +9,10 @@ per-clip row vector V, s_acc}, GroupNorm(+SiLU) in its 4-D and 5-D forms, and th
   dgrad  = the forward kernel on role-swapped weights (Linear: W^T; convs: taps reversed, channels transposed)
   wgrad  = ctrlv_gemm_wgrad (transposed-LDS-read MFMA kernel), bias / row-vector gradients = ctrlv_colsum
   norms  = ctrlv_groupnorm_bwd on the statistics the forward saved
-Activations and activation gradients are bf16 rows; parameter gradients are fp32 in the PyTorch layouts.  Attention,
-LayerNorm and GEGLU backward, strided / upsampling conv dgrad and DDP bucketing are the next steps.
+Activations and activation gradients are bf16 rows; parameter gradients are fp32 in the PyTorch layouts.
+Second slice: LayerNorm, GEGLU, the attention cores (flash-style backward, csrc/attention_bwd.hip), nn.Linear with the
+whole fused epilogue (FusedLinear / BlendLinear) => a complete `TransformerSpatioTemporalModel`; stride-2 and
+upsample-fused convs.  The model-level training step built from these lives in ctrlv_amd/training.py.
 """
 import math
 
@@ -246,3 +248,180 @@ def zero_conv_train_forward(conv, x, scale=1.0):
     """A ControlNet zero-conv (1x1) times conditioning_scale (controlnet.py:331-344) with gradients."""
     C = conv.weight.shape[0]
     return GatherGemm.apply(x, conv.weight.reshape(C, -1), conv.bias, None, None, float(scale), dict(mode=0))
+
+
+# =============================================================================== transformer (second slice)
+def _scaled(dy, s):
+    """s * dy as a new bf16 tensor (dy itself when s == 1)."""
+    if s == 1.0:
+        return dy
+    out = torch.empty_like(dy)
+    ops.axpby(dy, dy, float(s), 0.0, out)
+    return out
+
+
+class FusedLinear(torch.autograd.Function):
+    """out = s_acc * (A @ W^T + b) + s1 * R1 + s2 * R2 + V[(m // vdiv) % vmod]   (nn.Linear with the epilogue operands the
+    transformer fuses: residuals, the per-clip cross-attention vector, the frame positional embedding)."""
+
+    @staticmethod
+    def forward(ctx, A, weight, bias, R1, R2, V, cfg):
+        s_acc, s1, s2 = float(cfg.get("s_acc", 1.0)), float(cfg.get("s1", 1.0)), float(cfg.get("s2", 1.0))
+        vdiv, vmod = cfg.get("vdiv", 1), cfg.get("vmod", 1 << 30)
+        N, cin = weight.shape
+        out = _rows(A.shape[0], N, A)
+        ops.gemm(A, packing.pack_linear(weight), out, N=(N + 31) // 32 * 32, cin=cin,
+                 bias=None if bias is None else packing.pad_bias(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
+                 V=V, vmode=1 if V is not None else 0, vdiv=vdiv, vmod=vmod)
+        ctx.save_for_backward(A, weight)
+        ctx.cfg = (s_acc, s1, s2, vdiv, vmod, bias is not None, R1 is not None, R2 is not None,
+                   None if V is None else tuple(V.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dY):
+        A, weight = ctx.saved_tensors
+        s_acc, s1, s2, vdiv, vmod, has_b, has_r1, has_r2, vshape = ctx.cfg
+        need = ctx.needs_input_grad
+        dY = dY.contiguous()
+        dA, dW, db = gemm_grads(A, weight, dY, dict(mode=0), s_acc, need[0], need[1], has_b and need[2])
+        dR1 = _scaled(dY, s1) if (has_r1 and need[3]) else None
+        dR2 = _scaled(dY, s2) if (has_r2 and need[4]) else None
+        dV = None
+        if vshape is not None and need[5]:
+            dV = torch.zeros(vshape, dtype=torch.float32, device=A.device)
+            ops.colsum(dY, dV, vmode=1, vdiv=vdiv, vmod=min(vmod, vshape[0]))
+        return dA, dW, db, dR1, dR2, dV, None
+
+
+class BlendLinear(torch.autograd.Function):
+    """Temporal FF output with the transformer's AlphaBlender folded in:
+        out = a * h2 + (1 - a) * (g1 + u @ W^T + b),   a = sigmoid(mix_factor)."""
+
+    @staticmethod
+    def forward(ctx, u, weight, bias, g1, h2, mix_factor):
+        a = 1.0 / (1.0 + math.exp(-float(mix_factor.detach().float().cpu())))
+        N, cin = weight.shape
+        out = _rows(u.shape[0], N, u)
+        ops.gemm(u, packing.pack_linear(weight), out, N=N, cin=cin, bias=packing.pad_bias(bias), s_acc=1.0 - a,
+                 R1=g1, s1=1.0 - a, R2=h2, s2=a)
+        ctx.save_for_backward(u, weight, h2, out, mix_factor)
+        ctx.a = a
+        return out
+
+    @staticmethod
+    def backward(ctx, dY):
+        u, weight, h2, out, mix = ctx.saved_tensors
+        a = ctx.a
+        need = ctx.needs_input_grad
+        dY = dY.contiguous()
+        du, dW, db = gemm_grads(u, weight, dY, dict(mode=0), 1.0 - a, need[0], need[1], need[2])
+        dg1 = _scaled(dY, 1.0 - a) if need[3] else None
+        dh2 = _scaled(dY, a) if need[4] else None
+        dmix = None
+        if need[5]:
+            # dL/da = sum dY * (h2 - g1 - lin) = sum dY * (h2 - out) / (1 - a);  da/dmix = a (1 - a)
+            acc = torch.zeros(1, dtype=torch.float32, device=dY.device)
+            ops.dot_diff(dY, h2, out, acc, scale=a)
+            dmix = acc.to(mix.dtype).reshape(mix.shape)
+        return du, dW, db, dg1, dh2, dmix
+
+
+class SpatialAttention(torch.autograd.Function):
+    """softmax(q k^T / 8) v per (image, head) on qkv rows [n_img * S, 3C] (BasicTransformerBlock.attn1 core)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_img, S, C):
+        out = _rows(qkv.shape[0], C, qkv)
+        lse = torch.empty(n_img, C // 64, S, dtype=torch.float32, device=qkv.device)
+        ops.attention_spatial_lse(qkv, out, lse, n_img, S, C)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (n_img, S, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        n_img, S, C = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        ops.attention_spatial_bwd(qkv, out, dout.contiguous(), lse, dqkv, n_img, S, C)
+        return dqkv, None, None, None
+
+
+class TemporalAttention(torch.autograd.Function):
+    """Attention over the F frames of every (clip, pixel); rows ordered (b, f, s) (TemporalBasicTransformerBlock.attn1)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, F, S, C):
+        out = _rows(qkv.shape[0], C, qkv)
+        ops.attention_temporal(qkv, out, B, F, S, C)
+        ctx.save_for_backward(qkv, out)
+        ctx.cfg = (B, F, S, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out = ctx.saved_tensors
+        B, F, S, C = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        ops.attention_temporal_bwd(qkv, out, dout.contiguous(), dqkv, B, F, S, C)
+        return dqkv, None, None, None, None
+
+
+def sinusoid(t, dim):
+    """diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)` in fp32: [cos | sin]."""
+    half = dim // 2
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    arg = t.float()[:, None] * freq[None]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
+    """Training-mode forward of `ctrlv_amd.models.blocks.TransformerSpatioTemporalModel`: the same kernels and fusion as
+    `tr.run` with every op recording its backward.  x: bf16 rows [B*F*H*W, C]; ehs: fp32 [B, cross_dim] (the single CLIP
+    token per clip).  The tiny per-clip tensors (the two degenerate cross-attention vectors to_out(to_v(ehs)) and the
+    frame positional embedding MLP) are plain fp32 torch ops, so their parameters get gradients through torch autograd;
+    to_q / to_k / norm2 of the cross-attentions receive exactly zero gradient (softmax over one key is constant)."""
+    import torch.nn.functional as Fn
+    sb, tb = tr.transformer_blocks[0], tr.temporal_transformer_blocks[0]
+    N, S, C = B * F, H * W, tr.C
+    if time_context_order == "sb" and B > 1:
+        raise NotImplementedError("training forward: the diffusers-0.27.2 (s, b) time-context order is only wired for one "
+                                  "clip per step (cfg5 trains with batch 1)")
+
+    def xvec(attn):
+        return Fn.linear(Fn.linear(ehs.float(), attn.to_v.weight.float()), attn.to_out[0].weight.float(),
+                         attn.to_out[0].bias.float()).contiguous()
+
+    tpe = tr.time_pos_embed
+    emb = Fn.linear(Fn.silu(Fn.linear(sinusoid(torch.arange(F, device=x.device), C), tpe.linear_1.weight.float(),
+                                      tpe.linear_1.bias.float())), tpe.linear_2.weight.float(),
+                    tpe.linear_2.bias.float()).contiguous()                                   # fp32 [F, C]
+    big = 1 << 30
+
+    def ln(h, n, V=None, vdiv=1, vmod=big):
+        return LayerNormFn.apply(h, n.weight, n.bias, V, vdiv, vmod)
+
+    def qkv_w(attn):
+        return torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0)
+
+    t = GroupNormSiLU.apply(x, tr.norm.weight, tr.norm.bias, N, S, 1, 1e-6, False)
+    h0 = FusedLinear.apply(t, tr.proj_in.weight, tr.proj_in.bias, None, None, None, {})
+    # ---- spatial BasicTransformerBlock
+    qkv = FusedLinear.apply(ln(h0, sb.norm1), qkv_w(sb.attn1), None, None, None, None, {})
+    a = SpatialAttention.apply(qkv, N, S, C)
+    h1 = FusedLinear.apply(a, sb.attn1.to_out[0].weight, sb.attn1.to_out[0].bias, h0, None, xvec(sb.attn2),
+                           dict(vdiv=F * S))
+    u = GegluProj.apply(ln(h1, sb.norm3), sb.ff.net[0].proj.weight, sb.ff.net[0].proj.bias)
+    h2 = FusedLinear.apply(u, sb.ff.net[2].weight, sb.ff.net[2].bias, h1, None, None, {})
+    # ---- temporal block: rows stay ordered (b, f, s); the frame embedding is added inside the consumers
+    u = GegluProj.apply(ln(h2, tb.norm_in, emb, S, F), tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias)
+    g0 = FusedLinear.apply(u, tb.ff_in.net[2].weight, tb.ff_in.net[2].bias, h2, None, emb, dict(vdiv=S, vmod=F))
+    qkv = FusedLinear.apply(ln(g0, tb.norm1), qkv_w(tb.attn1), None, None, None, None, {})
+    a = TemporalAttention.apply(qkv, B, F, S, C)
+    g1 = FusedLinear.apply(a, tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, g0, None, xvec(tb.attn2),
+                           dict(vdiv=F * S))
+    u = GegluProj.apply(ln(g1, tb.norm3), tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
+    h3 = BlendLinear.apply(u, tb.ff.net[2].weight, tb.ff.net[2].bias, g1, h2, tr.time_mixer.mix_factor)
+    return FusedLinear.apply(h3, tr.proj_out.weight, tr.proj_out.bias, x, None, None, {})
+
