@@ -42,7 +42,11 @@ class GatherGemm(torch.autograd.Function):
         mode = geom["mode"]
         N, cin = weight.shape[0], weight.shape[1]
         taps = {0: 1, 1: 9, 2: 3}[mode]
-        out = _rows(A.shape[0], N, A)
+        m_out = A.shape[0]
+        if mode == 1:        # stride-2 / upsample-fused convs change the row count
+            H, W, Ho, Wo = geom["conv"][:4]
+            m_out = A.shape[0] // (H * W) * Ho * Wo
+        out = _rows(m_out, N, A)
         ops.gemm(A, GatherGemm._pack(weight, mode), out, N=(N + 31) // 32 * 32, cin=cin, taps=taps, mode=mode,
                  conv=geom.get("conv"), temporal=geom.get("temporal"),
                  bias=None if bias is None else packing.pad_bias(bias), R1=R1, s_acc=float(s_acc),
@@ -74,16 +78,38 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
     taps = {0: 1, 1: 9, 2: 3}[mode]
     dA = dW = db = None
     if need_dA:
-        # dgrad: the forward kernel with the weight's roles swapped
+        # dgrad: the forward kernel with the weight's roles swapped.  The contraction runs over the forward's OUTPUT
+        # channels: the GEMM needs a multiple of 64 of them (conv_out has 4: zero-padded).
+        npad = (N + 63) // 64 * 64
+        wd, dYd = weight.detach(), dY
+        if npad != N:
+            wd = torch.cat([wd, wd.new_zeros((npad - N,) + tuple(wd.shape[1:]))], 0)
+            dYd = torch.zeros(dY.shape[0], npad, dtype=dY.dtype, device=dY.device)
+            dYd[:, :N] = dY
+        conv = geom.get("conv")
         if mode == 0:
-            wt = packing.pack_linear(weight.detach().reshape(N, cin).t())
+            wt = packing.pack_linear(wd.reshape(npad, cin).t())
         elif mode == 1:
-            wt = packing.pack_conv3x3(weight.detach().flip(2, 3).transpose(0, 1))
+            wt = packing.pack_conv3x3(wd.flip(2, 3).transpose(0, 1))
+            H, W, Ho, Wo, stride, up = conv
+            n_img = dY.shape[0] // (Ho * Wo)
+            if stride == 2:
+                # transposed conv = stride-1 dgrad on the zero-inserted gradient: dYz[2 yo, 2 xo] = dY[yo, xo]
+                z = torch.zeros(n_img, H, W, npad, dtype=dY.dtype, device=dY.device)
+                z[:, 0:2 * Ho:2, 0:2 * Wo:2] = dYd.view(n_img, Ho, Wo, npad)
+                dYd = z.view(n_img * H * W, npad)
+                conv = (H, W, H, W, 1, 0)
+            elif up:
+                conv = (Ho, Wo, Ho, Wo, 1, 0)        # dgrad on the upsampled grid, 2x2 sum-pool below
         else:
-            wt = packing.pack_conv_temporal(weight.detach().flip(2).transpose(0, 1))
-        dA = _rows(A.shape[0], cin, A)
-        ops.gemm(dY, wt, dA, N=(cin + 31) // 32 * 32, cin=N, taps=taps, mode=mode, conv=geom.get("conv"),
+            wt = packing.pack_conv_temporal(wd.flip(2).transpose(0, 1))
+        dA = _rows(dYd.shape[0], cin, A)
+        ops.gemm(dYd, wt, dA, N=(cin + 31) // 32 * 32, cin=npad, taps=taps, mode=mode, conv=conv,
                  temporal=geom.get("temporal"), s_acc=s_acc)
+        if mode == 1 and geom["conv"][5]:
+            H, W = geom["conv"][0], geom["conv"][1]
+            n_img = A.shape[0] // (H * W)
+            dA = dA.view(n_img, H, 2, W, 2, cin).float().sum((2, 4)).to(torch.bfloat16).view(n_img * H * W, cin)
     if need_dW:
         dWp = torch.zeros(N, taps * cin, dtype=torch.float32, device=A.device)
         ops.gemm_wgrad(A, dY, dWp, N=N, cin=cin, taps=taps, mode=mode, conv=geom.get("conv"),

@@ -103,3 +103,39 @@ def test_shard_helpers_single_process():
     import pytest
     with pytest.raises(ValueError):
         D.shard_clips(4, 4, 4)
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ctrlv_amd import distributed as D
+    from ctrlv_amd.training import allreduce_gradients
+    D.init("gloo")
+    g = torch.Generator().manual_seed(7)
+    params = [torch.nn.Parameter(torch.randn(n, generator=g)) for n in (1000, 3, 4096, 17, 2500)]
+    for i, p in enumerate(params):
+        if not (i == 1 and rank == 1):                    # rank 1 has no gradient for parameter 1 (unused branch)
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    n_buckets = allreduce_gradients(params, bucket_bytes=8192)          # 1000 | 3 | 4096 | 17 + 2500 floats ...
+    out.put((rank, n_buckets, [float(p.grad[0]) for p in params], [bool((p.grad == p.grad[0]).all()) for p in params]))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_buckets_over_gloo_world2():
+    """The training step's data-parallel reduction (ctrlv_amd.training.allreduce_gradients; reference: DDP under
+    accelerate, train_video_controlnet.py:225,485): flat fp32 buckets, all launched before the first wait, averaged;
+    a parameter without a gradient on one rank contributes zeros."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_buckets, first, uniform in got:
+        assert n_buckets >= 3 and all(uniform)
+        # mean over ranks of (rank + 1) * (i + 1) = 1.5 * (i + 1); parameter 1: (2 + 0) / 2
+        assert first == [1.5, 1.0, 4.5, 6.0, 7.5]
