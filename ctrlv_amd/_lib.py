@@ -82,8 +82,9 @@ SIGNATURES = {
     "ctrlv_groupnorm_bwd_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctrlv_layernorm_bwd_scratch_floats": (ctypes.c_size_t, [c_int, c_int]),
     "ctrlv_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
-                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctrlv_geglu_bwd": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "ctrlv_plan_create": (c_int, [ctypes.POINTER(ModelConfig), c_int, ctypes.POINTER(c_void_p)]),
     "ctrlv_plan_load_weights": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_size_t]),
@@ -102,7 +103,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CtrlvHipError(RuntimeError):

@@ -60,73 +60,147 @@ __device__ __forceinline__ long wgrad_src(const WgradArgs& a, int m, int tap) {
   return ((long)n_img * a.H + yi) * a.Wd + xi;
 }
 
-// grid (ceil(N/64), Ktot/64, slabs); 256 threads; output tile 64 (n) x 64 (k), one 32x32 MFMA accumulator per wave
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(1024))) char ty[4096];   // dY rows [32][64 n]
-  __shared__ __attribute__((aligned(1024))) char ta[4096];   // A  rows [32][64 k]
+// grid (ceil(N/128), ceil(Ktot/256), slabs); 256 threads = 2 (n) x 2 (k) waves; output tile 128 (n) x 256 (k), a wave owns
+// 64 x 128 = 2 x 4 MFMA accumulators (6 transposed fragment reads per 8 MFMAs).  Rows advance in chunks of 64: the
+// next chunk's global loads (4 dY + 8 A pieces of 16 B per thread) are issued into registers before the current chunk
+// is consumed from LDS.  LDS: dY as 2 panels, A as 4 panels of [64 rows][64 columns] (the tr-read layout of tr_off);
+// every 64-column K panel lies inside one tap (Cin % 64 == 0), so the tap / channel offset is a per-thread constant.
+// (The first version -- 64 x 64 tile, one accumulator per wave, no prefetch -- ran at ~10 % of the MFMA peak and was
+// 12.6 % of the cfg5 training step.)
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) char ty[2 * 8192];   // dY rows: 2 panels [64][64 n]
+  __shared__ __attribute__((aligned(1024))) char ta[4 * 8192];   // A  rows: 4 panels [64][64 k]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;        // Cin % 64 == 0: a 64-wide K tile lies inside one tap
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 256;
+  const long ktot = (long)a.taps * a.Cin;
   const int m_lo = blockIdx.z * a.rows_per_slab;
   const int m_hi = min(a.M, m_lo + a.rows_per_slab);
-  const int r = tid >> 3, ch = tid & 7;                      // this thread stages row r, 16-byte chunk ch of both tiles
   const int nh = wid & 1, kh = wid >> 1;
-  f32x16 acc;
+  // staging roles: dY piece i of this thread = row (tid >> 4) + 16 i, 16-B chunk (tid & 15) of 16;
+  //                A  piece i                = row (tid >> 5) +  8 i, 16-B chunk (tid & 31) of 32
+  const int yr = tid >> 4, yc = tid & 15, ar = tid >> 5, ac = tid & 31;
+  const int ycol = n0 + yc * 8;
+  const bool y_ok = ycol < a.N;
+  const int kcol = k0 + ac * 8;                              // global K column of this thread's A pieces
+  const bool a_ok = kcol < ktot;
+  const int tap = a_ok ? kcol / a.Cin : 0, c = kcol - tap * a.Cin;
+  const bool second = a.A2 != nullptr && c >= a.c_split;
+  const bf16_t* abase = second ? a.A2 + (c - a.c_split) : a.A + c;
+  const long ald = second ? a.lda2 : a.lda;
+  auto sw = [](int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) * 16); };
+  uint4 vy[4], va[8];
+  auto load = [&](int m0) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const int sw_off = r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) * 16);
-  for (int m0 = m_lo; m0 < m_hi; m0 += 32) {
-    const int m = m0 + r;
-    uint4 vy = make_uint4(0, 0, 0, 0), va = make_uint4(0, 0, 0, 0);
-    if (m < m_hi) {
-      if (n0 + ch * 8 < a.N) vy = *(const uint4*)(a.dY + (long)m * a.ldy + n0 + ch * 8);
-      const long src = wgrad_src(a, m, tap);
-      if (src >= 0) {
-        const int c = c0 + ch * 8;
-        va = (a.A2 != nullptr && c >= a.c_split) ? *(const uint4*)(a.A2 + src * a.lda2 + (c - a.c_split))
-                                                 : *(const uint4*)(a.A + src * a.lda + c);
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + yr + 16 * i;
+      vy[i] = (y_ok && m < m_hi) ? *(const uint4*)(a.dY + (long)m * a.ldy + ycol) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + ar + 8 * i;
+      va[i] = make_uint4(0, 0, 0, 0);
+      if (a_ok && m < m_hi) {
+        const long src = wgrad_src(a, m, tap);
+        if (src >= 0) va[i] = *(const uint4*)(abase + src * ald);
       }
     }
-    __syncthreads();                                         // previous chunk's fragment reads are done
-    *(uint4*)(ty + sw_off) = vy;
-    *(uint4*)(ta + sw_off) = va;
-    __syncthreads();
+  };
+  f32x16 acc[2][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 fy = tr_frag(ty, 16 * s, 32 * nh, lane);  // A operand: i = n
-      const bf16x8 fa = tr_frag(ta, 16 * s, 32 * kh, lane);  // B operand: j = k
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fa, acc, 0, 0, 0);
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  load(m_lo);
+  for (int m0 = m_lo; m0 < m_hi; m0 += 64) {
+    __syncthreads();                                         // previous chunk's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(uint4*)(ty + (yc >> 3) * 8192 + sw(yr + 16 * i, yc & 7)) = vy[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(uint4*)(ta + (ac >> 3) * 8192 + sw(ar + 8 * i, ac & 7)) = va[i];
+    __syncthreads();
+    if (m0 + 64 < m_hi) load(m0 + 64);                       // in flight while this chunk is consumed
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fy[2], fa[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fy[i] = tr_frag(ty + nh * 8192, 16 * s, 32 * i, lane);          // A operand: i = n
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fa[j] = tr_frag(ta + (kh * 2 + (j >> 1)) * 8192, 16 * s, 32 * (j & 1), lane);   // B: j = k
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fa[j], acc[i][j], 0, 0, 0);
     }
   }
   // D[i][j]: lane holds column j = lane % 32, rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane / 32)
-  const int j = k0 + 32 * kh + (lane & 31);
-  const long ktot = (long)a.taps * a.Cin;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int n = n0 + 32 * nh + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-    if (n < a.N) atomicAdd(a.dW + (long)n * ktot + j, acc[e]);
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long k = (long)k0 + 128 * kh + 32 * j + (lane & 31);
+      if (k >= ktot) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (n < a.N) atomicAdd(a.dW + (long)n * ktot + k, acc[i][j][e]);
+      }
+    }
 }
 
 // out[idx(m)][n] += sum over this block's rows of x[m][n];  idx(m) = vmode ? (m / vdiv) % vmod : 0
+// 64 column groups of 8 (16-B loads) x 4 row lanes per workgroup; the row lanes are folded through LDS so that a
+// workgroup issues ONE atomic per column (same-address float atomics execute serially at the memory side: the first
+// version -- one column per thread, 2-B loads, an atomic per 256 rows -- cost 124 us per call on average).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int M, int N, int ldx, int rows_per_block,
                                                      int vmode, int vdiv, int vmod, float scale, float* __restrict__ out,
                                                      int ldo) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[4][64][8];
+  __shared__ int red_idx[4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 64 + tx) * 8;
   const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
-  if (n >= N) return;
-  float acc = 0.f;
+  const bool col_ok = n0 < N;                       // (N % 8 == 0)
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int cur = -1;
-  for (int m = m_lo; m < m_hi; ++m) {
+  auto flush = [&](int idx) {
+    if (idx >= 0 && col_ok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(out + (long)idx * ldo + n0 + e, acc[e] * scale);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  };
+  for (int m = m_lo + ty; m < m_hi; m += 4) {
     const int idx = vmode ? (m / vdiv) % vmod : 0;
     if (idx != cur) {
-      if (cur >= 0) atomicAdd(out + (long)cur * ldo + n, acc * scale);
+      flush(cur);
       cur = idx;
-      acc = 0.f;
     }
-    acc += bf16_to_f32(x[(long)m * ldx + n]);
+    if (col_ok) {
+      float f[8];
+      unpack_bf16x8(*(const uint4*)(x + (long)m * ldx + n0), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
   }
-  if (cur >= 0) atomicAdd(out + (long)cur * ldo + n, acc * scale);
+  // fold the four row lanes when they ended in the same table row (always, unless a row-group boundary fell inside the
+  // last four rows of this block); otherwise every lane flushes its own tail
+  if (tx == 0) red_idx[ty] = cur;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
+  __syncthreads();
+  const bool same = red_idx[0] == red_idx[1] && red_idx[1] == red_idx[2] && red_idx[2] == red_idx[3];
+  if (same) {
+    if (ty == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+      flush(cur);
+    }
+  } else {
+    flush(cur);
+  }
 }
 
 // out[0] += scale * sum_i dy[i] * (p[i] - q[i])      (gradient of a folded AlphaBlender's mixing weight)
@@ -209,43 +283,56 @@ __global__ void gn_bwd_partial_kernel(const bf16_t* __restrict__ x, const bf16_t
   }
 }
 
-// pass 2a: per (statistics row, group): m1 = mean(dz * gamma), m2 = mean(dz * gamma * xhat)    grid n_stat, 256 threads
+// pass 2a: per (statistics row, group): m1 = mean(dz * gamma), m2 = mean(dz * gamma * xhat)    grid (32, n_stat), 256 threads
+// (one workgroup per (row, GROUP): the 5-D norms of a one-clip batch have a single statistics row, and one workgroup
+// walking all of its partials serially took up to 0.45 ms)
 __global__ __launch_bounds__(256) void gn_bwd_group_kernel(GnB s, const float* __restrict__ part,
                                                            const float* __restrict__ gamma, float* __restrict__ gmean) {
-  __shared__ double dred[8][32][2];
-  const int tid = threadIdx.x, stat = blockIdx.x, g = tid & 31, sl = tid >> 5, cpg = s.C / 32;
+  __shared__ double dred[256][2];
+  const int tid = threadIdx.x, g = blockIdx.x, stat = blockIdx.y, cpg = s.C / 32;
   const int tot = s.ips * s.n_chunks;              // (image, chunk) pairs of this statistics row, contiguous in `part`
   double a1 = 0.0, a2 = 0.0;
-  for (int k = sl; k < tot; k += 8)
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      const float* p = part + (((long)stat * tot + k) * s.C + c) * 2;
-      a1 += (double)gamma[c] * (double)p[1];
-      a2 += (double)gamma[c] * (double)p[0];
-    }
-  dred[sl][g][0] = a1;
-  dred[sl][g][1] = a2;
+  for (int i = tid; i < tot * cpg; i += 256) {
+    const int k = i / cpg, c = g * cpg + i % cpg;
+    const float2 p = *(const float2*)(part + (((long)stat * tot + k) * s.C + c) * 2);
+    a1 += (double)gamma[c] * (double)p.y;
+    a2 += (double)gamma[c] * (double)p.x;
+  }
+  dred[tid][0] = a1;
+  dred[tid][1] = a2;
   __syncthreads();
-  if (tid < 32) {
-    a1 = a2 = 0.0;
-    for (int k = 0; k < 8; ++k) { a1 += dred[k][tid][0]; a2 += dred[k][tid][1]; }
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { dred[tid][0] += dred[tid + o][0]; dred[tid][1] += dred[tid + o][1]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
     const double cnt = (double)cpg * s.S * s.ips;
-    gmean[((long)stat * 32 + tid) * 2] = (float)(a1 / cnt);
-    gmean[((long)stat * 32 + tid) * 2 + 1] = (float)(a2 / cnt);
+    gmean[((long)stat * 32 + g) * 2] = (float)(dred[0][0] / cnt);
+    gmean[((long)stat * 32 + g) * 2 + 1] = (float)(dred[0][1] / cnt);
   }
 }
-// pass 2b: dgamma[c] += sum s1, dbeta[c] += sum s2 over every (image, chunk)               grid ceil(C/256)
+// pass 2b: dgamma[c] += sum s1, dbeta[c] += sum s2 over every (image, chunk): 64 channels x 4 row lanes per workgroup,
+// gridDim.y row groups, one atomic per channel per workgroup            grid (ceil(C/64), <= 16)
 __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnB s, const float* __restrict__ part, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= s.C) return;
-  double a1 = 0.0, a2 = 0.0;
+  __shared__ float red[4][64][2];
+  const int tx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a1 = 0.f, a2 = 0.f;
   const long tot = (long)s.n_img * s.n_chunks;
-  for (long k = 0; k < tot; ++k) {
-    a1 += (double)part[(k * s.C + c) * 2];
-    a2 += (double)part[(k * s.C + c) * 2 + 1];
+  if (c < s.C)
+    for (long k = blockIdx.y * 4 + rl; k < tot; k += gridDim.y * 4) {
+      const float2 p = *(const float2*)(part + (k * s.C + c) * 2);
+      a1 += p.x;
+      a2 += p.y;
+    }
+  red[rl][tx][0] = a1;
+  red[rl][tx][1] = a2;
+  __syncthreads();
+  if (rl == 0 && c < s.C) {
+    atomicAdd(dgamma + c, red[0][tx][0] + red[1][tx][0] + red[2][tx][0] + red[3][tx][0]);
+    atomicAdd(dbeta + c, red[0][tx][1] + red[1][tx][1] + red[2][tx][1] + red[3][tx][1]);
   }
-  dgamma[c] += (float)a1;
-  dbeta[c] += (float)a2;
 }
 // pass 3: dx = rstd * (dz * gamma - m1 - xhat * m2)
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, GnB s,
@@ -285,12 +372,14 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // One wave per row (grid-stride), 8 * NV columns per lane like the forward.  Recomputes mean / rstd of x (+ V row), then
 //   dz = dy * gamma;  dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat));  dgamma += dy * xhat;  dbeta += dy
-// (dgamma / dbeta: per-lane column partials over the wave's rows, one atomic per column per wave at the end).
+// dgamma / dbeta: per-lane column partials over the wave's rows go to a scratch row per wave ([waves][2C] fp32) and
+// ln_bwd_reduce_kernel folds the rows with 16 atomics per column.  (One atomic per column PER WAVE -- 4096 same-address
+// memory-side atomics per column -- made this kernel 10x slower than its HBM traffic: 0.93 ms at C = 320, M = 230 k.)
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int M, int C,
                                                      const float* __restrict__ gamma, float eps, const float* __restrict__ V,
                                                      int vdiv, int vmod, int ldv, bf16_t* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                     float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int CV = C >> 3;
   float g[NV][8], ag[NV][8], ab[NV][8];
@@ -360,16 +449,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
+  float* prow = part + ((long)blockIdx.x * 4 + wid) * (2L * C);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int cv = lane + k * 64;
     if (cv < CV) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(dgamma + cv * 8 + e, ag[k][e]);
-        atomicAdd(dbeta + cv * 8 + e, ab[k][e]);
-      }
+      *(float4*)(prow + cv * 8) = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
+      *(float4*)(prow + cv * 8 + 4) = make_float4(ag[k][4], ag[k][5], ag[k][6], ag[k][7]);
+      *(float4*)(prow + C + cv * 8) = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+      *(float4*)(prow + C + cv * 8 + 4) = make_float4(ab[k][4], ab[k][5], ab[k][6], ab[k][7]);
     }
+  }
+}
+
+// out0[c] += sum_r part[r][c], out1[c] += sum_r part[r][C + c]: 64 columns x 4 row lanes per workgroup, gridDim.y row groups
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int rows, int C,
+                                                            float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < 2 * C)
+    for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += part[(long)r * (2L * C) + col];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < 2 * C) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(col < C ? out0 + col : out1 + (col - C), s);
   }
 }
 
@@ -404,19 +509,24 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+static long ln_bwd_blocks(int M) {
+  long blocks = ((long)M + 3) / 4;
+  return blocks > 256 * 4 ? 256 * 4 : blocks;
+}
+extern "C" size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C) { return (size_t)ln_bwd_blocks(M) * 4 * 2 * (size_t)C; }
+
 extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V,
-                                   int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta,
+                                   int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch,
                                    ctrlv_stream_t stream) {
-  CTRLV_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  CTRLV_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && scratch, "layernorm_bwd: null pointer");
   CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm_bwd: C=%d must be a multiple of 8, <= 2048", C);
   if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm_bwd: bad row-vector table");
   const int nv = (C / 8 + 63) / 64;
-  long blocks = ((long)M + 3) / 4;
-  if (blocks > 256 * 4) blocks = 256 * 4;
+  const long blocks = ln_bwd_blocks(M);
   hipStream_t st = (hipStream_t)stream;
 #define LNB_LAUNCH(NV)                                                                                                  \
   hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, M, C, \
-                     gamma, eps, V, vdiv, vmod, ldv, (bf16_t*)dx, dgamma, dbeta)
+                     gamma, eps, V, vdiv, vmod, ldv, (bf16_t*)dx, scratch)
   switch (nv) {
     case 1: LNB_LAUNCH(1); break;
     case 2: LNB_LAUNCH(2); break;
@@ -424,6 +534,10 @@ extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, 
     default: LNB_LAUNCH(4); break;
   }
 #undef LNB_LAUNCH
+  CTRLV_LAUNCH_CHECK();
+  const int rows = (int)blocks * 4;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64, rows >= 64 ? 16 : 1), dim3(256), 0, st, scratch, rows, C,
+                     dgamma, dbeta);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -453,12 +567,12 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   a.M = d.M; a.N = d.N; a.Cin = d.Cin; a.taps = d.taps; a.lda = d.lda; a.lda2 = d.lda2; a.c_split = d.c_split; a.ldy = ldy;
   a.mode = d.mode; a.H = d.H; a.Wd = d.Wd; a.Ho = d.Ho; a.Wo = d.Wo; a.stride = d.stride ? d.stride : 1; a.up = d.up;
   a.F = d.F; a.S = d.S;
-  const int ktiles = d.taps * d.Cin / 64, ntiles = (d.N + 63) / 64;
-  // enough M slabs to fill the chip (~1024 workgroups), each a multiple of 32 rows
-  int slabs = 1024 / (ktiles * ntiles);
+  const int ktiles = (d.taps * d.Cin + 255) / 256, ntiles = (d.N + 127) / 128;
+  // enough M slabs to fill the chip (two workgroups per CU), each a multiple of 64 rows
+  int slabs = 512 / (ktiles * ntiles);
   if (slabs < 1) slabs = 1;
-  int rps = ((d.M + slabs - 1) / slabs + 31) / 32 * 32;
-  if (rps < 32) rps = 32;
+  int rps = ((d.M + slabs - 1) / slabs + 63) / 64 * 64;
+  if (rps < 64) rps = 64;
   slabs = (d.M + rps - 1) / rps;
   a.rows_per_slab = rps;
   CTRLV_CHECK_SHAPE(slabs <= 65535 && ktiles <= 65535, "gemm_wgrad: grid too large");
@@ -470,10 +584,10 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
 extern "C" int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out,
                             int ldo, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && out, "colsum: null pointer");
-  CTRLV_CHECK_SHAPE(M > 0 && N > 0 && ldx >= N, "colsum: bad shape");
+  CTRLV_CHECK_SHAPE(M > 0 && N > 0 && N % 8 == 0 && ldx >= N && ldx % 8 == 0, "colsum: N and ldx must be multiples of 8");
   CTRLV_CHECK_ARG(vmode == 0 || (vmode == 1 && vdiv > 0 && vmod > 0), "colsum: vmode must be 0 or 1 with vdiv, vmod > 0");
-  const int rpb = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+  const int rpb = M >= (1 << 18) ? 1024 : (M >= (1 << 14) ? 256 : 64);      // >= ~225 workgroups per 512 columns at L0
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, M, N, ldx, rpb, vmode, vdiv, vmod, scale, out, ldo);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
@@ -517,9 +631,12 @@ extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks, n_img), dim3(nt), (size_t)RPP * C * 2 * sizeof(float), st,
                      (const bf16_t*)x, (const bf16_t*)dy, s, stats, gamma, beta, silu, part);
   CTRLV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(n_img / imgs_per_stat), dim3(256), 0, st, s, part, gamma, gmean);
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(32, n_img / imgs_per_stat), dim3(256), 0, st, s, part, gamma, gmean);
   CTRLV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, s, part, dgamma, dbeta);
+  {
+    const long tot = (long)n_img * s.n_chunks;
+    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 63) / 64, tot >= 64 ? 16 : 1), dim3(256), 0, st, s, part, dgamma, dbeta);
+  }
   CTRLV_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, n_img), dim3(nt), 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, stats,
                      gmean, gamma, beta, silu, (bf16_t*)dx);

@@ -70,9 +70,11 @@ def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, 
 def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 << 30):
     _need_gpu(x, "x")
     M, C = x.shape
-    check(_lib.load().ctrlv_layernorm_bwd(_p(x), _p(dy), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
-                                          V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _stream()),
-          "ctrlv_layernorm_bwd")
+    lib = _lib.load()
+    scratch = torch.empty(lib.ctrlv_layernorm_bwd_scratch_floats(M, C), dtype=torch.float32, device=x.device)
+    check(lib.ctrlv_layernorm_bwd(_p(x), _p(dy), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
+                                  V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch),
+                                  _stream()), "ctrlv_layernorm_bwd")
     return dx
 
 

@@ -188,9 +188,11 @@ int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, 
                         float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
 
 /* LayerNorm backward over [M, C] rows (optionally of x + V[(m / vdiv) % vmod], as the forward): dx bf16; dgamma / dbeta
- * fp32 [C], ACCUMULATED (atomics).  The gradient of V's rows is ctrlv_colsum(dx, vmode 1). */
+ * fp32 [C], ACCUMULATED; scratch = ctrlv_layernorm_bwd_scratch_floats(M, C) floats (per-wave column partials, folded by a
+ * second kernel).  The gradient of V's rows is ctrlv_colsum(dx, vmode 1). */
+size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C);
 int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V, int vdiv,
-                        int vmod, int ldv, void* dx, float* dgamma, float* dbeta, ctrlv_stream_t stream);
+                        int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
 /* GEGLU backward.  raw: the projection output [M, 2I] bf16 in the packed (16 value, 16 gate) column-block order, i.e.
  * ctrlv_gemm on the GEGLU-packed weight with geglu = 0; du: [M, I] bf16; draw: [M, 2I] bf16, same layout as raw. */
 int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I, void* draw, ctrlv_stream_t stream);
