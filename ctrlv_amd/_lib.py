@@ -76,7 +76,7 @@ SIGNATURES = {
     "ctrlv_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                      c_float, c_void_p, c_void_p]),
-    "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p]),
+    "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "ctrlv_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "ctrlv_dot_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "ctrlv_groupnorm_bwd_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
@@ -103,7 +103,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CtrlvHipError(RuntimeError):

@@ -25,6 +25,24 @@ def _rows(M, C, like):
     return torch.empty(M, C, dtype=torch.bfloat16, device=like.device)
 
 
+# Packed (bf16, kernel-layout) forms of FROZEN parameters are built once: the UNet of the training step never changes,
+# and re-packing its decoder (forward form + role-swapped dgrad form) every step is ~10 ms of small torch kernels.
+# Trainable parameters are packed from the fp32 masters on every use.
+_PACK_CACHE = {}
+
+
+def _packed(weight, kind, fn):
+    if weight.requires_grad or not isinstance(weight, torch.nn.Parameter):     # (temporaries may recycle a data_ptr)
+        return fn(weight)
+    key = (weight.data_ptr(), weight._version, kind, tuple(weight.shape), weight.dtype)
+    hit = _PACK_CACHE.get(key)
+    if hit is None:
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        hit = _PACK_CACHE[key] = fn(weight)
+    return hit
+
+
 class GatherGemm(torch.autograd.Function):
     """out = s_acc * (gather-GEMM(A, weight) + bias) + R1 + V[(m // vdiv)]   (what the res block's convs fuse).
 
@@ -33,9 +51,8 @@ class GatherGemm(torch.autograd.Function):
 
     @staticmethod
     def _pack(weight, mode):
-        if mode == 0:
-            return packing.pack_linear(weight)
-        return packing.pack_conv3x3(weight) if mode == 1 else packing.pack_conv_temporal(weight)
+        fn = packing.pack_linear if mode == 0 else (packing.pack_conv3x3 if mode == 1 else packing.pack_conv_temporal)
+        return _packed(weight, ("fwd", mode), fn)
 
     @staticmethod
     def forward(ctx, A, weight, bias, R1, V, s_acc, geom):
@@ -87,10 +104,16 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
             dYd = torch.zeros(dY.shape[0], npad, dtype=dY.dtype, device=dY.device)
             dYd[:, :N] = dY
         conv = geom.get("conv")
-        if mode == 0:
-            wt = packing.pack_linear(wd.reshape(npad, cin).t())
-        elif mode == 1:
-            wt = packing.pack_conv3x3(wd.flip(2, 3).transpose(0, 1))
+
+        def swapped(_):
+            if mode == 0:
+                return packing.pack_linear(wd.reshape(npad, cin).t())
+            if mode == 1:
+                return packing.pack_conv3x3(wd.flip(2, 3).transpose(0, 1))
+            return packing.pack_conv_temporal(wd.flip(2).transpose(0, 1))
+
+        wt = _packed(weight, ("dgrad", mode), swapped)
+        if mode == 1:
             H, W, Ho, Wo, stride, up = conv
             n_img = dY.shape[0] // (Ho * Wo)
             if stride == 2:
@@ -101,8 +124,6 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
                 conv = (H, W, H, W, 1, 0)
             elif up:
                 conv = (Ho, Wo, Ho, Wo, 1, 0)        # dgrad on the upsampled grid, 2x2 sum-pool below
-        else:
-            wt = packing.pack_conv_temporal(wd.flip(2).transpose(0, 1))
         dA = _rows(dYd.shape[0], cin, A)
         ops.gemm(dYd, wt, dA, N=(cin + 31) // 32 * 32, cin=npad, taps=taps, mode=mode, conv=conv,
                  temporal=geom.get("temporal"), s_acc=s_acc)
@@ -111,17 +132,21 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
             n_img = A.shape[0] // (H * W)
             dA = dA.view(n_img, H, 2, W, 2, cin).float().sum((2, 4)).to(torch.bfloat16).view(n_img * H * W, cin)
     if need_dW:
+        # one kernel: dW (scaled by s_acc) and, riding along in the workgroups that stream dY anyway, the bias gradient
         dWp = torch.zeros(N, taps * cin, dtype=torch.float32, device=A.device)
+        dbp = torch.zeros(N, dtype=torch.float32, device=A.device) if need_db else None
         ops.gemm_wgrad(A, dY, dWp, N=N, cin=cin, taps=taps, mode=mode, conv=geom.get("conv"),
-                       temporal=geom.get("temporal"))
+                       temporal=geom.get("temporal"), dbias=dbp, scale=s_acc)
         if mode == 0:
             dW = dWp.reshape(weight.shape)
         elif mode == 1:
             dW = dWp.reshape(N, 3, 3, cin).permute(0, 3, 1, 2)
         else:
             dW = dWp.reshape(N, 3, cin).permute(0, 2, 1).reshape(N, cin, 3, 1, 1)
-        dW = (dW * s_acc).to(weight.dtype)
-    if need_db:
+        dW = dW.to(weight.dtype)
+        if need_db:
+            db = dbp.to(weight.dtype)
+    elif need_db:
         db = torch.zeros(N, dtype=torch.float32, device=A.device)
         ops.colsum(dY, db, scale=s_acc)
         db = db.to(weight.dtype)
@@ -296,7 +321,7 @@ class FusedLinear(torch.autograd.Function):
         vdiv, vmod = cfg.get("vdiv", 1), cfg.get("vmod", 1 << 30)
         N, cin = weight.shape
         out = _rows(A.shape[0], N, A)
-        ops.gemm(A, packing.pack_linear(weight), out, N=(N + 31) // 32 * 32, cin=cin,
+        ops.gemm(A, _packed(weight, ("fwd", 0), packing.pack_linear), out, N=(N + 31) // 32 * 32, cin=cin,
                  bias=None if bias is None else packing.pad_bias(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
                  V=V, vmode=1 if V is not None else 0, vdiv=vdiv, vmod=vmod)
         ctx.save_for_backward(A, weight)

@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int 
 }
 
 struct WgradArgs {
-  const bf16_t* A; const bf16_t* A2; const bf16_t* dY; float* dW;
+  const bf16_t* A; const bf16_t* A2; const bf16_t* dY; float* dW; float* dbias; float scale;
   int M, N, Cin, taps, lda, lda2, c_split, ldy, mode, H, Wd, Ho, Wo, stride, up, F, S, rows_per_slab;
 };
 
@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const bf16_t* abase = second ? a.A2 + (c - a.c_split) : a.A + c;
   const long ald = second ? a.lda2 : a.lda;
   auto sw = [](int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) * 16); };
+  // bias gradient (column sums of dY) rides along in the workgroups of the first K tile: they stream dY anyway
+  const bool do_bias = a.dbias != nullptr && blockIdx.y == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint4 vy[4], va[8];
   auto load = [&](int m0) {
 #pragma unroll
@@ -117,6 +120,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __syncthreads();                                         // previous chunk's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(uint4*)(ty + (yc >> 3) * 8192 + sw(yr + 16 * i, yc & 7)) = vy[i];
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack_bf16x8(vy[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) *(uint4*)(ta + (ac >> 3) * 8192 + sw(ar + 8 * i, ac & 7)) = va[i];
     __syncthreads();
@@ -144,9 +156,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (n < a.N) atomicAdd(a.dW + (long)n * ktot + k, acc[i][j][e]);
+        if (n < a.N) atomicAdd(a.dW + (long)n * ktot + k, acc[i][j][e] * a.scale);
       }
     }
+  if (do_bias) {                                             // fold the 16 row-threads of every column group through LDS
+    __syncthreads();
+    float* red = (float*)ta;                                 // [16 row threads][128 columns]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[yr * 128 + yc * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < a.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+      atomicAdd(a.dbias + n0 + tid, t * a.scale);
+    }
+  }
 }
 
 // out[idx(m)][n] += sum over this block's rows of x[m][n];  idx(m) = vmode ? (m / vdiv) % vmod : 0
@@ -553,7 +578,8 @@ extern "C" int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I,
   return CTRLV_OK;
 }
 
-extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, ctrlv_stream_t stream) {
+extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, float* dbias, float scale,
+                                ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dp && dY && dW, "gemm_wgrad: null pointer");
   const ctrlv_gemm_desc& d = *dp;
   CTRLV_CHECK_ARG(d.A != nullptr, "gemm_wgrad: A must be non-null");
@@ -563,7 +589,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
                     "gemm_wgrad: mode / taps mismatch");
   if (d.A2) CTRLV_CHECK_SHAPE(d.c_split % 64 == 0 && d.lda2 % 8 == 0, "gemm_wgrad: bad concat split");
   WgradArgs a;
-  a.A = (const bf16_t*)d.A; a.A2 = (const bf16_t*)d.A2; a.dY = (const bf16_t*)dY; a.dW = dW;
+  a.A = (const bf16_t*)d.A; a.A2 = (const bf16_t*)d.A2; a.dY = (const bf16_t*)dY; a.dW = dW; a.dbias = dbias; a.scale = scale;
   a.M = d.M; a.N = d.N; a.Cin = d.Cin; a.taps = d.taps; a.lda = d.lda; a.lda2 = d.lda2; a.c_split = d.c_split; a.ldy = ldy;
   a.mode = d.mode; a.H = d.H; a.Wd = d.Wd; a.Ho = d.Ho; a.Wo = d.Wo; a.stride = d.stride ? d.stride : 1; a.up = d.up;
   a.F = d.F; a.S = d.S;

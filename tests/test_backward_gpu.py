@@ -46,8 +46,10 @@ def ops(hip_lib):
 def test_wgrad_linear_and_colsum(ops, M, N, K):
     A, dY = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(M, N, generator=g(2)))
     dW = torch.zeros(N, K, dtype=torch.float32, device=DEV)
-    ops.gemm_wgrad(A.to(DEV), dY.to(DEV), dW, N=N, cin=K)
-    assert parity_err(dW, dY.float().T @ A.float(), "linear wgrad") < 2e-3
+    dbf = torch.zeros(N, dtype=torch.float32, device=DEV)
+    ops.gemm_wgrad(A.to(DEV), dY.to(DEV), dW, N=N, cin=K, dbias=dbf, scale=0.75)      # fused bias gradient + scale
+    assert parity_err(dW, 0.75 * dY.float().T @ A.float(), "linear wgrad") < 2e-3
+    assert parity_err(dbf, 0.75 * dY.float().sum(0), "fused bias grad") < 2e-3
     db = torch.zeros(N, dtype=torch.float32, device=DEV)
     ops.colsum(dY.to(DEV), db, scale=0.5)
     assert parity_err(db, 0.5 * dY.float().sum(0), "bias grad") < 2e-3

@@ -72,7 +72,7 @@ def main():
         wall = (time.time() - t0) * 1e3
         if i >= args.warmup:
             times.append((wall, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])))
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         del down, mid, pred, loss
     n = len(times)
     avg = [sum(t[k] for t in times) / n for k in range(4)]
