@@ -319,20 +319,21 @@ class FusedLinear(torch.autograd.Function):
     def forward(ctx, A, weight, bias, R1, R2, V, cfg):
         s_acc, s1, s2 = float(cfg.get("s_acc", 1.0)), float(cfg.get("s1", 1.0)), float(cfg.get("s2", 1.0))
         vdiv, vmod = cfg.get("vdiv", 1), cfg.get("vmod", 1 << 30)
+        vmode, vS = (cfg.get("vmode", 1), cfg.get("vS", 1)) if V is not None else (0, 1)
         N, cin = weight.shape
         out = _rows(A.shape[0], N, A)
         ops.gemm(A, _packed(weight, ("fwd", 0), packing.pack_linear), out, N=(N + 31) // 32 * 32, cin=cin,
                  bias=None if bias is None else packing.pad_bias(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
-                 V=V, vmode=1 if V is not None else 0, vdiv=vdiv, vmod=vmod)
+                 V=V, vmode=vmode, vdiv=vdiv, vmod=vmod, vS=vS)
         ctx.save_for_backward(A, weight)
         ctx.cfg = (s_acc, s1, s2, vdiv, vmod, bias is not None, R1 is not None, R2 is not None,
-                   None if V is None else tuple(V.shape))
+                   None if V is None else tuple(V.shape), vmode, vS)
         return out
 
     @staticmethod
     def backward(ctx, dY):
         A, weight = ctx.saved_tensors
-        s_acc, s1, s2, vdiv, vmod, has_b, has_r1, has_r2, vshape = ctx.cfg
+        s_acc, s1, s2, vdiv, vmod, has_b, has_r1, has_r2, vshape, vmode, vS = ctx.cfg
         need = ctx.needs_input_grad
         dY = dY.contiguous()
         dA, dW, db = gemm_grads(A, weight, dY, dict(mode=0), s_acc, need[0], need[1], has_b and need[2])
@@ -341,7 +342,15 @@ class FusedLinear(torch.autograd.Function):
         dV = None
         if vshape is not None and need[5]:
             dV = torch.zeros(vshape, dtype=torch.float32, device=A.device)
-            ops.colsum(dY, dV, vmode=1, vdiv=vdiv, vmod=min(vmod, vshape[0]))
+            if vmode == 1:
+                ops.colsum(dY, dV, vmode=1, vdiv=vdiv, vmod=min(vmod, vshape[0]))
+            else:
+                # vidx = ((m // vdiv) * vS + m % vS) % vmod (the diffusers-0.27.2 (s, b) context order): with vS and
+                # vdiv multiples of vmod this is m % vmod -- table row j collects every vmod-th row starting at j
+                if vS % vmod or vdiv % vmod:
+                    raise NotImplementedError("row-vector gradient for vmode 2 needs vS and vdiv to be multiples of vmod")
+                for j in range(vmod):
+                    ops.colsum(dY[j::vmod], dV[j:j + 1])
         return dA, dW, db, dR1, dR2, dV, None
 
 
@@ -436,9 +445,7 @@ def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
     import torch.nn.functional as Fn
     sb, tb = tr.transformer_blocks[0], tr.temporal_transformer_blocks[0]
     N, S, C = B * F, H * W, tr.C
-    if time_context_order == "sb" and B > 1:
-        raise NotImplementedError("training forward: the diffusers-0.27.2 (s, b) time-context order is only wired for one "
-                                  "clip per step (cfg5 trains with batch 1)")
+    quirk = time_context_order == "sb" and B > 1       # diffusers 0.27.2: time_context rows (s, b), tokens (b, s) -- H1
 
     def xvec(attn):
         return Fn.linear(Fn.linear(ehs.float(), attn.to_v.weight.float()), attn.to_out[0].weight.float(),
@@ -471,7 +478,7 @@ def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
     qkv = FusedLinear.apply(ln(g0, tb.norm1), qkv_w(tb.attn1), None, None, None, None, {})
     a = TemporalAttention.apply(qkv, B, F, S, C)
     g1 = FusedLinear.apply(a, tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, g0, None, xvec(tb.attn2),
-                           dict(vdiv=F * S))
+                           dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if quirk else dict(vdiv=F * S))
     u = GegluProj.apply(ln(g1, tb.norm3), tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
     h3 = BlendLinear.apply(u, tb.ff.net[2].weight, tb.ff.net[2].bias, g1, h2, tr.time_mixer.mix_factor)
     return FusedLinear.apply(h3, tr.proj_out.weight, tr.proj_out.bias, x, None, None, {})

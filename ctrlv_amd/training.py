@@ -7,8 +7,9 @@
 
 Everything activation-sized runs in the kernels of libctrlv_hip.so through ctrlv_amd.autograd; the per-clip vectors (time
 and added-id embeddings, time_emb_proj, the one-key cross-attention vectors, the frame positional embedding MLP) are
-plain fp32 torch ops on [B, 1280]-sized tensors.  Multi-GPU: `allreduce_gradients` buckets the fp32 gradients (25 MB,
-the reference's DDP default) and all-reduces them over torch.distributed (RCCL on the GPU box, gloo in the CPU tests).
+plain fp32 torch ops on [B, 1280]-sized tensors.  Multi-GPU: `GradientBuckets` all-reduces flat fp32 buckets (25 MB, the
+reference's DDP default) over torch.distributed WHILE the backward pass runs (hooks fire as gradients complete);
+`allreduce_gradients` is the simple reduce-after-backward form (RCCL on the GPU box, gloo in the CPU tests).
 """
 import math
 
@@ -189,8 +190,9 @@ def edm_loss(pred_rows, noisy_latents, target_latents, sigmas):
     return err.reshape(B, -1).mean(dim=1).mean()
 
 
-def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, world_size=1):
-    """One optimisation step.  batch: dict(latents (B,F,4,h,w) clean, noise, sigmas [B], image_latents (B,F,4,h,w)
+def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, world_size=1, buckets=None):
+    """One optimisation step.  Data parallel: pass `buckets=GradientBuckets(params)` (all-reduce overlapped with the
+    backward pass), or only `world_size > 1` for the simple reduce-after-backward path.  batch: dict(latents (B,F,4,h,w) clean, noise, sigmas [B], image_latents (B,F,4,h,w)
     (conditioning frame repeated), control_cond (B,F,4,h,w), encoder_hidden_states (B,1,D), added_time_ids (B,3)).
     Returns the loss (python float is NOT taken: no host sync inside)."""
     lat, noise, sig = batch["latents"].float(), batch["noise"].float(), batch["sigmas"].float()
@@ -206,7 +208,9 @@ def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, 
     pred = unet_train_forward(unet, sample, timesteps, batch["encoder_hidden_states"], batch["added_time_ids"], down, mid)
     loss = edm_loss(pred, noisy, lat, sig)
     loss.backward()
-    if world_size > 1:
+    if buckets is not None:
+        buckets.finish()
+    elif world_size > 1:
         allreduce_gradients([p for p in controlnet.parameters() if p.requires_grad])
     if optimizer is not None:
         optimizer.step()
@@ -215,6 +219,80 @@ def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, 
 
 
 # ------------------------------------------------------------------------------------------------- data parallel
+class GradientBuckets:
+    """DDP-style overlap of the gradient all-reduce with the backward pass (reference: torch DDP under `accelerate`,
+    train_video_controlnet.py:225,485).  Parameters are grouped into flat fp32 buckets of `bucket_bytes` in REVERSE
+    registration order (the order in which autograd finishes them); a post-accumulate-grad hook on every parameter counts
+    its bucket down and launches the bucket's asynchronous all-reduce (RCCL: on its own stream) the moment the last
+    gradient of the bucket exists, while the backward pass keeps running.  `finish()` -- after `loss.backward()` --
+    flushes buckets whose parameters got no gradient (zeros: every rank issues identical collectives), waits, divides by
+    the world size and writes the averaged gradients back.  One instance per model; re-armed by `finish()`."""
+
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.buckets, cur, size = [], [], 0
+        for p in reversed([p for p in params if p.requires_grad]):
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.launch_order = []
+        self._arm()
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for b in self.buckets for p in b] if self.active else []
+
+    def _arm(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.inflight = [None] * len(self.buckets)
+        self.launch_order = []
+
+    def _launch(self, i):
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).float().reshape(-1) for p in self.buckets[i]])
+        self.inflight[i] = (flat, self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launch_order.append(i)
+
+    def _hook(self, p):
+        i = self.bucket_of[id(p)]
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def finish(self):
+        if not self.active:
+            return 0
+        for i in range(len(self.buckets)):
+            if self.inflight[i] is None:
+                self._launch(i)
+        for i, b in enumerate(self.buckets):
+            flat, work = self.inflight[i]
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in b:
+                n = p.numel()
+                g = flat[off:off + n].reshape(p.shape).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.copy_(g)
+                off += n
+        n = len(self.buckets)
+        self._arm()
+        return n
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
 def allreduce_gradients(params, bucket_bytes=25 * 1024 * 1024, group=None):
     """Average the gradients over the process group in flat fp32 buckets (reference: DDP's 25 MB default under
     `accelerate`, train_video_controlnet.py:225,485).  All buckets are launched asynchronously before the first wait, so

@@ -322,7 +322,8 @@ def test_attention_temporal_backward(ops, B, Fr, S, C):
 
 
 # ------------------------------------------------------------------------------------------------ transformer block
-def test_transformer_backward_matches_oracle_autograd(hip_lib):
+@pytest.mark.parametrize("B,order", [(1, "sb"), (2, "sb"), (2, "bs")])
+def test_transformer_backward_matches_oracle_autograd(hip_lib, B, order):
     """TransformerSpatioTemporalModel forward + backward through the HIP kernels (GroupNorm, LayerNorm, fused Linears,
     GEGLU, both attention cores, folded cross-attention vectors, frame embedding, folded AlphaBlender) against
     torch.autograd on the oracle: gradients of the input, the CLIP token and EVERY parameter (to_q / to_k / norm2 of the
@@ -330,8 +331,8 @@ def test_transformer_backward_matches_oracle_autograd(hip_lib):
     import ctrlv_ref as R
     from ctrlv_amd.autograd import transformer_train_forward
     from ctrlv_amd.models.blocks import TransformerSpatioTemporalModel
-    B, Fr, H, W, C, D = 1, 3, 8, 8, 128, 64
-    ref = R.seeded_init_(R.TransformerSpatioTemporalModel(C // 64, 64, C, D), 17)
+    Fr, H, W, C, D = 3, 8, 8, 128, 64
+    ref = R.seeded_init_(R.TransformerSpatioTemporalModel(C // 64, 64, C, D, time_context_order=order), 17)
     with torch.no_grad():
         for p in ref.parameters():
             p.copy_(p.to(torch.bfloat16).float())
@@ -351,7 +352,7 @@ def test_transformer_backward_matches_oracle_autograd(hip_lib):
         p.requires_grad_(True)
     xh = rows(x).to(DEV, torch.bfloat16).requires_grad_(True)
     eh = ehs.reshape(B, D).to(DEV).requires_grad_(True)
-    yh = transformer_train_forward(tr, xh, eh, B, Fr, H, W)
+    yh = transformer_train_forward(tr, xh, eh, B, Fr, H, W, order)
     assert parity_err(nchw(yh.detach().float().cpu(), B * Fr, H, W), yo.detach(), "forward") < 6e-3
     yh.backward(rows(dy).to(DEV, torch.bfloat16))
     torch.cuda.synchronize()

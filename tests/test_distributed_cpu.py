@@ -139,3 +139,55 @@ def test_gradient_allreduce_buckets_over_gloo_world2():
         assert n_buckets >= 3 and all(uniform)
         # mean over ranks of (rank + 1) * (i + 1) = 1.5 * (i + 1); parameter 1: (2 + 0) / 2
         assert first == [1.5, 1.0, 4.5, 6.0, 7.5]
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ctrlv_amd import distributed as D
+    from ctrlv_amd.training import GradientBuckets
+    D.init("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
+                              torch.nn.Linear(256, 8))
+    unused = torch.nn.Parameter(torch.ones(5))                # never reaches the loss: no gradient on any rank
+    params = list(net.parameters()) + [unused]
+    gb = GradientBuckets(params, bucket_bytes=64 * 1024)
+    res = []
+    for step in range(2):                                     # the second step checks that finish() re-arms the hooks
+        x = torch.randn(16, 64, generator=torch.Generator().manual_seed(100 * step + rank))
+        for p in params:
+            p.grad = None
+        net(x).square().mean().backward()
+        launched_in_backward = list(gb.launch_order)          # buckets whose all-reduce started before backward returned
+        local = [p.grad.clone() for p in net.parameters()]
+        n = gb.finish()
+        res.append((n, launched_in_backward, [g.numpy().tobytes() for g in local],
+                    [p.grad.numpy().tobytes() for p in net.parameters()], float(unused.grad.abs().max())))
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_overlap_backward_over_gloo_world2():
+    """GradientBuckets: buckets are all-reduced from post-accumulate-grad hooks in the order autograd completes them (last
+    layer first), i.e. during the backward pass; the result is the mean of the two ranks' local gradients, identical on
+    both ranks; a parameter without a gradient is flushed as zeros in finish()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for step in range(2):
+        (n0, early0, loc0, avg0, u0), (n1, early1, loc1, avg1, u1) = got[0][step], got[1][step]
+        assert n0 == n1 >= 3 and u0 == u1 == 0.0
+        assert early0 == early1 and len(early0) >= n0 - 1 and early0 == sorted(early0)      # launched inside backward, in order
+        assert avg0 == avg1
+        for a, b, m in zip(loc0, loc1, avg0):
+            mean = (np.frombuffer(a, np.float32) + np.frombuffer(b, np.float32)) / 2
+            assert np.allclose(np.frombuffer(m, np.float32), mean, rtol=1e-6, atol=1e-7)
