@@ -4,7 +4,11 @@ full SVD width; tools/train_video_controlnet.py:366-488) through ctrlv_amd.train
 ms per optimisation step, its split (forward / backward / optimizer, HIP events), peak device memory, and the analytic
 work of SURVEY.md 8 a11 (219 TFLOP: ControlNet fwd 29.3 + UNet fwd 80.0 + ControlNet bwd 58.6 + UNet decoder dgrad 51).
 Synthetic data, random-init weights (there are no checkpoints in this image).
-usage: python tools/train_bench.py [--steps 3] [--warmup 1] [--frames 25] [--height 576] [--width 1024]"""
+usage: python tools/train_bench.py [--steps 3] [--warmup 1] [--frames 25] [--height 576] [--width 1024]
+Data parallel (one process per GPU, RCCL): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 --master-port P tools/train_bench.py ...  -- every rank trains on its own clip, the fp32 gradients are
+all-reduced in 25 MB buckets launched from autograd hooks while the backward runs (ctrlv_amd.training.GradientBuckets);
+the time is the MAX over ranks, `samples_per_s` the whole-job rate."""
 import argparse
 import json
 import os
@@ -25,9 +29,18 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--lr", type=float, default=1e-5)
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import __graft_entry__ as ge
-    ge.build()
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
     from ctrlv_amd import training
     from ctrlv_amd.models import ControlNetModel, UNetSpatioTemporalConditionModel
     from ctrlv_amd.utils import build_on_device, random_init_
@@ -39,8 +52,9 @@ def main():
         p.requires_grad_(False)
     params = [p for p in ctrl.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=1e-2)
+    buckets = training.GradientBuckets(params) if world > 1 else None
     B, F, h, w = 1, args.frames, args.height // 8, args.width // 8
-    g = torch.Generator(device=dev).manual_seed(1234)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)             # every rank: its own clip
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
     batch = dict(latents=rn(B, F, 4, h, w), noise=rn(B, F, 4, h, w), sigmas=torch.tensor([1.5], device=dev),
                  image_latents=rn(B, 1, 4, h, w).repeat(1, F, 1, 1, 1), control_cond=rn(B, F, 4, h, w),
@@ -49,6 +63,8 @@ def main():
     times, losses = [], []
     for i in range(args.warmup + args.steps):
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.time()
         e = [ev() for _ in range(4)]
         e[0].record()
@@ -64,12 +80,18 @@ def main():
         loss = training.edm_loss(pred, noisy, lat, sig)
         e[1].record()
         loss.backward()
+        if buckets is not None:
+            buckets.finish()
         e[2].record()
         opt.step()
         opt.zero_grad(set_to_none=True)
         e[3].record()
         torch.cuda.synchronize()
         wall = (time.time() - t0) * 1e3
+        if world > 1:                                             # slowest rank defines the step
+            wt = torch.tensor([wall], device=dev)
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            wall = float(wt)
         if i >= args.warmup:
             times.append((wall, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])))
         losses.append(float(loss.detach()))
@@ -77,7 +99,10 @@ def main():
     n = len(times)
     avg = [sum(t[k] for t in times) / n for k in range(4)]
     tf = 219.0 * (F / 25.0) * (h * w) / (72 * 128)          # scales with pixels x frames (attention: quadratic; quoted for 72x128)
-    print(json.dumps({"metric": "cfg5 ControlNet training step (B=1, no CFG)", "ms_per_step": round(avg[0], 1),
+    if rank != 0:
+        return
+    print(json.dumps({"metric": "cfg5 ControlNet training step (B=1 per GPU, no CFG)", "n_gpus": world,
+                      "samples_per_s": round(world * 1e3 / avg[0], 3), "scaling": "weak", "ms_per_step": round(avg[0], 1),
                       "forward_ms": round(avg[1], 1), "backward_ms": round(avg[2], 1), "optimizer_ms": round(avg[3], 1),
                       "steps": n, "warmup": args.warmup, "frames": F, "latent": [h, w], "analytic_tflop_per_step": round(tf, 1),
                       "tflops": round(tf / avg[0] * 1e3, 1), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
