@@ -532,6 +532,38 @@ int frame_embedding(Ctx& c, const Transformer& t, int F, float* e) {
   return CTRLV_OK;
 }
 
+// GEGLU projection -> FF output as M-CHUNKED pairs (blocks.py::_ff_pair).  At the C = 320 level u (the 4C-wide GEGLU
+// output) is 590 MB for the 50 frame-images of a CFG step; written whole and then read whole it misses the 256 MB
+// Infinity Cache on the way back.  In chunks of <= 160 MB the FF-out GEMM (HBM-bound there: K = 1280, N = 320) reads
+// what the projection has just written: -8 % on the isolated pair (tools/ff_chunk_bench.py: 1754 -> 1614 us), same
+// bits; wider levels (K >= 640) lose from the shorter launches.  IN THE MODEL it is a loss (242.5 vs 241.2 ms per step,
+// three alternating runs on one device: the ControlNet's kernels on the side stream share the cache and fill the
+// launch gaps differently), so it is OPT-IN: CTRLV_FF_CHUNK=1.
+int ff_rows_per_chunk(long M, int C) {
+  static const bool on = [] { const char* e = getenv("CTRLV_FF_CHUNK"); return e && atoi(e) != 0; }();   // opt-in (see above)
+  const long u_bytes = M * 4L * C * 2;
+  if (!on || C > 320 || u_bytes <= (256L << 20)) return (int)M;
+  const long n = (u_bytes + (160L << 20) - 1) / (160L << 20);
+  return (int)(((M + n - 1) / n + 255) / 256 * 256);
+}
+int ff_pair(Ctx& c, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C) {
+  const int M = proj.M, rows = ff_rows_per_chunk(M, C);
+  for (int m0 = 0; m0 < M; m0 += rows) {
+    const int mc = M - m0 < rows ? M - m0 : rows;
+    ctrlv_gemm_desc p = proj, o = outd;
+    p.M = o.M = mc;
+    p.A = (const bf16_t*)proj.A + (long)m0 * proj.lda;
+    p.out = (bf16_t*)proj.out + (long)m0 * proj.ldo;
+    o.A = (const bf16_t*)outd.A + (long)m0 * outd.lda;
+    o.out = (bf16_t*)outd.out + (long)m0 * outd.ldo;
+    if (outd.R1) o.R1 = (const bf16_t*)outd.R1 + (long)m0 * outd.ldr1;
+    if (outd.R2) o.R2 = (const bf16_t*)outd.R2 + (long)m0 * outd.ldr2;
+    TRY(gemm(c, p));
+    TRY(gemm(c, o));
+  }
+  return CTRLV_OK;
+}
+
 // ---- TransformerSpatioTemporalModel (blocks.py::TransformerSpatioTemporalModel.run)
 int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t** out_) {
   const int B = c.B, F = c.F, C = t.C, N = B * F, S = H * W;
@@ -563,16 +595,13 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
   }
   TRY(layernorm(c, h1, (int)M, C, t.s_ln3, tt));
   bf16_t* u = c.rows(M, 4 * C);
-  {
-    ctrlv_gemm_desc d = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
-    d.geglu = 1;
-    TRY(gemm(c, d));
-  }
   bf16_t* h2 = h0;      // h0 is dead from here on
   {
+    ctrlv_gemm_desc dp = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
+    dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
     d.R1 = h1; d.ldr1 = C;
-    TRY(gemm(c, d));
+    TRY(ff_pair(c, dp, d, C));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
   TRY(layernorm(c, h2, (int)M, C, t.t_lnin, tt, emb, S, F, C));
@@ -601,17 +630,14 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     TRY(gemm(c, d));
   }
   TRY(layernorm(c, g1, (int)M, C, t.t_ln3, tt));
-  {
-    ctrlv_gemm_desc d = gd(tt, C, t.t_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
-    d.geglu = 1;
-    TRY(gemm(c, d));
-  }
   bf16_t* h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
+    ctrlv_gemm_desc dp = gd(tt, C, t.t_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
+    dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
     d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
     d.s2 = (float)t.alpha;
-    TRY(gemm(c, d));
+    TRY(ff_pair(c, dp, d, C));
   }
   {
     ctrlv_gemm_desc d = gd(h3, C, t.pout, out, C, (int)M, C, C, C);

@@ -15,6 +15,7 @@ Dimension padding rules of the gather-GEMM (Cin % 64, N % 32) hold for every SVD
 concats); only the tiny test config needs the K zero-padding of the time-embedding inputs.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -122,6 +123,28 @@ class _TemporalBasicTransformerBlock(nn.Module):
 
 def _f32(t):
     return t.detach().float().contiguous()
+
+
+def _ff_rows_per_chunk(M, C):
+    """csrc/plan.hip::ff_rows_per_chunk -- the C = 320 level runs GEGLU projection -> FF output in M chunks whose slice of
+    u (<= 160 MB) is still in the 256 MB Infinity Cache when the FF-out GEMM reads it back: -8 % on the isolated pair, but
+    +0.5 % on the whole step, so opt-in (CTRLV_FF_CHUNK=1)."""
+    u_bytes = M * 4 * C * 2
+    if os.environ.get("CTRLV_FF_CHUNK", "0") != "1" or C > 320 or u_bytes <= (256 << 20):
+        return M
+    n = (u_bytes + (160 << 20) - 1) // (160 << 20)
+    return ((M + n - 1) // n + 255) // 256 * 256
+
+
+def _ff_pair(x, wproj, bproj, u, wout, bout, out, C, **epi):
+    """u = GEGLU(x); out = epilogue(u @ wout^T): issued as M-chunked pairs (same arithmetic, same bits)."""
+    M = x.shape[0]
+    rows = _ff_rows_per_chunk(M, C)
+    for m0 in range(0, M, rows):
+        m1 = min(M, m0 + rows)
+        kw = {k: (v[m0:m1] if k in ("R1", "R2") else v) for k, v in epi.items()}
+        ops.gemm(x[m0:m1], wproj, u[m0:m1], N=8 * C, cin=C, bias=bproj, geglu=1)
+        ops.gemm(u[m0:m1], wout, out[m0:m1], N=C, cin=4 * C, bias=bout, **kw)
 
 
 def _gn_scratch(ctx, n_img, S, C, ips):
@@ -304,9 +327,8 @@ class TransformerSpatioTemporalModel(nn.Module):
         ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)
         ops.layernorm(h1, pk["s_ln3"][0], pk["s_ln3"][1], 1e-5, t)
         u = ws.alloc((M, 4 * C))
-        ops.gemm(t, pk["s_ff"][0], u, N=8 * C, cin=C, bias=pk["s_ff"][1], geglu=1)
         h2 = h0                                         # h0 is dead from here on
-        ops.gemm(u, pk["s_ff"][2], h2, N=C, cin=4 * C, bias=pk["s_ff"][3], R1=h1)
+        _ff_pair(t, pk["s_ff"][0], pk["s_ff"][1], u, pk["s_ff"][2], pk["s_ff"][3], h2, C, R1=h1)
         # ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
         ops.layernorm(h2, pk["t_lnin"][0], pk["t_lnin"][1], 1e-5, t, V=emb, vdiv=S, vmod=F)
         ops.gemm(t, pk["t_ffin"][0], u, N=8 * C, cin=C, bias=pk["t_ffin"][1], geglu=1)
@@ -323,12 +345,11 @@ class TransformerSpatioTemporalModel(nn.Module):
         else:
             ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, vmode=1, vdiv=F * S)
         ops.layernorm(g1, pk["t_ln3"][0], pk["t_ln3"][1], 1e-5, t)
-        ops.gemm(t, pk["t_ff"][0], u, N=8 * C, cin=C, bias=pk["t_ff"][1], geglu=1)
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
-        ops.gemm(u, pk["t_ff"][2], h3, N=C, cin=4 * C, bias=pk["t_ff"][3], s_acc=1.0 - al, R1=g1, s1=1.0 - al,
-                 R2=h2, s2=al)
+        _ff_pair(t, pk["t_ff"][0], pk["t_ff"][1], u, pk["t_ff"][2], pk["t_ff"][3], h3, C, s_acc=1.0 - al, R1=g1,
+                 s1=1.0 - al, R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
         if ctx.trace is not None:
