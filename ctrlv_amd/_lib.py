@@ -23,6 +23,7 @@ class GemmDesc(ctypes.Structure):
         ("s_acc", c_float), ("s1", c_float), ("s2", c_float),
         ("vmode", c_int), ("vdiv", c_int), ("vmod", c_int), ("vS", c_int), ("ldv", c_int),
         ("act", c_int), ("geglu", c_int), ("out_f32", c_int), ("tile", c_int),
+        ("ld_raw", c_int), ("raw_out", c_void_p),
     ]
 
 
@@ -103,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class CtrlvHipError(RuntimeError):

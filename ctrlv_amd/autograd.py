@@ -236,28 +236,32 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class GegluProj(torch.autograd.Function):
-    """u = a * gelu_erf(g), (a | g) = x @ W^T + b   (diffusers GEGLU: `proj` Linear(C -> 2 I), chunk, exact gelu) -- the
-    forward is ONE GEMM with the GEGLU epilogue; the backward recomputes the raw projection (activation recompute instead
-    of storing an [M, 2I] tensor), applies ctrlv_geglu_bwd and reuses the GEMM family for dgrad / wgrad."""
+    """u = a * gelu_erf(g), (a | g) = x @ W^T + b   (diffusers GEGLU: `proj` Linear(C -> 2 I), chunk, exact gelu).  The
+    forward is ONE GEMM with the GEGLU epilogue that ALSO writes the raw projection (bf16, packed column order) for the
+    backward -- u itself comes from the fp32 accumulators exactly as in the inference path; shapes the ping-pong tiles do
+    not serve (K < 128) recompute the raw projection in the backward instead."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         two_i, cin = weight.shape
         wp, bp = packing.pack_geglu(weight, bias)
         u = _rows(x.shape[0], two_i // 2, x)
-        ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1)
-        ctx.save_for_backward(x, weight, bias)
+        raw = _rows(x.shape[0], two_i, x) if (cin >= 128 and cin % 32 == 0) else None
+        ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=raw)
+        ctx.save_for_backward(x, weight, bias, raw if raw is not None else torch.empty(0, device=x.device))
+        ctx.has_raw = raw is not None
         return u
 
     @staticmethod
     def backward(ctx, du):
-        x, weight, bias = ctx.saved_tensors
+        x, weight, bias, raw = ctx.saved_tensors
         two_i, cin = weight.shape
         inner = two_i // 2
         wi = packing.geglu_interleave(weight.detach())                 # rows in the packed (value, gate) block order
-        wp, bp = packing.pack_geglu(weight, bias)
-        raw = _rows(x.shape[0], two_i, x)
-        ops.gemm(x, wp, raw, N=two_i, cin=wp.shape[1], bias=bp)        # activation recompute (no GEGLU epilogue)
+        if not ctx.has_raw:
+            wp, bp = packing.pack_geglu(weight, bias)
+            raw = _rows(x.shape[0], two_i, x)
+            ops.gemm(x, wp, raw, N=two_i, cin=wp.shape[1], bias=bp)    # activation recompute (no GEGLU epilogue)
         draw = torch.empty_like(raw)
         ops.geglu_bwd(raw, du.contiguous(), draw)
         dx, dwi, dbi = gemm_grads(x, wi, draw, dict(mode=0), 1.0, ctx.needs_input_grad[0], ctx.needs_input_grad[1],

@@ -238,6 +238,12 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
+  if (d.raw_out) {      // second output of the GEGLU projection (training forward): ping-pong tiles only
+    CTRLV_CHECK_ARG(d.geglu && d.ld_raw >= d.N, "ctrlv_gemm: raw_out needs geglu = 1 and ld_raw >= N");
+    if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;
+    CTRLV_CHECK_SHAPE(ctrlv_gemm_pp_supports(d), "ctrlv_gemm: raw_out needs a shape the ping-pong tiles serve (K >= 128, "
+                                                 "ld_raw a multiple of 8)");
+  }
   if (tile >= 5) {
     // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
     const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&

@@ -101,7 +101,7 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
 }
 
-template <int TM, int TN, bool GEGLU, int EPI, bool PACKED = true>
+template <int TM, int TN, bool GEGLU, int EPI, bool PACKED = true, bool RAW = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3, const char* bias_lds) {
@@ -253,6 +253,43 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
+    if constexpr (RAW) {
+      // training forward: the projection itself (acc already holds acc + bias) also goes out, as bf16 [M][ld_raw] in the
+      // packed column order -- the plain path's LDS transpose, one 32 x 32 sub-tile at a time.  The backward then needs
+      // no recompute GEMM (ctrlv_geglu_bwd reads this tensor).
+      const __amdgpu_buffer_rsrc_t rsRaw =
+          __builtin_amdgcn_make_buffer_rsrc(d.raw_out, 0, (int)((long)d.M * d.ld_raw * 2), kFlags);
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        const int i = s / TN, j = s % TN;
+        const int ocol = wbase_n + j * 32 + l4 * 8;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int c = (2 * qd + hsel) ^ (r32 & 7);
+          *(float4*)(wrow + c * 16) =
+              make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 img[2][2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const char* rp = pass ? rp_b : rp_a;
+          img[pass][0] = *(const float4*)(rp + rx0);
+          img[pass][1] = *(const float4*)(rp + rx1);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const float4 v0 = img[pass][0], v1 = img[pass][1];
+          const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const int m = m0 + i * 32 + pass * 16;
+          const uint4 pk = pack_bf16x8(o);
+          const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+          __builtin_amdgcn_raw_buffer_store_b128(
+              pv, rsRaw, (m < d.M && ocol < d.N) ? (unsigned)m * (unsigned)(d.ld_raw * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+        }
+      }
+    }
     // GEGLU: weight rows come in 16-row (value, gate) blocks, so quads 0,1 of a 32x32 sub-tile are 16 values and
     // quads 2,3 their gates, in the same lane: out = (a + ba) * gelu(g + bg) is computed in the MFMA layout (its bias
     // is a per-column broadcast from the LDS strip) and two adjacent sub-tiles (16 outputs each) share one staged
@@ -314,7 +351,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 // HAS_A2: the launch has a second A source for channels >= c_split (skip concat).  Only the plain-GEMM / bias-only
 // combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
 // output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -705,7 +742,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
       u32x4_t nb = {0, 0, 0, 0};
       if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
-      gemm_epilogue_lds<TM, TN, GEGLU, EPI>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI, true, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024, bias_lds);
       if (refill) pp_bias_store<WTN>(bias_lds, nb, lane);
       // The accumulators are dead here -- the next tile's first MFMAs overwrite them from a literal-zero C operand --
@@ -742,13 +779,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
   constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0);
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));

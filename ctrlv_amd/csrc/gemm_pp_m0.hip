@@ -22,6 +22,7 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   if (d.taps * (d.Cin >> 5) < 4) return false;       // the DMA ring runs three half-steps ahead inside one tile
   // a second A source (skip concat) is instantiated for the plain GEMM with a bias-only epilogue (1x1 shortcut convs)
   if (d.A2 && !(d.mode == 0 && !d.geglu && pp_epi_of(d) == 0)) return false;
+  if (d.raw_out && ((long)d.M * d.ld_raw * 2 > lim || d.ld_raw % 8 != 0)) return false;
   if (d.geglu) return d.mode == 0;
   const int e = pp_epi_of(d);
   if (e < 0) return false;
@@ -35,6 +36,10 @@ int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream)
   if (d.mode == 1) return ctrlv_gemm_launch_pp_conv(d, tile, persistent, stream);
   if (d.mode == 2) return ctrlv_gemm_launch_pp_temporal(d, tile, persistent, stream);
   if (d.geglu) {
+    if (d.raw_out) {      // training forward: the raw projection is written too
+      if (tile == 5 || tile == 7) return launch_one<256, 2, 4, 0, true, 0, false, true>(d, persistent, stream);
+      return launch_one<320, 4, 2, 0, true, 0, false, true>(d, persistent, stream);
+    }
     if (tile == 5 || tile == 7) return launch_one<256, 2, 4, 0, true, 0>(d, persistent, stream);
     return launch_one<320, 4, 2, 0, true, 0>(d, persistent, stream);
   }

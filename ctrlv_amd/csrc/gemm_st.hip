@@ -5,7 +5,7 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);   // gemm_pp_m0.hip: 32-b
 
 // tile 9: 256 x 160, mode 0, one A source, K a multiple of 32 and >= 96
 bool ctrlv_gemm_st_supports(const ctrlv_gemm_desc& d) {
-  if (d.mode != 0 || d.A2 || (d.Cin & 31) || d.Cin < 96) return false;
+  if (d.mode != 0 || d.A2 || d.raw_out || (d.Cin & 31) || d.Cin < 96) return false;
   if (d.geglu) return true;
   return pp_epi_of(d) >= 0;
 }

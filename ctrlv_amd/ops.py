@@ -88,7 +88,7 @@ def geglu_bwd(raw, du, draw):
 
 def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
          R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
-         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, _dbg=0):
+         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, _dbg=0):
     """out = epilogue(gather-GEMM(A[, A2], W)).  `conv` = (H, W, Ho, Wo, stride, up); `temporal` = (F, S)."""
     _need_gpu(A, "A")
     d = GemmDesc()
@@ -113,6 +113,8 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
     d.ldv = V.stride(0) if V is not None else 0
     d.act, d.geglu, d.out_f32, d.tile = act, geglu, (_dbg if _dbg else (1 if out_f32 else 0)), tile
+    if raw_out is not None:
+        d.raw_out, d.ld_raw = _p(raw_out), raw_out.stride(0)
     ev = _prof.begin()
     check(_lib.load().ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
     if ev is not None:

@@ -83,6 +83,10 @@ typedef struct ctrlv_gemm_desc {
   int32_t geglu;
   int32_t out_f32;
   int32_t tile;                       /* 0 auto, else forces a tile configuration (testing) */
+  int32_t ld_raw;                     /* leading dimension of raw_out (elements) */
+  void* raw_out;                      /* GEGLU only, optional (training forward): the projection BEFORE the gate,
+                                         [M, ld_raw] bf16 in the packed (16 value | 16 gate) column-block order -- what
+                                         ctrlv_geglu_bwd consumes -- written by the same launch (ping-pong tiles) */
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);

@@ -376,3 +376,25 @@ def test_transformer_backward_matches_oracle_autograd(hip_lib, B, order):
     print("  zero-gradient parameters:", zero)
     assert any("attn2.to_q" in z for z in zero)
     assert max(errs.values()) < 3e-2, errs
+
+
+@pytest.mark.parametrize("tile", [0, 5, 6])
+def test_geglu_projection_raw_output(ops, tile):
+    """The training forward's GEGLU GEMM also writes the raw projection (what ctrlv_geglu_bwd consumes): identical bits to
+    the plain GEMM on the same packed weight, and u is unchanged by the second output.  Many tiles per workgroup, ragged M."""
+    from ctrlv_amd import packing
+    M, C = 256 * 300 + 77, 320
+    A = bf(torch.randn(M, C, generator=g(1))).to(DEV)
+    Wt = torch.randn(8 * C, C, generator=g(2)) / math.sqrt(C)
+    b = torch.randn(8 * C, generator=g(3))
+    Wp, bp = packing.pack_geglu(Wt, b)
+    Wp, bp = Wp.to(DEV), bp.to(DEV)
+    u0 = torch.empty(M, 4 * C, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, Wp, u0, N=8 * C, cin=C, bias=bp, geglu=1, tile=tile)
+    raw_ref = torch.empty(M, 8 * C, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, Wp, raw_ref, N=8 * C, cin=C, bias=bp, tile=tile)
+    u1 = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    raw = torch.full((M, 8 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, Wp, u1, N=8 * C, cin=C, bias=bp, geglu=1, raw_out=raw, tile=tile)
+    assert torch.equal(u0, u1)
+    assert torch.equal(raw, raw_ref)
