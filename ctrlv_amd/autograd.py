@@ -15,6 +15,7 @@ whole fused epilogue (FusedLinear / BlendLinear) => a complete `TransformerSpati
 upsample-fused convs.  The model-level training step built from these lives in ctrlv_amd/training.py.
 """
 import math
+import weakref
 
 import torch
 
@@ -27,20 +28,29 @@ def _rows(M, C, like):
 
 # Packed (bf16, kernel-layout) forms of FROZEN parameters are built once: the UNet of the training step never changes,
 # and re-packing its decoder (forward form + role-swapped dgrad form) every step is ~10 ms of small torch kernels.
-# Trainable parameters are packed from the fp32 masters on every use.
+# Trainable parameters are packed from the fp32 masters on every use.  (Writes through `.data` do not bump _version:
+# call clear_pack_cache() after editing a frozen model that way.)
 _PACK_CACHE = {}
 
 
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
 def _packed(weight, kind, fn):
-    if weight.requires_grad or not isinstance(weight, torch.nn.Parameter):     # (temporaries may recycle a data_ptr)
+    if weight.requires_grad or not isinstance(weight, torch.nn.Parameter):     # (temporaries may recycle an address)
         return fn(weight)
-    key = (weight.data_ptr(), weight._version, kind, tuple(weight.shape), weight.dtype)
+    key = (id(weight), kind)
     hit = _PACK_CACHE.get(key)
-    if hit is None:
-        if len(_PACK_CACHE) > 4096:
-            _PACK_CACHE.clear()
-        hit = _PACK_CACHE[key] = fn(weight)
-    return hit
+    # the entry is valid only for THIS parameter object (ids are recycled after garbage collection) at THIS version and
+    # storage (in-place updates bump _version; .to() / load_state_dict may swap the storage)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr(), weight.dtype):
+        return hit[2]
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    out = fn(weight)
+    _PACK_CACHE[key] = (weakref.ref(weight), (weight._version, weight.data_ptr(), weight.dtype), out)
+    return out
 
 
 class GatherGemm(torch.autograd.Function):
