@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--height", type=int, default=576)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--fused-adamw", type=int, default=1, help="torch.optim.AdamW(fused=...)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
     dev = torch.device(f"cuda:{local}")
@@ -51,7 +52,7 @@ def main():
     for p in unet.parameters():
         p.requires_grad_(False)
     params = [p for p in ctrl.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=1e-2)
+    opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=1e-2, fused=bool(args.fused_adamw))
     buckets = training.GradientBuckets(params) if world > 1 else None
     B, F, h, w = 1, args.frames, args.height // 8, args.width // 8
     g = torch.Generator(device=dev).manual_seed(1234 + rank)             # every rank: its own clip
