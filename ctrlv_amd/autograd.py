@@ -15,6 +15,7 @@ whole fused epilogue (FusedLinear / BlendLinear) => a complete `TransformerSpati
 upsample-fused convs.  The model-level training step built from these lives in ctrlv_amd/training.py.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -31,6 +32,7 @@ def _rows(M, C, like):
 # Trainable parameters are packed from the fp32 masters on every use.  (Writes through `.data` do not bump _version:
 # call clear_pack_cache() after editing a frozen model that way.)
 _PACK_CACHE = {}
+_WGRAD_DIRECT = os.environ.get("CTRLV_WGRAD_DIRECT", "0") == "1"     # conv dW straight in [N, cin, taps] (A/B handle)
 
 
 def clear_pack_cache():
@@ -142,13 +144,16 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
             n_img = A.shape[0] // (H * W)
             dA = dA.view(n_img, H, 2, W, 2, cin).float().sum((2, 4)).to(torch.bfloat16).view(n_img * H * W, cin)
     if need_dW:
-        # one kernel: dW (scaled by s_acc) and, riding along in the workgroups that stream dY anyway, the bias gradient
-        dWp = torch.zeros(N, taps * cin, dtype=torch.float32, device=A.device)
+        # one kernel: dW (scaled by s_acc) and, riding along in the workgroups that stream dY anyway, the bias gradient.
+        # Linear weights are written in place; conv weights in the packed tap-major order and permuted afterwards
+        # (writing [N, cin, taps] directly scatters the atomics at a 36-byte stride: A/B in DESIGN 3.6)
+        direct = taps == 1 or _WGRAD_DIRECT
+        dWp = torch.zeros(weight.shape if direct else (N, taps * cin), dtype=torch.float32, device=A.device)
         dbp = torch.zeros(N, dtype=torch.float32, device=A.device) if need_db else None
         ops.gemm_wgrad(A, dY, dWp, N=N, cin=cin, taps=taps, mode=mode, conv=geom.get("conv"),
-                       temporal=geom.get("temporal"), dbias=dbp, scale=s_acc)
-        if mode == 0:
-            dW = dWp.reshape(weight.shape)
+                       temporal=geom.get("temporal"), dbias=dbp, scale=s_acc, torch_layout=direct)
+        if direct:
+            dW = dWp
         elif mode == 1:
             dW = dWp.reshape(N, 3, 3, cin).permute(0, 3, 1, 2)
         else:

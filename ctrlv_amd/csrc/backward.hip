@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int 
 }
 
 struct WgradArgs {
-  const bf16_t* A; const bf16_t* A2; const bf16_t* dY; float* dW; float* dbias; float scale;
+  const bf16_t* A; const bf16_t* A2; const bf16_t* dY; float* dW; float* dbias; float scale; int torch_layout;
   int M, N, Cin, taps, lda, lda2, c_split, ldy, mode, H, Wd, Ho, Wo, stride, up, F, S, rows_per_slab;
 };
 
@@ -153,10 +153,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < 4; ++j) {
       const long k = (long)k0 + 128 * kh + 32 * j + (lane & 31);
       if (k >= ktot) continue;
+      long col = k;                                          // packed (tap-major) K order ...
+      if (a.torch_layout) {                                  // ... or the parameter's own [N][Cin][taps] layout
+        const int tp = (int)(k / a.Cin);
+        col = (k - (long)tp * a.Cin) * a.taps + tp;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (n < a.N) atomicAdd(a.dW + (long)n * ktot + k, acc[i][j][e] * a.scale);
+        if (n < a.N) atomicAdd(a.dW + (long)n * ktot + col, acc[i][j][e] * a.scale);
       }
     }
   if (do_bias) {                                             // fold the 16 row-threads of every column group through LDS
@@ -579,7 +584,7 @@ extern "C" int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I,
 }
 
 extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, float* dbias, float scale,
-                                ctrlv_stream_t stream) {
+                                int torch_layout, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dp && dY && dW, "gemm_wgrad: null pointer");
   const ctrlv_gemm_desc& d = *dp;
   CTRLV_CHECK_ARG(d.A != nullptr, "gemm_wgrad: A must be non-null");
@@ -589,7 +594,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
                     "gemm_wgrad: mode / taps mismatch");
   if (d.A2) CTRLV_CHECK_SHAPE(d.c_split % 64 == 0 && d.lda2 % 8 == 0, "gemm_wgrad: bad concat split");
   WgradArgs a;
-  a.A = (const bf16_t*)d.A; a.A2 = (const bf16_t*)d.A2; a.dY = (const bf16_t*)dY; a.dW = dW; a.dbias = dbias; a.scale = scale;
+  a.A = (const bf16_t*)d.A; a.A2 = (const bf16_t*)d.A2; a.dY = (const bf16_t*)dY; a.dW = dW; a.dbias = dbias; a.scale = scale; a.torch_layout = torch_layout;
   a.M = d.M; a.N = d.N; a.Cin = d.Cin; a.taps = d.taps; a.lda = d.lda; a.lda2 = d.lda2; a.c_split = d.c_split; a.ldy = ldy;
   a.mode = d.mode; a.H = d.H; a.Wd = d.Wd; a.Ho = d.Ho; a.Wo = d.Wo; a.stride = d.stride ? d.stride : 1; a.up = d.up;
   a.F = d.F; a.S = d.S;

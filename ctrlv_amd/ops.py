@@ -23,9 +23,11 @@ def _need_gpu(t, name="tensor"):
         raise _lib.CtrlvHipError(f"ctrlv_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
 
 
-def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=None, temporal=None, dbias=None, scale=1.0):
+def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=None, temporal=None, dbias=None, scale=1.0,
+               torch_layout=False):
     """dW[N, taps*cin] (fp32, packed tap-major K order) += scale * dY^T . gather(A) for the forward GEMM of the same
-    geometry; dbias[N] (fp32, optional) += scale * column sums of dY."""
+    geometry; dbias[N] (fp32, optional) += scale * column sums of dY.  torch_layout: dW is [N, cin, taps] (the conv
+    parameter's own layout) instead of the packed [N, taps*cin]."""
     _need_gpu(A, "A")
     d = GemmDesc()
     d.A, d.A2 = _p(A), _p(A2)
@@ -37,8 +39,8 @@ def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=No
         d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
     if temporal is not None:
         d.F, d.S = temporal
-    check(_lib.load().ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale), _stream()),
-          "ctrlv_gemm_wgrad")
+    check(_lib.load().ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
+                                       1 if torch_layout else 0, _stream()), "ctrlv_gemm_wgrad")
     return dW
 
 

@@ -174,11 +174,12 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
  * ------------------------------------------------------------------------------------------------------------------ */
 /* dW[n][tap*Cin + c] += sum_m dY[m][n] * A[src(m, tap)][c]  for the forward GEMM described by `fwd` (A, A2/c_split, M, N,
  * Cin, taps, mode and its geometry are read; W / out / epilogue fields are ignored).  dY: bf16 [M][ldy]; dW: fp32
- * [N][taps*Cin] in the packed (tap-major) K order, accumulated with atomics -- zero it first.  dbias (fp32 [N], or
+ * [N][taps*Cin] in the packed (tap-major) K order -- or, with torch_layout = 1, [N][Cin][taps], the layout of the
+ * nn.Conv2d / nn.Conv3d / nn.Linear parameter itself -- accumulated with atomics: zero it first.  dbias (fp32 [N], or
  * NULL) += scale * column sums of dY, computed by the workgroups that stream dY anyway; dW is scaled by `scale` too
  * (the forward's s_acc). */
 int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float* dW, float* dbias, float scale,
-                     ctrlv_stream_t stream);
+                     int torch_layout, ctrlv_stream_t stream);
 /* out[idx(m)][n] += scale * x[m][n] summed over rows; idx = 0 (vmode 0: bias gradient) or (m / vdiv) % vmod (vmode 1: the
  * gradient of a per-clip row-vector operand V).  x bf16 [M][ldx], out fp32 [*][ldo], accumulated with atomics. */
 int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out, int ldo,

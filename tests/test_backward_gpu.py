@@ -75,6 +75,10 @@ def test_wgrad_conv3x3(ops, stride, up):
     ops.gemm_wgrad(rows(x).to(DEV), rows(dy).to(DEV), dW, N=cout, cin=cin, taps=9, mode=1, conv=(H, W, Ho, Wo, stride, up))
     got = dW.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
     assert parity_err(got, w.grad, f"conv3x3 wgrad stride {stride} up {up}") < 2e-3
+    dWt = torch.zeros(cout, cin, 3, 3, dtype=torch.float32, device=DEV)       # the parameter's own layout
+    ops.gemm_wgrad(rows(x).to(DEV), rows(dy).to(DEV), dWt, N=cout, cin=cin, taps=9, mode=1, conv=(H, W, Ho, Wo, stride, up),
+                   torch_layout=True)
+    assert parity_err(dWt, w.grad, "conv3x3 wgrad, parameter layout") < 2e-3
 
 
 def test_wgrad_temporal_conv(ops):
@@ -88,6 +92,10 @@ def test_wgrad_temporal_conv(ops):
                    temporal=(Fr, H * W))
     got = dW.reshape(c, 3, c).permute(0, 2, 1).reshape(c, c, 3, 1, 1)
     assert parity_err(got, w.grad, "temporal wgrad") < 2e-3
+    dWt = torch.zeros(c, c, 3, 1, 1, dtype=torch.float32, device=DEV)
+    ops.gemm_wgrad(x.reshape(-1, c).to(DEV), dy.reshape(-1, c).to(DEV), dWt, N=c, cin=c, taps=3, mode=2,
+                   temporal=(Fr, H * W), torch_layout=True)
+    assert parity_err(dWt, w.grad, "temporal wgrad, parameter layout") < 2e-3
 
 
 @pytest.mark.parametrize("C,H,W,n,ips", [(320, 9, 16, 6, 1), (320, 9, 16, 6, 3), (64, 16, 16, 4, 2), (128, 72, 64, 2, 1)])
