@@ -14,27 +14,36 @@ from ctrlv_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
 # (name, M, N, K(cin), taps, mode, geometry, geglu)
-N0, N1, N2, N3 = 50 * 9216, 50 * 2304, 50 * 576, 50 * 144
+PIX = int(os.environ.get("SWEEP_PIXELS", "9216"))          # latent pixels per frame-image at L0 (72x128; 40x64 = 2560)
+N0, N1, N2, N3 = 50 * PIX, 50 * PIX // 4, 50 * PIX // 16, 50 * PIX // 64
+_G = {9216: ((72, 128), (36, 64), (18, 32), (9, 16)), 2560: ((40, 64), (20, 32), (10, 16), (5, 8))}[PIX]
+
+
+def _geo(level):
+    h, w = _G[level]
+    return (h, w, h, w, 1, 0)
+
+
 SHAPES = [
     ("L0 ff.proj geglu 320->2560", N0, 2560, 320, 1, 0, None, 1),
     ("L0 ff.out 1280->320", N0, 320, 1280, 1, 0, None, 0),
     ("L0 qkv 320->960", N0, 960, 320, 1, 0, None, 0),
     ("L0 proj 320->320", N0, 320, 320, 1, 0, None, 0),
-    ("L0 conv3x3 320->320", N0, 320, 320, 9, 1, (72, 128, 72, 128, 1, 0), 0),
-    ("L0 conv3x3 960->320", N0, 320, 960, 9, 1, (72, 128, 72, 128, 1, 0), 0),
-    ("L0 convT 320->320", N0, 320, 320, 3, 2, (25, 9216), 0),
+    ("L0 conv3x3 320->320", N0, 320, 320, 9, 1, _geo(0), 0),
+    ("L0 conv3x3 960->320", N0, 320, 960, 9, 1, _geo(0), 0),
+    ("L0 convT 320->320", N0, 320, 320, 3, 2, (25, PIX), 0),
     ("L1 ff.proj geglu 640->5120", N1, 5120, 640, 1, 0, None, 1),
     ("L1 ff.out 2560->640", N1, 640, 2560, 1, 0, None, 0),
     ("L1 qkv 640->1920", N1, 1920, 640, 1, 0, None, 0),
-    ("L1 conv3x3 640->640", N1, 640, 640, 9, 1, (36, 64, 36, 64, 1, 0), 0),
-    ("L1 conv3x3 1920->640", N1, 640, 1920, 9, 1, (36, 64, 36, 64, 1, 0), 0),
+    ("L1 conv3x3 640->640", N1, 640, 640, 9, 1, _geo(1), 0),
+    ("L1 conv3x3 1920->640", N1, 640, 1920, 9, 1, _geo(1), 0),
     ("L2 ff.proj geglu 1280->10240", N2, 10240, 1280, 1, 0, None, 1),
     ("L2 ff.out 5120->1280", N2, 1280, 5120, 1, 0, None, 0),
     ("L2 qkv 1280->3840", N2, 3840, 1280, 1, 0, None, 0),
-    ("L2 conv3x3 1280->1280", N2, 1280, 1280, 9, 1, (18, 32, 18, 32, 1, 0), 0),
-    ("L2 conv3x3 2560->1280", N2, 1280, 2560, 9, 1, (18, 32, 18, 32, 1, 0), 0),
-    ("L3 conv3x3 1280->1280", N3, 1280, 1280, 9, 1, (9, 16, 9, 16, 1, 0), 0),
-    ("L3 conv3x3 2560->1280", N3, 1280, 2560, 9, 1, (9, 16, 9, 16, 1, 0), 0),
+    ("L2 conv3x3 1280->1280", N2, 1280, 1280, 9, 1, _geo(2), 0),
+    ("L2 conv3x3 2560->1280", N2, 1280, 2560, 9, 1, _geo(2), 0),
+    ("L3 conv3x3 1280->1280", N3, 1280, 1280, 9, 1, _geo(3), 0),
+    ("L3 conv3x3 2560->1280", N3, 1280, 2560, 9, 1, _geo(3), 0),
     ("L3 ff.proj geglu 1280->10240", N3, 10240, 1280, 1, 0, None, 1),
 ]
 
