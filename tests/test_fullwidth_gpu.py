@@ -61,3 +61,65 @@ def test_fullwidth_error_growth_trace(full_pair):
     tr = error_growth_trace(ou, hu, make_inputs(cfg, 2, 2, 32, 32), DEV, oc, hc)
     assert len(tr) == 55
     check_trace(tr)
+
+
+def test_fullwidth_train_step_matches_oracle_autograd(full_pair):
+    """The cfg5 training step (tools/train_video_controlnet.py:451-488) at PRODUCTION WIDTHS (B = 1, 2 frames, 32x32
+    latent): loss and every ControlNet parameter gradient against fp32 autograd on the oracle, next to the torch-bf16
+    yardstick.  Reaches what the tiny configuration cannot: wgrad with N = 320 (ragged 128-wide tiles) and K up to 5120,
+    the raw-output GEGLU GEMM on the 320-wide tile, 5 / 10 / 20-head attention backward, 10-channel GroupNorm groups.
+    LAST test of the module: it turns the shared ControlNet into an fp32-master training model and restores it."""
+    import copy
+    from tests.parity_utils import rel_l2, set_context_order
+    from tests.test_train_gpu import _batch, _oracle_step
+    from ctrlv_amd.training import train_step
+    cfg, (ou, oc, hu, hc) = full_pair
+    set_context_order((ou, oc, hu, hc), "sb")
+    b = _batch(cfg, 1, 2, 32, 32, seed=11)
+    for p in oc.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    with torch.enable_grad():
+        loss_ref = float(_oracle_step(ou, oc, b, 0.8))
+        hc.float()
+        for p in hc.parameters():
+            p.requires_grad_(True)
+        for p in hu.parameters():
+            p.requires_grad_(False)
+        loss = float(train_step(hc, hu, {k: v.to(DEV) for k, v in b.items()}, conditioning_scale=0.8))
+        torch.cuda.synchronize()
+        yu, yc = copy.deepcopy(ou).to(DEV, torch.bfloat16), copy.deepcopy(oc).to(DEV, torch.bfloat16)
+        for q in yc.parameters():
+            q.grad = None
+        _oracle_step(yu, yc, b, 0.8)
+    try:
+        print(f"  loss: HIP {loss:.6f}  oracle {loss_ref:.6f}")
+        assert abs(loss - loss_ref) <= 5e-3 * abs(loss_ref)
+        refp, yp = dict(oc.named_parameters()), dict(yc.named_parameters())
+        gmax = max(float(q.grad.abs().max()) for q in refp.values() if q.grad is not None)
+        got, ref, yard, worst = [], [], [], []
+        for name, p in hc.named_parameters():
+            rg = refp[name].grad
+            if rg is None or float(rg.abs().max()) <= 1e-6 * gmax:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+                continue
+            assert p.grad is not None, name
+            pg = p.grad.float().cpu().reshape(rg.shape)
+            got.append(pg.reshape(-1)); ref.append(rg.reshape(-1)); yard.append(yp[name].grad.float().cpu().reshape(-1))
+            if not name.endswith("mix_factor"):
+                worst.append((rel_l2(pg, rg), name))
+        tot, ytot = rel_l2(torch.cat(got), torch.cat(ref)), rel_l2(torch.cat(yard), torch.cat(ref))
+        worst.sort(reverse=True)
+        for v, n in worst[:6]:
+            print(f"  {v:.2e}  d/d {n}")
+        print(f"  {len(got)} parameter gradients (680.9 M values), concatenated: rel-L2 {tot:.2e}   (torch bf16: {ytot:.2e})")
+        assert tot < 3e-2 and tot < 1.5 * ytot
+        assert worst[0][0] < 1e-1, worst[:3]
+    finally:
+        for m in (oc, hc):
+            for p in m.parameters():
+                p.grad = None
+                p.requires_grad_(False)
+        hc.to(torch.bfloat16)
+        for p in oc.parameters():
+            p.requires_grad_(True)
