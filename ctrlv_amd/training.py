@@ -190,9 +190,13 @@ def edm_loss(pred_rows, noisy_latents, target_latents, sigmas):
     return err.reshape(B, -1).mean(dim=1).mean()
 
 
-def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, world_size=1, buckets=None):
+def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, world_size=1, buckets=None,
+               accumulate=False, loss_scale=1.0):
     """One optimisation step.  Data parallel: pass `buckets=GradientBuckets(params)` (all-reduce overlapped with the
-    backward pass), or only `world_size > 1` for the simple reduce-after-backward path.  batch: dict(latents (B,F,4,h,w) clean, noise, sigmas [B], image_latents (B,F,4,h,w)
+    backward pass), or only `world_size > 1` for the simple reduce-after-backward path.
+    Gradient accumulation (`accelerator.accumulate`, gradient_accumulation_steps of train_video_controlnet.py:376): call
+    with accumulate=True and loss_scale=1/steps for every micro-batch but the last -- gradients add up locally, nothing is
+    all-reduced and the optimizer does not step; the last micro-batch (accumulate=False) reduces the sums and steps.  batch: dict(latents (B,F,4,h,w) clean, noise, sigmas [B], image_latents (B,F,4,h,w)
     (conditioning frame repeated), control_cond (B,F,4,h,w), encoder_hidden_states (B,1,D), added_time_ids (B,3)).
     Returns the loss (python float is NOT taken: no host sync inside)."""
     lat, noise, sig = batch["latents"].float(), batch["noise"].float(), batch["sigmas"].float()
@@ -207,7 +211,11 @@ def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, 
                                          conditioning_scale)
     pred = unet_train_forward(unet, sample, timesteps, batch["encoder_hidden_states"], batch["added_time_ids"], down, mid)
     loss = edm_loss(pred, noisy, lat, sig)
-    loss.backward()
+    if buckets is not None:
+        buckets.enabled = not accumulate
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    if accumulate:
+        return loss.detach()
     if buckets is not None:
         buckets.finish()
     elif world_size > 1:
@@ -244,6 +252,7 @@ class GradientBuckets:
         if cur:
             self.buckets.append(cur)
         self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.enabled = True               # False = accumulate locally (accelerate's no_sync micro-batches): no collective
         self.launch_order = []
         self._arm()
         self.handles = [p.register_post_accumulate_grad_hook(self._hook) for b in self.buckets for p in b] if self.active else []
@@ -259,13 +268,15 @@ class GradientBuckets:
         self.launch_order.append(i)
 
     def _hook(self, p):
+        if not self.enabled:
+            return
         i = self.bucket_of[id(p)]
         self.pending[i] -= 1
         if self.pending[i] == 0:
             self._launch(i)
 
     def finish(self):
-        if not self.active:
+        if not self.active or not self.enabled:
             return 0
         for i in range(len(self.buckets)):
             if self.inflight[i] is None:

@@ -164,6 +164,18 @@ def _overlap_worker(rank, world, port, out):
         n = gb.finish()
         res.append((n, launched_in_backward, [g.numpy().tobytes() for g in local],
                     [p.grad.numpy().tobytes() for p in net.parameters()], float(unused.grad.abs().max())))
+    # accumulation (no_sync): two micro-batches add up locally without any collective, the third reduces the SUM
+    for p in params:
+        p.grad = None
+    gb.enabled = False
+    for mb in range(2):
+        net(torch.randn(4, 64, generator=torch.Generator().manual_seed(7 + mb + 10 * rank))).square().mean().backward()
+    assert gb.launch_order == [] and gb.finish() == 0
+    gb.enabled = True
+    net(torch.randn(4, 64, generator=torch.Generator().manual_seed(9 + 10 * rank))).square().mean().backward()
+    local_sum = [p.grad.clone() for p in net.parameters()]       # (hooks fired on the accumulated .grad)
+    gb.finish()
+    res.append((local_sum[0].numpy().tobytes(), next(net.parameters()).grad.numpy().tobytes()))
     out.put((rank, res))
     dist.destroy_process_group()
 
@@ -183,6 +195,10 @@ def test_gradient_buckets_overlap_backward_over_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     import numpy as np
+    (s0, a0), (s1, a1) = got[0][2], got[1][2]            # accumulated micro-batches: mean over ranks of the local SUMS
+    assert a0 == a1
+    assert np.allclose(np.frombuffer(a0, np.float32), (np.frombuffer(s0, np.float32) + np.frombuffer(s1, np.float32)) / 2,
+                       rtol=1e-6, atol=1e-7)
     for step in range(2):
         (n0, early0, loc0, avg0, u0), (n1, early1, loc1, avg1, u1) = got[0][step], got[1][step]
         assert n0 == n1 >= 3 and u0 == u1 == 0.0
