@@ -77,6 +77,7 @@ SIGNATURES = {
     "ctrlv_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                      c_float, c_void_p, c_void_p]),
+    "ctrlv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "ctrlv_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "ctrlv_dot_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
@@ -104,7 +105,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CtrlvHipError(RuntimeError):

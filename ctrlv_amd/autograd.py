@@ -55,6 +55,16 @@ def _packed(weight, kind, fn):
     return out
 
 
+def _pack_fwd(weight, mode, geglu=False):
+    """bf16 forward GEMM layout of a parameter: one kernel (ctrlv_pack_weight) where the shape allows, else packing.py."""
+    out = ops.pack_weight(weight, 0, geglu) if weight.is_cuda else None
+    if out is not None:
+        return out
+    if geglu:
+        return packing.pack_geglu(weight, weight.new_zeros(weight.shape[0]))[0]
+    return (packing.pack_linear if mode == 0 else (packing.pack_conv3x3 if mode == 1 else packing.pack_conv_temporal))(weight)
+
+
 class GatherGemm(torch.autograd.Function):
     """out = s_acc * (gather-GEMM(A, weight) + bias) + R1 + V[(m // vdiv)]   (what the res block's convs fuse).
 
@@ -63,8 +73,7 @@ class GatherGemm(torch.autograd.Function):
 
     @staticmethod
     def _pack(weight, mode):
-        fn = packing.pack_linear if mode == 0 else (packing.pack_conv3x3 if mode == 1 else packing.pack_conv_temporal)
-        return _packed(weight, ("fwd", mode), fn)
+        return _packed(weight, ("fwd", mode), lambda w: _pack_fwd(w, mode))
 
     @staticmethod
     def forward(ctx, A, weight, bias, R1, V, s_acc, geom):
@@ -118,6 +127,9 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
         conv = geom.get("conv")
 
         def swapped(_):
+            direct = ops.pack_weight(weight, 1) if weight.is_cuda else None     # one kernel incl. the zero padding of N
+            if direct is not None:
+                return direct
             if mode == 0:
                 return packing.pack_linear(wd.reshape(npad, cin).t())
             if mode == 1:
@@ -259,7 +271,7 @@ class GegluProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         two_i, cin = weight.shape
-        wp, bp = packing.pack_geglu(weight, bias)
+        wp, bp = _pack_fwd(weight, 0, geglu=True), packing.geglu_interleave(bias.detach()).float().contiguous()
         u = _rows(x.shape[0], two_i // 2, x)
         raw = _rows(x.shape[0], two_i, x) if (cin >= 128 and cin % 32 == 0) else None
         ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=raw)
@@ -341,7 +353,7 @@ class FusedLinear(torch.autograd.Function):
         vmode, vS = (cfg.get("vmode", 1), cfg.get("vS", 1)) if V is not None else (0, 1)
         N, cin = weight.shape
         out = _rows(A.shape[0], N, A)
-        ops.gemm(A, _packed(weight, ("fwd", 0), packing.pack_linear), out, N=(N + 31) // 32 * 32, cin=cin,
+        ops.gemm(A, _packed(weight, ("fwd", 0), lambda w: _pack_fwd(w, 0)), out, N=(N + 31) // 32 * 32, cin=cin,
                  bias=None if bias is None else packing.pad_bias(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
                  V=V, vmode=vmode, vdiv=vdiv, vmod=vmod, vS=vS)
         ctx.save_for_backward(A, weight)
@@ -382,7 +394,7 @@ class BlendLinear(torch.autograd.Function):
         a = 1.0 / (1.0 + math.exp(-float(mix_factor.detach().float().cpu())))
         N, cin = weight.shape
         out = _rows(u.shape[0], N, u)
-        ops.gemm(u, packing.pack_linear(weight), out, N=N, cin=cin, bias=packing.pad_bias(bias), s_acc=1.0 - a,
+        ops.gemm(u, _pack_fwd(weight, 0), out, N=N, cin=cin, bias=packing.pad_bias(bias), s_acc=1.0 - a,
                  R1=g1, s1=1.0 - a, R2=h2, s2=a)
         ctx.save_for_backward(u, weight, h2, out, mix_factor)
         ctx.a = a

@@ -50,6 +50,28 @@ __global__ void pack_weight_kernel(const void* __restrict__ src, int dtype, int 
     dst[(long)(n_off + row_map(n, N, geglu)) * ld + tap * cp + c_off + c] = f32_to_bf16(ld_any(src, dtype, i));
   }
 }
+// Role-swapped (dgrad) form of a weight: dst[c][(taps - 1 - tap) * Np + n] = src[(n * C + c) * taps + tap]  -- taps
+// reversed, output and input channels transposed (autograd.py::gemm_grads); columns n in [N, Np) are zeros.
+// grid (ceil(taps * Np / 256), C)
+__global__ void pack_weight_swapped_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps, int Np,
+                                           bf16_t* __restrict__ dst, int ld) {
+  const int c = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;       // column of dst: tapd * Np + n
+  if (k >= taps * Np) return;
+  const int tapd = k / Np, n = k - tapd * Np;
+  float v = 0.f;
+  if (n < N) v = ld_any(src, dtype, ((long)n * C + c) * taps + (taps - 1 - tapd));
+  dst[(long)c * ld + k] = f32_to_bf16(v);
+}
+// Forward form with coalesced writes: dst[rowmap(n)][tap * C + c] = src[(n * C + c) * taps + tap]   grid (ceil(taps*C/256), N)
+__global__ void pack_weight_rows_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps,
+                                        bf16_t* __restrict__ dst, int ld, int geglu) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= taps * C) return;
+  const int tap = k / C, c = k - tap * C;
+  dst[(long)row_map(n, N, geglu) * ld + k] = f32_to_bf16(ld_any(src, dtype, ((long)n * C + c) * taps + tap));
+}
 __global__ void pack_vector_kernel(const void* __restrict__ src, int dtype, int N, float* __restrict__ dst, int n_off,
                                    int geglu, int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -881,6 +903,25 @@ void free_owned(ctrlv_plan* p) {
 }  // namespace
 
 // ================================================================================================== C entry points
+extern "C" int ctrlv_pack_weight(const void* src, int src_dtype, int N, int C, int taps, int form, int geglu, void* dst,
+                                 int ld_dst, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(src && dst, "pack_weight: null pointer");
+  CTRLV_CHECK_ARG(src_dtype >= 0 && src_dtype <= 2 && (form == 0 || form == 1), "pack_weight: bad dtype / form");
+  CTRLV_CHECK_SHAPE(N > 0 && C > 0 && taps > 0 && N <= 65535 && C <= 65535, "pack_weight: bad shape");
+  if (form == 0) {
+    CTRLV_CHECK_SHAPE(ld_dst >= taps * C && (!geglu || N % 32 == 0), "pack_weight: ld_dst < taps * C (or odd GEGLU rows)");
+    hipLaunchKernelGGL(pack_weight_rows_kernel, dim3((taps * C + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dtype, N, C, taps, (bf16_t*)dst, ld_dst, geglu);
+  } else {
+    CTRLV_CHECK_SHAPE(ld_dst % taps == 0 && ld_dst / taps >= N && !geglu, "pack_weight: ld_dst must be taps * Np, Np >= N");
+    const int Np = ld_dst / taps;
+    hipLaunchKernelGGL(pack_weight_swapped_kernel, dim3((taps * Np + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dtype, N, C, taps, Np, (bf16_t*)dst, ld_dst);
+  }
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
 extern "C" int ctrlv_plan_create(const ctrlv_model_config* cfg, int device, ctrlv_plan** out) {
   CTRLV_CHECK_ARG(cfg && out, "plan_create: null argument");
   ctrlv_plan* p = new ctrlv_plan();

@@ -8,6 +8,7 @@ from . import _lib, profiler as _prof
 from ._lib import GemmDesc, check
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_NO_PACK_KERNEL = __import__("os").environ.get("CTRLV_PACK_KERNEL", "1") == "0"      # A/B handle: torch packers only
 
 
 def _stream():
@@ -42,6 +43,29 @@ def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=No
     check(_lib.load().ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
                                        1 if torch_layout else 0, _stream()), "ctrlv_gemm_wgrad")
     return dW
+
+
+def pack_weight(weight, form=0, geglu=False):
+    """bf16 GEMM layout of a PyTorch-layout parameter in ONE kernel (ctrlv_pack_weight): form 0 = forward
+    [N32, taps*C], form 1 = role-swapped dgrad [C32, taps*N64].  Returns None when the shape needs the torch packer
+    (K not a multiple of 64 for Linear, odd channel counts)."""
+    w = weight.detach()
+    if _NO_PACK_KERNEL or not (w.is_cuda and w.is_contiguous() and w.dtype in _DT):
+        return None
+    N, C = w.shape[0], w.shape[1]
+    taps = w.numel() // (N * C)
+    if form == 0:
+        if (taps == 1 and C % 64) or C % 8:
+            return None
+        rows, ld = (N + 31) // 32 * 32, taps * C
+    else:
+        if C % 32:
+            return None
+        rows, ld = C, taps * ((N + 63) // 64 * 64)
+    dst = (torch.zeros if rows != (N if form == 0 else C) else torch.empty)(rows, ld, dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().ctrlv_pack_weight(_p(w), _DT[w.dtype], N, C, taps, form, 1 if geglu else 0, _p(dst), ld, _stream()),
+          "ctrlv_pack_weight")
+    return dst
 
 
 def colsum(x, out, vmode=0, vdiv=1, vmod=1, scale=1.0):

@@ -180,6 +180,13 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
  * (the forward's s_acc). */
 int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float* dW, float* dbias, float scale,
                      int torch_layout, ctrlv_stream_t stream);
+/* One-kernel packing of a PyTorch-layout parameter (fp32 / fp16 / bf16: src_dtype 0 / 1 / 2; [N][C][taps] contiguous:
+ * nn.Linear taps 1, Conv2d 3x3 taps 9, Conv3d (3,1,1) taps 3) into the bf16 GEMM layouts -- what a training step does
+ * to every trainable weight every step.  form 0: the forward layout dst[n][tap*C + c] (geglu: rows in the packed
+ * (value, gate) block order); form 1: the role-swapped dgrad layout dst[c][(taps-1-tap)*Np + n], Np = ld_dst / taps
+ * (columns n >= N zero).  Rows of dst beyond those written (row padding to 32) must be zeroed by the caller. */
+int ctrlv_pack_weight(const void* src, int src_dtype, int N, int C, int taps, int form, int geglu, void* dst, int ld_dst,
+                      ctrlv_stream_t stream);
 /* out[idx(m)][n] += scale * x[m][n] summed over rows; idx = 0 (vmode 0: bias gradient) or (m / vdiv) % vmod (vmode 1: the
  * gradient of a per-clip row-vector operand V).  x bf16 [M][ldx], out fp32 [*][ldo], accumulated with atomics. */
 int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out, int ldo,

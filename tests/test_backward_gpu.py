@@ -406,3 +406,26 @@ def test_geglu_projection_raw_output(ops, tile):
     ops.gemm(A, Wp, u1, N=8 * C, cin=C, bias=bp, geglu=1, raw_out=raw, tile=tile)
     assert torch.equal(u0, u1)
     assert torch.equal(raw, raw_ref)
+
+
+def test_pack_weight_kernel_matches_the_torch_packers(ops):
+    """ctrlv_pack_weight (one kernel per trainable weight per step) against packing.py: forward layouts of Linear / 3x3 /
+    temporal convs incl. the GEGLU row interleave and row padding to 32, and the role-swapped dgrad layouts (taps
+    reversed, channels transposed, N zero-padded to 64)."""
+    from ctrlv_amd import packing
+    lin = torch.randn(320, 128, generator=g(1)).to(DEV)
+    assert torch.equal(ops.pack_weight(lin, 0), packing.pack_linear(lin))
+    assert torch.equal(ops.pack_weight(lin, 1), packing.pack_linear(lin.t()))
+    odd = torch.randn(40, 128, generator=g(2)).to(DEV)                          # rows padded 40 -> 64, dgrad N 40 -> 64
+    assert torch.equal(ops.pack_weight(odd, 0), packing.pack_linear(odd))
+    padded = torch.cat([odd, odd.new_zeros(24, 128)], 0)
+    assert torch.equal(ops.pack_weight(odd, 1), packing.pack_linear(padded.t()))
+    conv = torch.randn(64, 96, 3, 3, generator=g(3)).to(DEV)
+    assert torch.equal(ops.pack_weight(conv, 0), packing.pack_conv3x3(conv))
+    assert torch.equal(ops.pack_weight(conv, 1), packing.pack_conv3x3(conv.flip(2, 3).transpose(0, 1)))
+    tc = torch.randn(64, 64, 3, 1, 1, generator=g(4)).to(DEV).to(torch.bfloat16)
+    assert torch.equal(ops.pack_weight(tc, 0), packing.pack_conv_temporal(tc))
+    assert torch.equal(ops.pack_weight(tc, 1), packing.pack_conv_temporal(tc.flip(2).transpose(0, 1)))
+    gw, gb = torch.randn(512, 64, generator=g(5)).to(DEV), torch.randn(512, generator=g(6)).to(DEV)
+    assert torch.equal(ops.pack_weight(gw, 0, geglu=True), packing.pack_geglu(gw, gb)[0])
+    assert ops.pack_weight(torch.randn(64, 40, device=DEV), 0) is None             # K = 40: the torch packer pads it
