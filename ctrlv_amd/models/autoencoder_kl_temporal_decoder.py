@@ -5,7 +5,9 @@ The reference takes this model from diffusers==0.27.2 (`tools/train_video_contro
 once per clip to encode the conditioning image / the bbox frames (`.encode(x).latent_dist.mode()`,
 `pipeline_video_control.py:71-101,235`) and once to decode the final latents in chunks
 (`.decode(z, num_frames=n).sample`, `:346`).  north_star keeps the VAE on PyTorch-ROCm, so this is ordinary `torch.nn`
-code (MIOpen / rocBLAS / SDPA), not HIP kernels; it exists so that `StableVideoControlPipeline.from_pretrained` is
+code (MIOpen / rocBLAS / SDPA) -- except that `decode` on a HIP device executes the TemporalDecoder's parameters through
+the gather-GEMM / GroupNorm kernels of libctrlv_hip.so (vae_decoder_hip.py; the torch forward stays as the reference and
+the CPU path).  It exists so that `StableVideoControlPipeline.from_pretrained` is
 self-sufficient on a machine without diffusers.  Module and parameter names follow the diffusers state-dict layout, so
 `vae/diffusion_pytorch_model.safetensors` of SVD-XT loads by name.
 
@@ -247,7 +249,15 @@ class AutoencoderKLTemporalDecoder(HipModelMixin):
     def decode(self, z, num_frames, return_dict=True):
         if z.shape[0] % num_frames:
             raise ValueError(f"decode: {z.shape[0]} latent frames are not a multiple of num_frames={num_frames}")
-        sample = self.decoder(z, num_frames)
+        # the decoder runs on the HIP kernels when it can (vae_decoder_hip.py: ~30x the MIOpen path at 576x1024);
+        # CTRLV_VAE_HIP=0, CPU tensors, autograd or > 4 GiB intermediates use the torch modules below
+        from . import vae_decoder_hip as vh
+        import os
+        if (os.environ.get("CTRLV_VAE_HIP", "1") != "0" and z.is_cuda and not torch.is_grad_enabled()
+                and vh.supports(z, num_frames)):
+            sample = vh.decode(self.decoder, z, num_frames)
+        else:
+            sample = self.decoder(z, num_frames)
         return types.SimpleNamespace(sample=sample) if return_dict else (sample,)
 
     def forward(self, sample, sample_posterior=False, generator=None, num_frames=1):

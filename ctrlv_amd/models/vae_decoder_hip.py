@@ -1,0 +1,213 @@
+"""`TemporalDecoder.forward` of the SVD VAE on the HIP kernels (the once-per-clip decode that follows the
+denoising loop: `self.vae.decode(latents[i:i+chunk], num_frames=n).sample`, pipeline_video_control.py:346 ->
+diffusers `decode_latents`).
+
+Why it exists: on this PyTorch-ROCm stack the 25-frame 576x1024 decode through MIOpen takes 3.4 s per clip (and minutes
+on first use while MIOpen searches), against 6.1 s for the whole 25-step denoising loop (tools/vae_decode_bench.py).  The
+decoder is the same op vocabulary as the UNet's res blocks -- GroupNorm(+SiLU), 3x3 convs, (3,1,1) convs, a learned
+AlphaBlender, nearest-x2 upsampling fused into the next conv -- so it runs on the gather-GEMM / GroupNorm kernels of
+libctrlv_hip.so with the same fusions (blend and residuals in GEMM epilogues, upsample in the conv's gather).  The one
+exception is the mid block's single-head attention (head dim 512; the HIP attention cores are specialised for 64): its
+projections are HIP GEMMs, the core is torch SDPA.  `time_conv_out` (3 -> 3 channels) is three tiny channel mixes in torch.
+
+The parameters stay in the `AutoencoderKLTemporalDecoder` module (diffusers state-dict layout); this file only executes
+them.  Packed weights are cached per decoder object (the VAE is frozen).  Activations are channels-last bf16 rows
+[n_frames * H * W, C]; a chunk of n frames is ONE clip of n frames for the temporal blocks, exactly as the reference's
+chunked decode treats it.  Limit: tensors are addressed with 32-bit byte offsets, i.e. n * 576 * 1024 * 256 channels * 2 B
+< 4 GiB -> chunks of at most 14 frames at 576x1024 (the reference scripts use 8); larger chunks raise.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops, packing
+
+_CACHE = {}
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _sig(p):
+    return 1.0 / (1.0 + math.exp(-float(p.detach().float().cpu())))
+
+
+def _pack_res(blk):
+    s, t = blk.spatial_res_block, blk.temporal_res_block
+    pk = dict(cin=s.conv1.weight.shape[1], cout=s.conv1.weight.shape[0],
+              g1=_f32(s.norm1.weight), b1=_f32(s.norm1.bias), w1=packing.pack_conv3x3(s.conv1.weight), cb1=_f32(s.conv1.bias),
+              g2=_f32(s.norm2.weight), b2=_f32(s.norm2.bias), w2=packing.pack_conv3x3(s.conv2.weight), cb2=_f32(s.conv2.bias),
+              tg1=_f32(t.norm1.weight), tb1=_f32(t.norm1.bias), tw1=packing.pack_conv_temporal(t.conv1.weight),
+              tcb1=_f32(t.conv1.bias),
+              tg2=_f32(t.norm2.weight), tb2=_f32(t.norm2.bias), tw2=packing.pack_conv_temporal(t.conv2.weight),
+              tcb2=_f32(t.conv2.bias),
+              # switch_spatial_to_temporal_mix: alpha = 1 - sigmoid(mix);  alpha*xs + (1-alpha)*(xs + h) = xs + sigmoid(mix)*h
+              mix=_sig(blk.time_mixer.mix_factor), eps_s=s.norm1.eps, eps_t=t.norm1.eps)
+    if s.conv_shortcut is not None:
+        pk["wsc"], pk["bsc"] = packing.pack_linear(s.conv_shortcut.weight), _f32(s.conv_shortcut.bias)
+    return pk
+
+
+def _pack(dec):
+    key = id(dec)
+    ver = tuple(p._version for p in dec.parameters()) + (next(dec.parameters()).data_ptr(),)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[1]() is dec:
+        return hit[2]
+    import weakref
+    pk = {}
+    cin = dec.conv_in.weight.shape[1]
+    cp = (cin + 7) // 8 * 8
+    kp = (9 * cp + 63) // 64 * 64
+    pk["cin"] = (cp, kp, packing.pack_conv_in([dec.conv_in.weight], cp, kp), packing.pad_bias(dec.conv_in.bias))
+    pk["mid_res"] = [_pack_res(r) for r in dec.mid_block.resnets]
+    a = dec.mid_block.attentions[0]
+    pk["attn"] = dict(g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), eps=a.group_norm.eps, heads=a.heads,
+                      wqkv=packing.pack_linear(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0)),
+                      bqkv=_f32(torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], 0)),
+                      wo=packing.pack_linear(a.to_out[0].weight), bo=_f32(a.to_out[0].bias))
+    pk["up"] = []
+    for blk in dec.up_blocks:
+        up = None
+        if blk.upsamplers is not None:
+            up = (packing.pack_conv3x3(blk.upsamplers[0].conv.weight), _f32(blk.upsamplers[0].conv.bias))
+        pk["up"].append(([_pack_res(r) for r in blk.resnets], up))
+    pk["gno"] = (_f32(dec.conv_norm_out.weight), _f32(dec.conv_norm_out.bias), dec.conv_norm_out.eps)
+    pk["cout"] = (packing.pack_conv3x3(dec.conv_out.weight), packing.pad_bias(dec.conv_out.bias), dec.conv_out.weight.shape[0])
+    _CACHE[key] = (ver, weakref.ref(dec), pk)
+    return pk
+
+
+def _rows(M, C, dev):
+    return torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+
+
+class _Scratch:
+    """GroupNorm partial-sum scratch, grown on demand (one buffer per decode call)."""
+
+    def __init__(self, dev):
+        self.buf, self.dev = None, dev
+
+    def get(self, n_img, S, C, ips):
+        need = ops.groupnorm_scratch_floats(n_img, S, C, ips)
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(max(need, 1 << 18), dtype=torch.float32, device=self.dev)
+        return self.buf
+
+
+def _res(pk, x, n, H, W, sc):
+    """SpatioTemporalResBlock of the VAE (no time embedding): rows [n*H*W, cin] -> [.., cout]; n frames = one clip."""
+    S, M = H * W, n * H * W
+    cin, cout, dev = pk["cin"], pk["cout"], x.device
+    geo = (H, W, H, W, 1, 0)
+    xn = _rows(M, cin, dev)
+    ops.groupnorm(x, None, n, S, cin, 1, pk["g1"], pk["b1"], pk["eps_s"], True, xn, sc.get(n, S, cin, 1))
+    h = _rows(M, cout, dev)
+    ops.gemm(xn, pk["w1"], h, N=cout, cin=cin, taps=9, mode=1, conv=geo, bias=pk["cb1"])
+    del xn
+    hn = _rows(M, cout, dev)
+    ops.groupnorm(h, None, n, S, cout, 1, pk["g2"], pk["b2"], pk["eps_s"], True, hn, sc.get(n, S, cout, 1))
+    if "wsc" in pk:
+        res = _rows(M, cout, dev)
+        ops.gemm(x, pk["wsc"], res, N=cout, cin=cin, bias=pk["bsc"])
+    else:
+        res = x
+    xs = _rows(M, cout, dev)
+    ops.gemm(hn, pk["w2"], xs, N=cout, cin=cout, taps=9, mode=1, conv=geo, bias=pk["cb2"], R1=res)
+    del res
+    # temporal res block on (1, C, n, H, W): GroupNorm statistics over (C/32, n, H, W), conv along the frames
+    ops.groupnorm(xs, None, n, S, cout, n, pk["tg1"], pk["tb1"], pk["eps_t"], True, hn, sc.get(n, S, cout, n))
+    ops.gemm(hn, pk["tw1"], h, N=cout, cin=cout, taps=3, mode=2, temporal=(n, S), bias=pk["tcb1"])
+    ops.groupnorm(h, None, n, S, cout, n, pk["tg2"], pk["tb2"], pk["eps_t"], True, hn, sc.get(n, S, cout, n))
+    out = h
+    ops.gemm(hn, pk["tw2"], out, N=cout, cin=cout, taps=3, mode=2, temporal=(n, S), bias=pk["tcb2"], s_acc=pk["mix"], R1=xs)
+    return out
+
+
+def _attn(pk, x, n, H, W, sc):
+    """VAE mid-block attention: GroupNorm -> q, k, v (bias) -> softmax(q k^T / sqrt(d)) v per frame -> to_out -> + x."""
+    S, M, C, dev = H * W, n * H * W, x.shape[1], x.device
+    t = _rows(M, C, dev)
+    ops.groupnorm(x, None, n, S, C, 1, pk["g"], pk["b"], pk["eps"], False, t, sc.get(n, S, C, 1))
+    qkv = _rows(M, 3 * C, dev)
+    ops.gemm(t, pk["wqkv"], qkv, N=3 * C, cin=C, bias=pk["bqkv"])
+    heads = pk["heads"]
+    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(n, S, heads, C // heads).transpose(1, 2) for i in range(3))
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(M, C).contiguous()
+    out = _rows(M, C, dev)
+    ops.gemm(o, pk["wo"], out, N=C, cin=C, bias=pk["bo"], R1=x)
+    return out
+
+
+def supports(z, num_frames):
+    """Shapes the HIP decoder takes: bf16/fp16/fp32 CUDA latents, every intermediate tensor below 4 GiB."""
+    if not z.is_cuda or z.dim() != 4 or z.shape[0] % num_frames:
+        return False
+    H, W = z.shape[2] * 8, z.shape[3] * 8
+    return num_frames * H * W * 256 * 2 < (1 << 32) - (1 << 24)
+
+
+@torch.no_grad()
+def decode(dec, z, num_frames):
+    """dec: `TemporalDecoder` module (parameters on the device); z: (n, 4, h, w) latents already divided by the scaling
+    factor; num_frames = frames per clip in z (the reference passes the chunk length).  Returns (n, 3, 8h, 8w) in z.dtype."""
+    n_tot, _, h, w = z.shape
+    if n_tot % num_frames:
+        raise ValueError(f"decode: {n_tot} latent frames are not a multiple of num_frames={num_frames}")
+    if not supports(z, num_frames):
+        raise ValueError(f"HIP VAE decode: a clip of {num_frames} frames at {8 * h}x{8 * w} exceeds the 4 GiB tensor limit "
+                         "(use decode_chunk_size <= 14 at 576x1024)")
+    outs = []
+    for c0 in range(0, n_tot, num_frames):                     # independent clips
+        outs.append(_decode_clip(dec, z[c0:c0 + num_frames]))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+def _decode_clip(dec, z):
+    pk = _pack(dec)
+    n, cz, H, W = z.shape
+    dev = z.device
+    sc = _Scratch(dev)
+    M = n * H * W
+    cp, kp, wci, bci = pk["cin"]
+    x16 = torch.zeros(M, cp, dtype=torch.bfloat16, device=dev)
+    ops.nchw_to_rows(z.contiguous(), x16, 0)
+    col = _rows(M, kp, dev)
+    ops.im2col3x3(x16, n, H, W, col)
+    x = _rows(M, wci.shape[0], dev)
+    ops.gemm(col, wci, x, N=wci.shape[0], cin=kp, bias=bci)
+    del col, x16
+    x = _res(pk["mid_res"][0], x, n, H, W, sc)
+    for rp in pk["mid_res"][1:]:
+        x = _attn(pk["attn"], x, n, H, W, sc)
+        x = _res(rp, x, n, H, W, sc)
+    for res_list, up in pk["up"]:
+        for rp in res_list:
+            x = _res(rp, x, n, H, W, sc)
+        if up is not None:
+            C = x.shape[1]
+            y = _rows(n * 4 * H * W, C, dev)
+            ops.gemm(x, up[0], y, N=C, cin=C, taps=9, mode=1, conv=(H, W, 2 * H, 2 * W, 1, 1), bias=up[1])
+            x, H, W = y, 2 * H, 2 * W
+    M, C = n * H * W, x.shape[1]
+    g, b, eps = pk["gno"]
+    xn = _rows(M, C, dev)
+    ops.groupnorm(x, None, n, H * W, C, 1, g, b, eps, True, xn, sc.get(n, H * W, C, 1))
+    del x
+    wco, bco, co = pk["cout"]
+    co_p = (co + 3) // 4 * 4
+    y = _rows(M, co_p, dev)
+    ops.gemm(xn, wco, y, N=wco.shape[0], cin=C, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=bco, n_store=co_p)
+    del xn
+    frames = torch.empty(n, co, H, W, dtype=torch.float32, device=dev)
+    ops.rows_to_nchw(y, frames)
+    # time_conv_out: Conv3d(co, co, (3, 1, 1), padding (1, 0, 0)) over the clip's frames -- three 3x3 channel mixes
+    wt = dec.time_conv_out.weight.detach().float()[:, :, :, 0, 0]           # [o, c, t]
+    out = dec.time_conv_out.bias.detach().float().view(1, co, 1, 1).expand(n, co, H, W).clone()
+    for t in range(3):
+        lo, hi = max(0, 1 - t), min(n, n + 1 - t)                           # output frames whose tap t is inside the clip
+        if hi > lo:
+            out[lo:hi] += torch.einsum("oc,fchw->fohw", wt[:, :, t], frames[lo + t - 1:hi + t - 1])
+    return out.to(z.dtype)
