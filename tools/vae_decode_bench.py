@@ -18,6 +18,16 @@ def main():
     dt = torch.float16 if "--fp16" in sys.argv else torch.bfloat16
     vae = AutoencoderKLTemporalDecoder().to(dev, dt).eval()
     lat = torch.randn(25, 4, 72, 128, device=dev, dtype=dt)
+    if "--encode" in sys.argv:          # the once-per-clip encode of the 25 bbox frames (pipeline_video_control.py:71-101)
+        img = torch.randn(25, 3, 576, 1024, device=dev, dtype=dt)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            with torch.no_grad():
+                out = [vae.encode(img[i:i + 5]).latent_dist.mode() for i in range(0, 25, 5)]
+            torch.cuda.synchronize()
+            print(f"  encode pass {rep}: {time.time() - t0:.2f} s for 25 frames, latents {tuple(torch.cat(out).shape)}", flush=True)
+        return
     for chunk in ([int(a) for a in sys.argv[1:] if a.isdigit()] or [8, 14, 25]):
         for rep in range(2):            # first pass: MIOpen kernel search
             torch.cuda.synchronize()
