@@ -254,7 +254,7 @@ class AutoencoderKLTemporalDecoder(HipModelMixin):
         from . import vae_decoder_hip as vh
         import os
         if (os.environ.get("CTRLV_VAE_HIP", "1") != "0" and z.is_cuda and not torch.is_grad_enabled()
-                and vh.supports(z, num_frames)):
+                and vh.supports(z, num_frames, self.decoder)):
             sample = vh.decode(self.decoder, z, num_frames)
         else:
             sample = self.decoder(z, num_frames)

@@ -141,12 +141,20 @@ def _attn(pk, x, n, H, W, sc):
     return out
 
 
-def supports(z, num_frames):
-    """Shapes the HIP decoder takes: bf16/fp16/fp32 CUDA latents, every intermediate tensor below 4 GiB."""
+def supports(z, num_frames, dec=None):
+    """Shapes the HIP decoder takes: bf16/fp16/fp32 CUDA latents, every intermediate tensor below 4 GiB, channel counts
+    that are multiples of 64 (GEMM K granularity; the SVD VAE has 128 / 256 / 512)."""
     if not z.is_cuda or z.dim() != 4 or z.shape[0] % num_frames:
         return False
-    H, W = z.shape[2] * 8, z.shape[3] * 8
-    return num_frames * H * W * 256 * 2 < (1 << 32) - (1 << 24)
+    cmax = 256
+    if dec is not None:
+        chans = [m.weight.shape[0] for m in dec.modules() if isinstance(m, torch.nn.Conv2d) and m is not dec.conv_out]
+        if any(c % 64 for c in chans) or len(dec.mid_block.attentions) != 1:
+            return False
+        cmax = max(dec.up_blocks[-1].resnets[0].spatial_res_block.conv1.weight.shape[1], 1)
+    up = 2 ** (len(dec.up_blocks) - 1) if dec is not None else 8
+    H, W = z.shape[2] * up, z.shape[3] * up
+    return num_frames * H * W * cmax * 2 < (1 << 32) - (1 << 24)
 
 
 @torch.no_grad()
@@ -156,7 +164,7 @@ def decode(dec, z, num_frames):
     n_tot, _, h, w = z.shape
     if n_tot % num_frames:
         raise ValueError(f"decode: {n_tot} latent frames are not a multiple of num_frames={num_frames}")
-    if not supports(z, num_frames):
+    if not supports(z, num_frames, dec):
         raise ValueError(f"HIP VAE decode: a clip of {num_frames} frames at {8 * h}x{8 * w} exceeds the 4 GiB tensor limit "
                          "(use decode_chunk_size <= 14 at 576x1024)")
     outs = []
