@@ -234,13 +234,14 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // (profiles/r02_gemm_streamed_ab.txt).
     static const bool use_st = [] { const char* e = getenv("CTRLV_GEMM_ST"); return e && atoi(e) != 0; }();
     if (!big) tile = 1;
+    else if (d.N <= 128 && d.mode != 0) tile = 10;     // 256x128 ping-pong tile (profiles/r02_vae_decode.txt)
     else if (use_st && d.geglu && d.Cin <= 320 && d.N % 160 == 0 && d.M >= 16384 && ctrlv_gemm_st_supports(d)) tile = 9;
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
   if (d.raw_out) {      // second output of the GEGLU projection (training forward): ping-pong tiles only
     CTRLV_CHECK_ARG(d.geglu && d.ld_raw >= d.N, "ctrlv_gemm: raw_out needs geglu = 1 and ld_raw >= N");
-    if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;
+    if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;   // (9, 10 do not write raw_out)
     CTRLV_CHECK_SHAPE(ctrlv_gemm_pp_supports(d), "ctrlv_gemm: raw_out needs a shape the ping-pong tiles serve (K >= 128, "
                                                  "ld_raw a multiple of 8)");
   }
@@ -264,6 +265,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 6:
     case 8: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 9: return ctrlv_gemm_launch_st(d, stream);
+    case 10: return ctrlv_gemm_launch_pp(d, tile, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }
   return CTRLV_OK;

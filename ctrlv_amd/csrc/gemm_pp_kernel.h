@@ -379,6 +379,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
   constexpr bool UNEVEN = (B_TOT % NW) != 0;
   constexpr int BIAS_OFF = NH * SLOT, DUMMY_OFF = BIAS_OFF + NW * WTN * 4;
+  // The epilogue stages through FOUR wave-private 1-KiB pieces: the wave's two A pieces and two B pieces of the slot
+  // consumed last.  A 128-wide tile has only one B piece per wave: its fourth piece is a private strip behind the ring.
+  constexpr bool OWN_P3 = B_TOT < 2 * NW;
+  constexpr int P3_OFF = DUMMY_OFF + (UNEVEN ? NW * 1024 : 0);
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | 8 dummy pieces
 
@@ -743,7 +747,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       u32x4_t nb = {0, 0, 0, 0};
       if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
       gemm_epilogue_lds<TM, TN, GEGLU, EPI, true, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
-                                s0 + A_SLOT + wid * 1024, s0 + A_SLOT + (NW + wid) * 1024, bias_lds);
+                                s0 + A_SLOT + wid * 1024,
+                                OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds);
       if (refill) pp_bias_store<WTN>(bias_lds, nb, lane);
       // The accumulators are dead here -- the next tile's first MFMAs overwrite them from a literal-zero C operand --
       // but that redefinition sits behind a `j == 0` test inside the K loop, so the compiler would keep all 128-160
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
-  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0);
+  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0) + ((BN / 16) < 16 ? 8 * 1024 : 0);
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW>;

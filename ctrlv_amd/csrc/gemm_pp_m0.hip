@@ -30,11 +30,16 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
 }
 
 // tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
-// workgroup per output tile instead of one persistent workgroup per CU.
+// workgroup per output tile instead of one persistent workgroup per CU; tile 10: 256x128 (waves 4x2; 3x3 and temporal
+// convs with N <= 128 -- on the 256-wide tile half of every MFMA would be padding).
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
-  const bool persistent = tile <= 6;
+  const bool persistent = tile <= 6 || tile == 10;
   if (d.mode == 1) return ctrlv_gemm_launch_pp_conv(d, tile, persistent, stream);
   if (d.mode == 2) return ctrlv_gemm_launch_pp_temporal(d, tile, persistent, stream);
+  if (tile == 10) {
+    ctrlv_set_error("ctrlv_gemm: tile 10 (256x128) is instantiated for the 3x3 and temporal convs only");
+    return CTRLV_E_BAD_ARG;
+  }
   if (d.geglu) {
     if (d.raw_out) {      // training forward: the raw projection is written too
       if (tile == 5 || tile == 7) return launch_one<256, 2, 4, 0, true, 0, false, true>(d, persistent, stream);

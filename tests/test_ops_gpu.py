@@ -111,7 +111,7 @@ def test_gemm_geglu(ops, tile):
     assert parity_err(out, ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 10])
 @pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
 def test_gemm_conv3x3(ops, tile, stride, up):
     from ctrlv_amd import packing
@@ -131,7 +131,7 @@ def test_gemm_conv3x3(ops, tile, stride, up):
     assert parity_err(nchw_from_rows(out.cpu(), n, Ho, Wo), ref) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [1, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 4, 5, 6, 10])
 def test_gemm_temporal_conv(ops, tile):
     from ctrlv_amd import packing
     B, Fr, C, H, W = 2, 5, 64, 4, 6
@@ -174,7 +174,7 @@ def test_gemm_concat_split(ops, tile):
     assert parity_err(nchw_from_rows(outc.cpu(), n, H, W), refc) < 3e-3
 
 
-@pytest.mark.parametrize("tile", [5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [5, 6, 7, 8, 10])
 def test_gemm_persistent_many_tiles(ops, tile):
     """More output tiles than CUs: every persistent workgroup walks several tiles and the LDS-DMA ring runs through the
     tile boundaries (ragged last M tile, conv halo rows, 2 N tiles for the 256-wide tile)."""
@@ -188,6 +188,8 @@ def test_gemm_persistent_many_tiles(ops, tile):
     ops.gemm(rows_from_nchw(x).to(DEV), packing.pack_conv3x3(wt).to(DEV), out, N=cout, cin=cin, taps=9, mode=1,
              conv=(H, W, H, W, 1, 0), bias=b.to(DEV), tile=tile)
     assert parity_err(nchw_from_rows(out.cpu(), n, H, W), ref) < 3e-3
+    if tile == 10:          # the 256x128 tile is instantiated for the convs only
+        return
     # shortest K the ping-pong tiles take (4 half-steps per tile: the ring always holds pieces of two tiles at once)
     M = 86400
     A = bf(torch.randn(M, 128, generator=g(4)))
