@@ -208,6 +208,9 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
     }
     s->rows_per_chunk = S >= 4096 ? rpc_big : (S >= 1024 ? 64 : 32);
   }
+  // very large images (the VAE decoder: up to 576 x 1024 pixels per frame): at most 256 chunks per image, so that the
+  // finalize pass (one workgroup per statistics row) does not walk tens of thousands of partials
+  if ((S + s->rows_per_chunk - 1) / s->rows_per_chunk > 256) s->rows_per_chunk = (((S + 255) / 256) + 255) / 256 * 256;
   if (s->rows_per_chunk > S) s->rows_per_chunk = S;
   s->n_chunks = (S + s->rows_per_chunk - 1) / s->rows_per_chunk;
   return CTRLV_OK;
