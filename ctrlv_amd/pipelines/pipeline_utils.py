@@ -19,6 +19,11 @@ import torch.nn.functional as Fnn
 
 from .. import ops
 
+# The VAE encoder / CLIP run through MIOpen.  Its default find mode benchmarks every solver the first time a conv shape is
+# seen -- minutes for the 576x1024 VAE shapes on this stack (tools/vae_decode_bench.py) -- for kernels that run once per
+# clip; the heuristic ("FAST") choice costs milliseconds.  Only a default: an exported MIOPEN_FIND_MODE wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 try:                                  # PIL is optional: tensors are the primary input type
     import PIL.Image
 except Exception:                     # pragma: no cover
