@@ -243,7 +243,14 @@ class AutoencoderKLTemporalDecoder(HipModelMixin):
         self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
 
     def encode(self, x, return_dict=True):
-        dist = DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
+        import os
+        from . import vae_encoder_hip as ve
+        if (os.environ.get("CTRLV_VAE_HIP", "1") != "0" and x.is_cuda and not torch.is_grad_enabled()
+                and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and ve.supports(x, self.encoder)):
+            moments = ve.encode(self.encoder, x)           # HIP kernels (vae_encoder_hip.py)
+        else:
+            moments = self.encoder(x)
+        dist = DiagonalGaussianDistribution(self.quant_conv(moments))
         return types.SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
     def decode(self, z, num_frames, return_dict=True):

@@ -57,3 +57,24 @@ def test_vae_decode_two_clips_and_limits(vae):
     assert not vh.supports(big, 25) and vh.supports(big[:14], 14)
     with pytest.raises(ValueError):
         vh.decode(dev_vae.decoder, big, 25)
+
+
+@pytest.mark.parametrize("n,H,W", [(2, 128, 192), (1, 64, 64)])
+def test_vae_encode_hip_matches_torch_module(vae, n, H, W):
+    """Encoder on the HIP kernels (asymmetric-padding down-samplers as stride-1 conv + odd-position subsampling) against the
+    torch module in fp32; also through `AutoencoderKLTemporalDecoder.encode(...).latent_dist.mode()`."""
+    import copy
+    from ctrlv_amd.models import vae_encoder_hip as ve
+    x = (torch.rand(n, 3, H, W, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref_m = vae.encoder(x)
+        ref_lat = vae.encode(x).latent_dist.mode()
+    dev_vae = copy.deepcopy(vae).to(DEV, torch.bfloat16)
+    xd = x.to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        got_m = ve.encode(dev_vae.encoder, xd)
+        got_lat = dev_vae.encode(xd).latent_dist.mode()
+    torch.cuda.synchronize()
+    assert got_m.shape == (n, 8, H // 8, W // 8) and got_lat.shape == (n, 4, H // 8, W // 8)
+    assert parity_err(got_m.float().cpu(), ref_m, "vae encoder moments") < 2.5e-2
+    assert parity_err(got_lat.float().cpu(), ref_lat, "vae latents (mode)") < 2.5e-2

@@ -24,7 +24,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.time()
             with torch.no_grad():
-                out = [vae.encode(img[i:i + 5]).latent_dist.mode() for i in range(0, 25, 5)]
+                out = [vae.encode(img).latent_dist.mode()]           # all 25 frames at once, as the pipeline does
             torch.cuda.synchronize()
             print(f"  encode pass {rep}: {time.time() - t0:.2f} s for 25 frames, latents {tuple(torch.cat(out).shape)}", flush=True)
         return
