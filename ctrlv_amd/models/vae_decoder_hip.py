@@ -13,8 +13,9 @@ projections are HIP GEMMs, the core is torch SDPA.  `time_conv_out` (3 -> 3 chan
 The parameters stay in the `AutoencoderKLTemporalDecoder` module (diffusers state-dict layout); this file only executes
 them.  Packed weights are cached per decoder object (the VAE is frozen).  Activations are channels-last bf16 rows
 [n_frames * H * W, C]; a chunk of n frames is ONE clip of n frames for the temporal blocks, exactly as the reference's
-chunked decode treats it.  Limit: tensors are addressed with 32-bit byte offsets, i.e. n * 576 * 1024 * 256 channels * 2 B
-< 4 GiB -> chunks of at most 14 frames at 576x1024 (the reference scripts use 8); larger chunks raise.
+chunked decode treats it.  Limit: tensors are addressed with 32-bit byte offsets.  Per-frame ops run on frame ranges
+(pointer-offset views) when a tensor is larger; the whole-clip tensors of the temporal halves (128 channels at
+576x1024) must fit: at most 28 frames per chunk there (the reference scripts use 8, the pipeline default is all 25).
 """
 import math
 
@@ -97,26 +98,37 @@ class _Scratch:
         return self.buf
 
 
+_LIMIT = (1 << 32) - (1 << 24)        # the kernels address a tensor with 32-bit byte offsets
+
+
+def _frame_batches(n, S, C):
+    """Frame ranges whose [frames * S, C] bf16 slice stays below the 32-bit offset limit (per-frame ops only)."""
+    per = max(1, min(n, _LIMIT // (S * C * 2)))
+    return [(f0, min(n, f0 + per)) for f0 in range(0, n, per)]
+
+
 def _res(pk, x, n, H, W, sc):
-    """SpatioTemporalResBlock of the VAE (no time embedding): rows [n*H*W, cin] -> [.., cout]; n frames = one clip."""
+    """SpatioTemporalResBlock of the VAE (no time embedding): rows [n*H*W, cin] -> [.., cout]; n frames = one clip.
+    The spatial half is per frame, so a tensor above 4 GiB (256 channels at 576x1024 with more than 14 frames) is
+    processed in frame ranges through pointer-offset views; the temporal half needs the whole clip (its tensors have
+    `cout` channels: 128 there)."""
     S, M = H * W, n * H * W
     cin, cout, dev = pk["cin"], pk["cout"], x.device
     geo = (H, W, H, W, 1, 0)
     xn = _rows(M, cin, dev)
-    ops.groupnorm(x, None, n, S, cin, 1, pk["g1"], pk["b1"], pk["eps_s"], True, xn, sc.get(n, S, cin, 1))
     h = _rows(M, cout, dev)
-    ops.gemm(xn, pk["w1"], h, N=cout, cin=cin, taps=9, mode=1, conv=geo, bias=pk["cb1"])
-    del xn
     hn = _rows(M, cout, dev)
-    ops.groupnorm(h, None, n, S, cout, 1, pk["g2"], pk["b2"], pk["eps_s"], True, hn, sc.get(n, S, cout, 1))
-    if "wsc" in pk:
-        res = _rows(M, cout, dev)
-        ops.gemm(x, pk["wsc"], res, N=cout, cin=cin, bias=pk["bsc"])
-    else:
-        res = x
+    res = _rows(M, cout, dev) if "wsc" in pk else x
     xs = _rows(M, cout, dev)
-    ops.gemm(hn, pk["w2"], xs, N=cout, cin=cout, taps=9, mode=1, conv=geo, bias=pk["cb2"], R1=res)
-    del res
+    for f0, f1 in _frame_batches(n, S, max(cin, cout)):
+        r0, r1, k = f0 * S, f1 * S, f1 - f0
+        ops.groupnorm(x[r0:r1], None, k, S, cin, 1, pk["g1"], pk["b1"], pk["eps_s"], True, xn[r0:r1], sc.get(k, S, cin, 1))
+        ops.gemm(xn[r0:r1], pk["w1"], h[r0:r1], N=cout, cin=cin, taps=9, mode=1, conv=geo, bias=pk["cb1"])
+        ops.groupnorm(h[r0:r1], None, k, S, cout, 1, pk["g2"], pk["b2"], pk["eps_s"], True, hn[r0:r1], sc.get(k, S, cout, 1))
+        if "wsc" in pk:
+            ops.gemm(x[r0:r1], pk["wsc"], res[r0:r1], N=cout, cin=cin, bias=pk["bsc"])
+        ops.gemm(hn[r0:r1], pk["w2"], xs[r0:r1], N=cout, cin=cout, taps=9, mode=1, conv=geo, bias=pk["cb2"], R1=res[r0:r1])
+    del xn, res
     # temporal res block on (1, C, n, H, W): GroupNorm statistics over (C/32, n, H, W), conv along the frames
     ops.groupnorm(xs, None, n, S, cout, n, pk["tg1"], pk["tb1"], pk["eps_t"], True, hn, sc.get(n, S, cout, n))
     ops.gemm(hn, pk["tw1"], h, N=cout, cin=cout, taps=3, mode=2, temporal=(n, S), bias=pk["tcb1"])
@@ -146,15 +158,15 @@ def supports(z, num_frames, dec=None):
     that are multiples of 64 (GEMM K granularity; the SVD VAE has 128 / 256 / 512)."""
     if not z.is_cuda or z.dim() != 4 or z.shape[0] % num_frames:
         return False
-    cmax = 256
+    # whole-clip tensors (the temporal halves): `cout` channels of every up block at its resolution
+    levels = [(512, 1), (512, 2), (256, 4), (128, 8)]
     if dec is not None:
         chans = [m.weight.shape[0] for m in dec.modules() if isinstance(m, torch.nn.Conv2d) and m is not dec.conv_out]
         if any(c % 64 for c in chans) or len(dec.mid_block.attentions) != 1:
             return False
-        cmax = max(dec.up_blocks[-1].resnets[0].spatial_res_block.conv1.weight.shape[1], 1)
-    up = 2 ** (len(dec.up_blocks) - 1) if dec is not None else 8
-    H, W = z.shape[2] * up, z.shape[3] * up
-    return num_frames * H * W * cmax * 2 < (1 << 32) - (1 << 24)
+        levels = [(blk.resnets[0].spatial_res_block.conv1.weight.shape[0], 2 ** i) for i, blk in enumerate(dec.up_blocks)]
+    h, w = z.shape[2], z.shape[3]
+    return all(num_frames * h * w * f * f * c * 2 < _LIMIT for c, f in levels)
 
 
 @torch.no_grad()
@@ -166,7 +178,7 @@ def decode(dec, z, num_frames):
         raise ValueError(f"decode: {n_tot} latent frames are not a multiple of num_frames={num_frames}")
     if not supports(z, num_frames, dec):
         raise ValueError(f"HIP VAE decode: a clip of {num_frames} frames at {8 * h}x{8 * w} exceeds the 4 GiB tensor limit "
-                         "(use decode_chunk_size <= 14 at 576x1024)")
+                         "(at most 28 frames per chunk at 576x1024)")
     outs = []
     for c0 in range(0, n_tot, num_frames):                     # independent clips
         outs.append(_decode_clip(dec, z[c0:c0 + num_frames]))
@@ -197,7 +209,9 @@ def _decode_clip(dec, z):
         if up is not None:
             C = x.shape[1]
             y = _rows(n * 4 * H * W, C, dev)
-            ops.gemm(x, up[0], y, N=C, cin=C, taps=9, mode=1, conv=(H, W, 2 * H, 2 * W, 1, 1), bias=up[1])
+            for f0, f1 in _frame_batches(n, 4 * H * W, C):                 # per-frame op: ranges below 4 GiB
+                ops.gemm(x[f0 * H * W:f1 * H * W], up[0], y[f0 * 4 * H * W:f1 * 4 * H * W], N=C, cin=C, taps=9, mode=1,
+                         conv=(H, W, 2 * H, 2 * W, 1, 1), bias=up[1])
             x, H, W = y, 2 * H, 2 * W
     M, C = n * H * W, x.shape[1]
     g, b, eps = pk["gno"]

@@ -53,10 +53,20 @@ def test_vae_decode_two_clips_and_limits(vae):
         both = vh.decode(dev_vae.decoder, z, 2)
         first, second = vh.decode(dev_vae.decoder, z[:2], 2), vh.decode(dev_vae.decoder, z[2:], 2)
     assert torch.equal(both, torch.cat([first, second]))
-    big = torch.empty(25, 4, 72, 128, device=DEV, dtype=torch.bfloat16)
-    assert not vh.supports(big, 25) and vh.supports(big[:14], 14)
+    big = torch.empty(30, 4, 72, 128, device=DEV, dtype=torch.bfloat16)
+    assert not vh.supports(big, 30) and vh.supports(big[:25], 25) and vh.supports(big[:25], 25, dev_vae.decoder)
     with pytest.raises(ValueError):
-        vh.decode(dev_vae.decoder, big, 25)
+        vh.decode(dev_vae.decoder, big, 30)
+    # frame-range path of the per-frame ops (forced by a tiny limit): identical bits to the whole-clip launches
+    ref = vh.decode(dev_vae.decoder, z[:3], 3)
+    old = vh._LIMIT
+    try:
+        vh._LIMIT = 3 * 64 * 64 * 128 * 2 + 1          # the clip's 128-channel tensors fit, its 256-channel ones do not
+        assert len(vh._frame_batches(3, 64 * 64, 256)) == 3
+        got = vh.decode(dev_vae.decoder, z[:3], 3)
+    finally:
+        vh._LIMIT = old
+    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("n,H,W", [(2, 128, 192), (1, 64, 64)])
