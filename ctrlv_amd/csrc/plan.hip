@@ -52,16 +52,23 @@ __global__ void pack_weight_kernel(const void* __restrict__ src, int dtype, int 
 }
 // Role-swapped (dgrad) form of a weight: dst[c][(taps - 1 - tap) * Np + n] = src[(n * C + c) * taps + tap]  -- taps
 // reversed, output and input channels transposed (autograd.py::gemm_grads); columns n in [N, Np) are zeros.
-// grid (ceil(taps * Np / 256), C)
-__global__ void pack_weight_swapped_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps, int Np,
-                                           bf16_t* __restrict__ dst, int ld) {
-  const int c = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;       // column of dst: tapd * Np + n
-  if (k >= taps * Np) return;
-  const int tapd = k / Np, n = k - tapd * Np;
-  float v = 0.f;
-  if (n < N) v = ld_any(src, dtype, ((long)n * C + c) * taps + (taps - 1 - tapd));
-  dst[(long)c * ld + k] = f32_to_bf16(v);
+// A transpose: 32 output rows n x 64 consecutive (c, tap) source elements per workgroup go through LDS, so that reads are
+// contiguous along a source row and writes are 32 consecutive n (64 B) per (c, tap).   grid (ceil(C*taps/64), ceil(Np/32))
+__global__ __launch_bounds__(256) void pack_weight_swapped_kernel(const void* __restrict__ src, int dtype, int N, int C,
+                                                                  int taps, int Np, bf16_t* __restrict__ dst, int ld) {
+  __shared__ float tile[32][65];
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 32, ktot = C * taps;
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+    const int r = i >> 6, kk = i & 63, n = n0 + r, k = k0 + kk;
+    tile[r][kk] = (n < N && k < ktot) ? ld_any(src, dtype, (long)n * ktot + k) : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int kk = i >> 5, r = i & 31, k = k0 + kk, n = n0 + r;
+    if (k >= ktot || n >= Np) continue;
+    const int c = k / taps, tap = k - c * taps;
+    dst[(long)c * ld + (long)(taps - 1 - tap) * Np + n] = f32_to_bf16(tile[r][kk]);
+  }
 }
 // Forward form with coalesced writes: dst[rowmap(n)][tap * C + c] = src[(n * C + c) * taps + tap]   grid (ceil(taps*C/256), N)
 __global__ void pack_weight_rows_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps,
@@ -915,8 +922,8 @@ extern "C" int ctrlv_pack_weight(const void* src, int src_dtype, int N, int C, i
   } else {
     CTRLV_CHECK_SHAPE(ld_dst % taps == 0 && ld_dst / taps >= N && !geglu, "pack_weight: ld_dst must be taps * Np, Np >= N");
     const int Np = ld_dst / taps;
-    hipLaunchKernelGGL(pack_weight_swapped_kernel, dim3((taps * Np + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, src,
-                       src_dtype, N, C, taps, Np, (bf16_t*)dst, ld_dst);
+    hipLaunchKernelGGL(pack_weight_swapped_kernel, dim3((taps * C + 63) / 64, (Np + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, src, src_dtype, N, C, taps, Np, (bf16_t*)dst, ld_dst);
   }
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
