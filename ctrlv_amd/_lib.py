@@ -24,6 +24,7 @@ class GemmDesc(ctypes.Structure):
         ("vmode", c_int), ("vdiv", c_int), ("vmod", c_int), ("vS", c_int), ("ldv", c_int),
         ("act", c_int), ("geglu", c_int), ("out_f32", c_int), ("tile", c_int),
         ("ld_raw", c_int), ("raw_out", c_void_p),
+        ("n_scale2", c_int), ("s_acc2", c_float),
     ]
 
 
@@ -54,7 +55,6 @@ SIGNATURES = {
     "ctrlv_build_id": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
-    "ctrlv_gemm_st_occupancy": (c_int, []),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p]),
@@ -63,6 +63,7 @@ SIGNATURES = {
     "ctrlv_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ctrlv_attention_spatial_prescaled": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_spatial_lse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_bwd_scratch_floats": (ctypes.c_size_t, [c_int, c_int, c_int]),
@@ -105,7 +106,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CtrlvHipError(RuntimeError):
@@ -173,6 +174,6 @@ def check(rc, what):
     if rc == 0:
         return
     msg = f"{what}: {last_error()} (status {rc})"
-    if rc in (-1, -2):
+    if rc in (-1, -2, -4, -5):     # bad argument / shape / dtype / workspace size
         raise ValueError(msg)
     raise CtrlvHipError(msg)

@@ -50,6 +50,16 @@ __device__ __forceinline__ int v_off(int key, int d) {
   return key * 128 + chunk * 16 + (d & 7) * 2;
 }
 
+// D = A.B + C with D and C in DIFFERENT registers (C stays live).  hipcc selects the accumulate-in-place form of the
+// MFMA and copies C into D first (16 v_mov_b64 per 64-key tile when C is the kept -m block of attn_spatial64_kernel),
+// so this one instruction is written out.  Hazards: A / B / C are not written inside the statement; the consumer of D is
+// the next MFMA of the same accumulation chain (C operand, same registers: no wait states needed).
+__device__ __forceinline__ f32x16 mfma_keep_c(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  f32x16 d;
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
   bf16x8 r;
 #pragma unroll
@@ -60,7 +70,8 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 // ---------------------------------------------------------------------------------------------- spatial
 // launch_bounds(256, 2): a 256-register budget makes hipcc keep the score / output accumulators in arch VGPRs; with the
 // default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
-template <int NSLOT>
+// PRE: q arrives pre-scaled by (1/8) log2(e) (see attn_spatial64_kernel); here that only changes the constant.
+template <int NSLOT, bool PRE>
 __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 3 x (K 8 KiB | V 8 KiB) ring
@@ -71,8 +82,7 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   const long row0 = (long)img * S;
   const int ld = 3 * C;
   const bf16_t* qp = qkv + head * 64;
-  const bf16_t* kp = qp + C;
-  const bf16_t* vp = qp + 2 * C;
+  constexpr float kScale = PRE ? 1.0f : kScaleLog2;
 
   const int qrow = blockIdx.x * 128 + wid * 32 + r32;
   bf16x8 qf[4];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 #if CTRLV_ATTN_DBG == 3          // diagnostic build (timing only): no softmax arithmetic
         f32x2_t pe = x;
 #else
-        x = x * kScaleLog2 + nm;
+        x = x * kScale + nm;
         f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
 #endif
         sacc[kt][e] = pe.x;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
-      mx = half_max(mx) * kScaleLog2;
+      mx = half_max(mx) * kScale;
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -277,24 +287,20 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 // LDS feeds two MFMAs, the per-tile loop / DMA / barrier overhead is shared by 32 MFMAs instead of 16, and a wave
 // carries four independent accumulator chains.  The spatial kernel is bound by instruction issue around the MFMAs
 // (SQ counters: MFMA busy 36 %, LDS and VMEM waits negligible; no-traffic diagnostic build only +10 %), so fewer
-// instructions per MFMA is what moves it.  ~200 VGPRs => 2 waves per SIMD.
-// PIPE (experiment, off by default; CTRLV_ATTN_PIPE=1): the two 32-row blocks of a wave run SKEWED by half a tile inside
-// one instruction stream --
-//     K.Q^T(rb0) | K.Q^T(rb1) + softmax(rb0) | P.V(rb0) + softmax(rb1) | P.V(rb1)
-// so that the wave's own softmax VALU work (64 v_exp + ~90 other per 64-key tile) issues in the shadow of its own MFMAs
-// instead of after them: the un-skewed order is [16 MFMA][~190 VALU][16 MFMA] per tile, and with only two waves per
-// SIMD the matrix pipe idles whenever both are in their VALU phase (MFMA busy 36-40 %).  sched_group_barrier pins the
-// MFMA : VALU interleave (the machine scheduler otherwise clusters the MFMAs again).
-// MEASURED on MI355X (tools/attn_bench.py, S = 9216): 5.87 ms against 5.56 ms for the un-skewed order -- the forced
-// interleave costs ~120 more instructions per tile (K fragments read twice, hazard s_nops between transcendental and
-// dependent VALU, per-block slow-path tests) and the two waves of a SIMD already overlap each other's phases to the same
-// degree.  Kept as a documented negative result and A/B handle.
-template <bool PIPE>
-#ifndef CTRLV_ATTN_OCC
-#define CTRLV_ATTN_OCC 2
-#endif
-__global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              float* __restrict__ lse, int S, int C, int phase_delay) {
+// instructions per MFMA is what moves it.  2 waves per SIMD.
+//
+// PRE (round 3): the caller's q columns are PRE-SCALED by (1/sqrt(64)) * log2(e) -- the fused q|k|v projection applies
+// that factor to its q column block in its fp32 epilogue, before the one bf16 rounding (ctrlv_gemm_desc.s_acc2), so the
+// scaled scores come out of the K.Q^T MFMAs directly -- and the running max is SUBTRACTED BY THE MATRIX PIPE: each row
+// block keeps 16 registers holding -m (all equal; a lane owns one query row, so its 16 accumulators of a 32-key block
+// share one max) and the first MFMA of a score chain takes them as its C operand.  The exponent's argument is then the
+// accumulator itself: the per-score v_fma (64 of the ~240 VALU instructions of a 64-key tile, ~18 % of the loop's issue
+// slots) is gone.  m only changes on the slow path (see attn_spatial_kernel), which rewrites the 16 registers.
+// The other experiments of round 2 (skewed row blocks, anti-phase start delay, one wave per SIMD) are recorded in
+// DESIGN.md section 8 and tools/experiments/.
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
   const long row0 = (long)img * S;
   const int ld = 3 * C;
   const bf16_t* qp = qkv + head * 64;
+  constexpr float kScale = PRE ? 1.0f : kScaleLog2;      // what is left to apply to a raw score
 
   int qrow[2];
   bf16x8 qf[2][4];
@@ -349,26 +356,38 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[rb][dt][e] = 0.f;
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  // PRE: -m of each row block as the C operand of its score chains (+inf before the first tile: the first tile's sums
+  // are inf and take the slow path, exactly as with m = -inf in the subtracting form)
+  f32x16 negm[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) negm[rb][e] = INFINITY;
 
   const int i16 = lane & 15;
   const int vkey = 4 * hsel + (i16 >> 2);
   const int vcol = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
 
   constexpr float kSumLimit = 4096.0f;
-  auto scores = [&](const char* kst, f32x16 (&sacc)[2][2], int t, auto masked_tag) {
+  // scores of one 64-key tile for both row blocks.  SUB (PRE only): start the chains from -m instead of zero.
+  auto scores = [&](const char* kst, f32x16 (&sacc)[2][2], int t, auto masked_tag, auto sub_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool SUB = decltype(sub_tag)::value;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (!SUB) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[rb][kt][e] = 0.f;
+          for (int e = 0; e < 16; ++e) sacc[rb][kt][e] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
-          sacc[rb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sacc[rb][kt], 0, 0, 0);
+          if (SUB && ks == 0) sacc[rb][kt] = mfma_keep_c(kf, qf[rb][ks], negm[rb]);
+          else sacc[rb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sacc[rb][kt], 0, 0, 0);
       }
 #ifdef CTRLV_ATTN64_SERIAL
       if (kt == 0) asm volatile("" ::: "memory");   // keep the second half's K fragments out of flight (registers)
@@ -386,134 +405,51 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
           }
     }
   };
-  auto exp_sum = [&](f32x16 (&sacc)[2], float m) -> float {
-#ifdef CTRLV_ATTN_PACKED
-    f32x2_t rs2 = {0.f, 0.f};
-    const f32x2_t nm = {-m, -m};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        f32x2_t x = {sacc[kt][e], sacc[kt][e + 1]};
-        x = x * kScaleLog2 + nm;
-        f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-        sacc[kt][e] = pe.x;
-        sacc[kt][e + 1] = pe.y;
-        rs2 += pe;
-      }
-    return rs2.x + rs2.y;
-#else
-    // SCALAR fp32 on purpose (this file is built with -fno-slp-vectorize): beside MFMAs a v_pk_add_f32 / v_pk_fma_f32
-    // costs about four issue slots, two plain v_fma_f32 cost two (MI355X_MICROARCH.md, "price of one filler beside
-    // MFMAs") -- packing the softmax arithmetic halves the instruction count and doubles its cost.
+  // SCALAR fp32 on purpose (this file is built with -fno-slp-vectorize): beside MFMAs a v_pk_add_f32 / v_pk_fma_f32 costs
+  // about four issue slots, two plain v_fma_f32 cost two (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+  // DIRECT: the accumulators already hold scale * s - m (PRE fast path).  The exponentials are packed to bf16 at once
+  // (the B operands of O^T += V^T.P), so the 64 score registers of a tile die here and not at the end of the P.V phase.
+  auto exp_pack = [&](const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float m, auto direct_tag) -> float {
+    constexpr bool DIRECT = decltype(direct_tag)::value;
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
     const float nm = -m;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; e += 4) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e], kScaleLog2, nm));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 1], kScaleLog2, nm));
-        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 2], kScaleLog2, nm));
-        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 3], kScaleLog2, nm));
-        sacc[kt][e] = p0; sacc[kt][e + 1] = p1; sacc[kt][e + 2] = p2; sacc[kt][e + 3] = p3;
+        float p0, p1, p2, p3;
+        if (DIRECT) {
+          p0 = __builtin_amdgcn_exp2f(sacc[kt][e]);
+          p1 = __builtin_amdgcn_exp2f(sacc[kt][e + 1]);
+          p2 = __builtin_amdgcn_exp2f(sacc[kt][e + 2]);
+          p3 = __builtin_amdgcn_exp2f(sacc[kt][e + 3]);
+        } else {
+          p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e], kScale, nm));
+          p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 1], kScale, nm));
+          p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 2], kScale, nm));
+          p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 3], kScale, nm));
+        }
+        bf16x8& d = pf[kt][e >> 3];
+        const int o = e & 7;
+        d[o] = (__bf16)p0; d[o + 1] = (__bf16)p1; d[o + 2] = (__bf16)p2; d[o + 3] = (__bf16)p3;
         r0 += p0; r1 += p1; r2 += p2; r3 += p3;
       }
     return (r0 + r1) + (r2 + r3);
-#endif
   };
-  // ---- skewed schedule: one row block's scores / softmax / P.V, callable piecewise
-  auto scores_rb = [&](const char* kst, f32x16 (&sa)[2], int rb, int t, auto masked_tag) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sa[kt][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
-        sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sa[kt], 0, 0, 0);
-      }
-    }
-    if (MASKED) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = t * 64 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hsel;
-          if (key >= S) sa[kt][e] = -INFINITY;
-        }
-    }
-  };
-  auto rescale_rb = [&](const char* kst, f32x16 (&sa)[2], int rb, int t, auto masked_tag) -> float {   // slow path
-    scores_rb(kst, sa, rb, t, masked_tag);
-    float mx = sa[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[kt][e]);
-    mx = half_max(mx) * kScaleLog2;
-    const float m_new = fmaxf(m_run[rb], mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
-    m_run[rb] = m_new;
-    l_run[rb] *= alpha;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
-    return exp_sum(sa, m_run[rb]);
-  };
-  auto pv_rb = [&](const char* vst, f32x16 (&sa)[2], int rb) {
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = pack_p(sa[kt], s);
-        const int kb = kt * 32 + 16 * s + vkey;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
-          oacc[rb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[rb][dt], 0, 0, 0);
-        }
-      }
-  };
-  // 8 x (1 MFMA, NV VALU) -- masks: 0x008 MFMA, 0x002 VALU (incl. transcendental), 0x100 DS read
-#define ATTN_INTERLEAVE(NV)                                         \
-  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);             \
-  }
-  auto tile_pipe = [&](int t, auto masked_tag) {
+  auto tile = [&](int t, auto masked_tag) {
     const char* kst = smem + (t & 1) * 16384;
     const char* vst = kst + 8192;
-    f32x16 s0[2], s1[2];
-    scores_rb(kst, s0, 0, t, masked_tag);                         // phase 1: 8 MFMA
-    // phase 2: K.Q^T of row block 1 in the shadow of row block 0's softmax
-    scores_rb(kst, s1, 1, t, masked_tag);
-    float rs0 = exp_sum(s0, m_run[0]);
-    ATTN_INTERLEAVE(10)
-    if (!__all(rs0 <= kSumLimit)) rs0 = rescale_rb(kst, s0, 0, t, masked_tag);
-    l_run[0] += rs0;
-    // phase 3: P.V of row block 0 in the shadow of row block 1's softmax
-    pv_rb(vst, s0, 0);
-    float rs1 = exp_sum(s1, m_run[1]);
-    ATTN_INTERLEAVE(12)
-    if (!__all(rs1 <= kSumLimit)) rs1 = rescale_rb(kst, s1, 1, t, masked_tag);
-    l_run[1] += rs1;
-    pv_rb(vst, s1, 1);                                            // phase 4: 8 MFMA
-  };
-#undef ATTN_INTERLEAVE
-  auto tile_flat = [&](int t, auto masked_tag) {
-    const char* kst = smem + (t & 1) * 16384;
-    const char* vst = kst + 8192;
-    f32x16 sacc[2][2];
-    scores(kst, sacc, t, masked_tag);
+    bf16x8 pf[2][2][2];       // [row block][32-key half][16-key step]
     float rs[2];
+    {
+      f32x16 sacc[2][2];
+      scores(kst, sacc, t, masked_tag, std::integral_constant<bool, PRE>{});
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) rs[rb] = exp_sum(sacc[rb], m_run[rb]);
+      for (int rb = 0; rb < 2; ++rb) rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::integral_constant<bool, PRE>{});
+    }
     if (!__all(rs[0] <= kSumLimit && rs[1] <= kSumLimit)) {       // slow path: see attn_spatial_kernel
-      scores(kst, sacc, t, masked_tag);
+      f32x16 sacc[2][2];
+      scores(kst, sacc, t, masked_tag, std::false_type{});
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         float mx = sacc[rb][0][0];
@@ -521,7 +457,7 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[rb][kt][e]);
-        mx = half_max(mx) * kScaleLog2;
+        mx = half_max(mx) * kScale;
         const float m_new = fmaxf(m_run[rb], mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
         m_run[rb] = m_new;
@@ -530,7 +466,11 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
-        rs[rb] = exp_sum(sacc[rb], m_run[rb]);
+        if (PRE) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) negm[rb][e] = -m_new;
+        }
+        rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::false_type{});
       }
     }
     l_run[0] += rs[0];
@@ -539,32 +479,20 @@ __global__ __launch_bounds__(256, CTRLV_ATTN_OCC) void attn_spatial64_kernel(con
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf0 = pack_p(sacc[0][kt], s), pf1 = pack_p(sacc[1][kt], s);
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
-          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0, oacc[0][dt], 0, 0, 0);
-          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1, oacc[1][dt], 0, 0, 0);
+          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kt][s], oacc[0][dt], 0, 0, 0);
+          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kt][s], oacc[1][dt], 0, 0, 0);
         }
       }
     }
-  };
-  auto tile = [&](int t, auto masked_tag) {
-    if constexpr (PIPE) tile_pipe(t, masked_tag); else tile_flat(t, masked_tag);
   };
 
   const int nt = (S + 63) / 64;
   const int nt_full = S / 64;
   issue(0, 0);
-  // Two workgroups share a CU (two waves per SIMD): every wave alternates a matrix phase (16 + 16 MFMAs) and a softmax
-  // VALU phase of about the same length.  Workgroups that start together stay IN phase (both want the matrix pipe, then
-  // both the VALU); delaying every second dispatch "generation" by half a tile puts the co-resident pair in anti-phase.
-  if (phase_delay > 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if ((lin >> 8) & 1)
-      for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   for (int t = 0; t < nt_full; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -714,13 +642,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
 
 }  // namespace
 
-int ctrlv_attention_spatial_pipelined(const void* qkv, void* out, int n_img, int S, int C, hipStream_t stream);  // attention_pipe.hip
-
-extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream);
-extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
-  return ctrlv_attention_spatial_lse(qkv, out, nullptr, n_img, S, C, stream);
-}
-extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream) {
+static int attention_spatial_launch(const void* qkv, void* out, float* lse, int n_img, int S, int C, bool pre, hipStream_t stream) {
   CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
   CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
@@ -731,57 +653,34 @@ extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* ls
     rows = (e && e[0] == '3') ? 32 : (e && e[0] == '6') ? 64 : -1;
   }
   const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
-  static int xpipe = -1;                        // CTRLV_ATTN_X=1: cross-tile pipelined kernel (attention_pipe.hip)
-  if (xpipe < 0) {
-    const char* e = getenv("CTRLV_ATTN_X");
-    xpipe = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (use64 && xpipe && !lse) return ctrlv_attention_spatial_pipelined(qkv, out, n_img, S, C, (hipStream_t)stream);
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
-    static int pipe = -1;                       // CTRLV_ATTN_PIPE=1 selects the skewed schedule (A/B; measured slower)
-    if (pipe < 0) {
-      const char* e = getenv("CTRLV_ATTN_PIPE");
-      pipe = (e && e[0] == '1') ? 1 : 0;
-    }
-    static int delay = -1;                      // CTRLV_ATTN_DELAY=<n>: anti-phase start delay in units of ~1024 cycles
-    if (delay < 0) {
-      const char* e = getenv("CTRLV_ATTN_DELAY");
-      delay = e ? atoi(e) : 0;
-    }
-    // (diagnostic builds -DCTRLV_ATTN_OCC=1 ask for > half of the LDS so that one workgroup owns the CU)
-    constexpr int kSmem64 = CTRLV_ATTN_OCC == 1 ? 98304 : 32768;
-    static bool attr64[CTRLV_MAX_DEVICES] = {};
-    if (kSmem64 > 65536 && !attr64[ctrlv_current_device()]) {
-      CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)attn_spatial64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64));
-      CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)attn_spatial64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64));
-      attr64[ctrlv_current_device()] = true;
-    }
-    if (pipe)
-      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, lse, S, C, delay);
+    if (pre)
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
     else
-      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kSmem64, (hipStream_t)stream, (const bf16_t*)qkv,
-                         (bf16_t*)out, lse, S, C, delay);
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
+  // 32 rows per wave, 2-slot K/V ring (32 KiB LDS, 4 waves/SIMD): 883 TFLOP/s at S = 9216 against 810 for 3 slots (two
+  // tiles of LDS-DMA in flight but 3 waves/SIMD) -- occupancy beats prefetch depth for this VALU-heavy d = 64 kernel.
   dim3 grid((S + 127) / 128, C / 64, n_img);
-  // K/V ring depth: 2 slots (32 KiB LDS, 4 waves/SIMD) measured 883 TFLOP/s at S = 9216 against 810 for 3 slots (two
-  // tiles of LDS-DMA in flight but 3 waves/SIMD): occupancy beats prefetch depth for this VALU-heavy d = 64 kernel.
-  static int nslot = 0;
-  if (nslot == 0) {
-    const char* e = getenv("CTRLV_ATTN_SLOTS");
-    nslot = (e && e[0] == '3') ? 3 : 2;
-  }
-  if (nslot == 3)
-    hipLaunchKernelGGL((attn_spatial_kernel<3>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, C);
+  if (pre)
+    hipLaunchKernelGGL((attn_spatial_kernel<2, true>), grid, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
   else
-    hipLaunchKernelGGL((attn_spatial_kernel<2>), grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, S, C);
+    hipLaunchKernelGGL((attn_spatial_kernel<2, false>), grid, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
+}
+
+extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
+  return attention_spatial_launch(qkv, out, nullptr, n_img, S, C, false, (hipStream_t)stream);
+}
+extern "C" int ctrlv_attention_spatial_lse(const void* qkv, void* out, float* lse, int n_img, int S, int C, ctrlv_stream_t stream) {
+  return attention_spatial_launch(qkv, out, lse, n_img, S, C, false, (hipStream_t)stream);
+}
+extern "C" int ctrlv_attention_spatial_prescaled(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
+  return attention_spatial_launch(qkv, out, nullptr, n_img, S, C, true, (hipStream_t)stream);
 }
 
 extern "C" int ctrlv_attention_temporal(const void* qkv, void* out, int B, int F, int S, int C,

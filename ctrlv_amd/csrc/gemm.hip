@@ -21,9 +21,6 @@
 
 // ping-pong schedule (gemm_pp_kernel.h, gemm_pp_m*.hip): tile 5 = 256x256, tile 6 = 256x320 (7 / 8: non-persistent)
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
-// streamed 4-wave schedule, two workgroups per CU (gemm_st_kernel.h, gemm_st.hip): tile 9 = 256x160, mode 0
-bool ctrlv_gemm_st_supports(const ctrlv_gemm_desc& d);
-int ctrlv_gemm_launch_st(const ctrlv_gemm_desc& d, hipStream_t stream);
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);
 
 namespace {
@@ -42,6 +39,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wid / WN, wc = wid % WN;
+  // Phi table of the GEGLU epilogue (common.h), behind the two stages; the K loop's barriers order it before its use
+  if (d.geglu) gelu_table_fill(smem + 2 * STAGE, threadIdx.x, NW * 64);
 
   const int tiles_n = (d.N + BN - 1) / BN;
   const int tiles_m = (d.M + BM - 1) / BM;
@@ -166,12 +165,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
     }
   }
 
-  gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel);
+  gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel, smem + 2 * STAGE);
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = 2 * (BM + BN) * 128 + kGeluTabBytes;   // staging ring | Phi table (GEGLU launches)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};      // per device: the attribute belongs to the device's code object
   auto kfn = gemm_kernel<BM, BN, WM, WN>;
   const int dev = ctrlv_current_device();
@@ -216,6 +215,8 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   }
   CTRLV_CHECK_ARG(d.vmode >= 0 && d.vmode <= 2, "ctrlv_gemm: bad vmode");
   if (d.vmode) CTRLV_CHECK_ARG(d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv % 4 == 0 && (d.vmode == 1 || d.vS > 0), "ctrlv_gemm: bad row-vector table");
+  CTRLV_CHECK_SHAPE(d.n_scale2 >= 0 && d.n_scale2 % 32 == 0 && (d.n_scale2 == 0 || !d.geglu),
+                    "ctrlv_gemm: n_scale2=%d must be a non-negative multiple of 32 (and 0 with GEGLU)", d.n_scale2);
   if (d.geglu) {
     CTRLV_CHECK_SHAPE(d.N % 32 == 0, "ctrlv_gemm: GEGLU needs N %% 32 == 0 (16 value + 16 gate columns per sub-tile)");
     CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !(d.out_f32 & 1) && d.mode == 0,
@@ -228,20 +229,14 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // 1280, GEGLU at K < 1280), 256x256 otherwise (N = 3840 qkv, K = 1280 GEGLU: +7 %); tiny-M per-clip GEMMs stay on
     // 128x128.
     const bool big = d.M >= 1024 && d.N >= 128;
-    // tile 9 (streamed, two 4-wave workgroups per CU: one's epilogue beside the other's K loop) is opt-in
-    // (CTRLV_GEMM_ST=1): isolated it is +4-5 % on the K = 320 GEGLU projections and behind the ping-pong tiles
-    // elsewhere; in the model (graph replay, ControlNet on the side stream) the step time does not move
-    // (profiles/r02_gemm_streamed_ab.txt).
-    static const bool use_st = [] { const char* e = getenv("CTRLV_GEMM_ST"); return e && atoi(e) != 0; }();
     if (!big) tile = 1;
     else if (d.N <= 128 && d.mode != 0) tile = 10;     // 256x128 ping-pong tile (profiles/r02_vae_decode.txt)
-    else if (use_st && d.geglu && d.Cin <= 320 && d.N % 160 == 0 && d.M >= 16384 && ctrlv_gemm_st_supports(d)) tile = 9;
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
   }
   if (d.raw_out) {      // second output of the GEGLU projection (training forward): ping-pong tiles only
     CTRLV_CHECK_ARG(d.geglu && d.ld_raw >= d.N, "ctrlv_gemm: raw_out needs geglu = 1 and ld_raw >= N");
-    if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;   // (9, 10 do not write raw_out)
+    if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;   // (tile 10 does not write raw_out)
     CTRLV_CHECK_SHAPE(ctrlv_gemm_pp_supports(d), "ctrlv_gemm: raw_out needs a shape the ping-pong tiles serve (K >= 128, "
                                                  "ld_raw a multiple of 8)");
   }
@@ -249,7 +244,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // the ping-pong kernels' epilogue moves 8 columns (16 B of bf16) per lane: needs 8-element granularity
     const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&
                          (!d.R2 || d.ldr2 % 8 == 0) && (!d.vmode || d.ldv % 8 == 0);
-    if (!wide_ok || !ctrlv_gemm_pp_supports(d) || (tile == 9 && !ctrlv_gemm_st_supports(d))) {
+    if (!wide_ok || !ctrlv_gemm_pp_supports(d)) {
       CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8 and an "
                                      "epilogue of {bias, V, R1, R1+V, R1+R2} without SiLU / fp32 output");
       tile = 1;
@@ -264,7 +259,6 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     case 7: return ctrlv_gemm_launch_pp(d, tile, stream);
     case 6:
     case 8: return ctrlv_gemm_launch_pp(d, tile, stream);
-    case 9: return ctrlv_gemm_launch_st(d, stream);
     case 10: return ctrlv_gemm_launch_pp(d, tile, stream);
     default: CTRLV_CHECK_ARG(false, "ctrlv_gemm: unknown tile %d", tile);
   }

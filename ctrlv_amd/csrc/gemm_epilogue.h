@@ -6,7 +6,8 @@
 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
-                                              int wr, int wc, int WTM, int WTN, int r32, int hsel) {
+                                              int wr, int wc, int WTM, int WTN, int r32, int hsel,
+                                              const char* gelu_tab) {
   // ---- epilogue: lane owns row m; accumulator quad q holds columns n0 + 8q + 4h + {0..3}
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -31,7 +32,7 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float a = acc[i][j][4 * q + e], g = acc[i][j][4 * (q + 2) + e];
-            o[e] = a * gelu_erf_f(g);
+            o[e] = geglu_tab(a, g, gelu_tab);
           }
           if (ocol < d.n_store) {
             uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
@@ -56,7 +57,7 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
           {
 #pragma clang fp contract(off)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = o[e] * d.s_acc;
+            for (int e = 0; e < 4; ++e) o[e] = o[e] * (ncol < d.n_scale2 ? d.s_acc2 : d.s_acc);
           }
           if (d.R1) {
             const uint2 rv = *(const uint2*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ncol);

@@ -101,10 +101,10 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
 }
 
-template <int TM, int TN, bool GEGLU, int EPI, bool PACKED = true, bool RAW = false>
+template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
-                                                  char* p2, char* p3, const char* bias_lds) {
+                                                  char* p2, char* p3, const char* bias_lds, const char* gelu_tab) {
   constexpr unsigned kOOB = 0xFFFFFFFFu;
   constexpr int kFlags = 0x00020000;
   const int r32 = lane & 31, hsel = lane >> 5, l4 = lane & 3;
@@ -182,6 +182,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           if (k < NSUB) load_res(k);
       }
       const int ocol = ocol0 + j * 32;
+      // scale of this 32-column block (wave-uniform): the q block of a fused q|k|v projection takes s_acc2
+      const float sc = (wbase_n + j * 32 < d.n_scale2) ? d.s_acc2 : d.s_acc;
       // row-vector operands (L2-resident tables): issued ahead of this sub-tile's LDS round trip
       u32x4_t vv[2][2] = {};
       if (EPI & 1) {
@@ -220,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         {
 #pragma clang fp contract(off)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = o[e] * d.s_acc;         // (the bias is already in the accumulator)
+          for (int e = 0; e < 8; ++e) o[e] = o[e] * sc;              // (the bias is already in the accumulator)
         }
         if (EPI & 2) {
           float f[8];
@@ -309,14 +311,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
             const f32x4_t g = {acc[i][js][4 * (qd + 2)], acc[i][js][4 * (qd + 2) + 1], acc[i][js][4 * (qd + 2) + 2],
                                acc[i][js][4 * (qd + 2) + 3]};
             const f32x4_t a = {acc[i][js][4 * qd], acc[i][js][4 * qd + 1], acc[i][js][4 * qd + 2], acc[i][js][4 * qd + 3]};
-            f32x4_t o;
-            if constexpr (PACKED) {
-              o = a * gelu_erf4(g);
-            } else {
-#pragma clang fp contract(off)
+            f32x4_t o;      // a * gelu(g), Phi from the LDS table (common.h: 8 VALU per gate instead of 20)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = a[e] * (g[e] * gelu_phi1(g[e]));
-            }
+            for (int e = 0; e < 4; ++e) o[e] = geglu_tab(a[e], g[e], gelu_tab);
             const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
             *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
           }
@@ -378,13 +375,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // issue a DUMMY one -- out-of-range source (zeros, no memory traffic) into a private 1-KiB scratch strip -- so that
   // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
   constexpr bool UNEVEN = (B_TOT % NW) != 0;
+  // (one dummy KiB serves all waves: it is only ever written, with zeros)
   constexpr int BIAS_OFF = NH * SLOT, DUMMY_OFF = BIAS_OFF + NW * WTN * 4;
   // The epilogue stages through FOUR wave-private 1-KiB pieces: the wave's two A pieces and two B pieces of the slot
   // consumed last.  A 128-wide tile has only one B piece per wave: its fourth piece is a private strip behind the ring.
   constexpr bool OWN_P3 = B_TOT < 2 * NW;
-  constexpr int P3_OFF = DUMMY_OFF + (UNEVEN ? NW * 1024 : 0);
+  constexpr int P3_OFF = DUMMY_OFF + (UNEVEN ? 1024 : 0);
+  constexpr int TAB_OFF = P3_OFF + (OWN_P3 ? NW * 1024 : 0);      // Phi table of the GEGLU epilogue (common.h)
 
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | 8 dummy pieces
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | dummy piece | P3 | Phi
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     if (!UNEVEN || q < B_Q - 1) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(is_sb + (q * NW + wid) * 1024), 16, b_voff[q], is_so_w, 0, 0);
     } else {
-      char* dst = (q * NW + wid < B_TOT) ? is_sb + (q * NW + wid) * 1024 : smem + DUMMY_OFF + wid * 1024;
+      char* dst = (q * NW + wid < B_TOT) ? is_sb + (q * NW + wid) * 1024 : smem + DUMMY_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst), 16, b_voff[q], is_so_w, 0, 0);
     }
   };
@@ -557,6 +556,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     }
     return c;
   };
+  // Phi table: written here, read in the first epilogue -- every wave passes an `lgkmcnt(0)` + barrier of the K loop between
+  if constexpr (GEGLU) gelu_table_fill(smem + TAB_OFF, threadIdx.x, NW * 64);
   // ---- prologue: 3 half-steps in flight
   int is_tile = my_first;
   next_tile(is_tile);
@@ -746,9 +747,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
       u32x4_t nb = {0, 0, 0, 0};
       if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
-      gemm_epilogue_lds<TM, TN, GEGLU, EPI, true, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane, s0 + wid * 1024, s0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024,
-                                OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds);
+                                OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds,
+                                smem + TAB_OFF);
       if (refill) pp_bias_store<WTN>(bias_lds, nb, lane);
       // The accumulators are dead here -- the next tile's first MFMAs overwrite them from a literal-zero C operand --
       // but that redefinition sits behind a `j == 0` test inside the K loop, so the compiler would keep all 128-160
@@ -786,8 +788,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
-  // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece per wave (ragged B piece count only)
-  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 8 * 1024 : 0) + ((BN / 16) < 16 ? 8 * 1024 : 0);
+  // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece (ragged B piece count only) + private fourth
+  // staging pieces (128-wide tile only) + the Phi table (GEGLU only)
+  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 1024 : 0) + ((BN / 16) < 16 ? 8 * 1024 : 0) +
+                       (GEGLU ? kGeluTabBytes : 0);
+  static_assert(smem <= 160 * 1024, "ping-pong tile does not fit the LDS");
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
   auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW>;

@@ -149,6 +149,8 @@ struct ctrlv_plan {
   std::vector<Linear> zc;     // controlnet_down_blocks
   Linear zc_mid;
   std::vector<void*> owned;   // every device allocation of load_weights
+  struct WsEntry { int B, F, H, W; size_t bytes; };
+  std::vector<WsEntry> ws_cache;   // ctrlv_plan_workspace_bytes per input shape (check_workspace)
 };
 
 namespace {
@@ -612,9 +614,13 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
   // ---- spatial BasicTransformerBlock
   TRY(layernorm(c, h0, (int)M, C, t.s_ln1, tt));
   bf16_t* qkv = c.rows(M, 3 * C);
-  TRY(gemm(c, gd(tt, C, t.s_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
+  {
+    ctrlv_gemm_desc d = gd(tt, C, t.s_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C);
+    d.n_scale2 = C; d.s_acc2 = 0.125f * 1.44269504088896340736f;      // q block pre-scaled: (1/sqrt(64)) log2(e)
+    TRY(gemm(c, d));
+  }
   bf16_t* a = c.rows(M, C);
-  if (!c.dry) TRY(ctrlv_attention_spatial(qkv, a, N, S, C, c.st));
+  if (!c.dry) TRY(ctrlv_attention_spatial_prescaled(qkv, a, N, S, C, c.st));
   bf16_t* h1 = c.rows(M, C);
   {   // attn2 with one key == to_out(to_v(ehs[b])) for every query: a per-clip row vector
     ctrlv_gemm_desc d = gd(a, C, t.s_o, h1, C, (int)M, C, C, C);
@@ -1096,6 +1102,25 @@ extern "C" size_t ctrlv_plan_workspace_bytes(ctrlv_plan* p, int B, int F, int H,
   return rc == CTRLV_OK ? c.peak + 256 : 0;
 }
 
+// A too-small workspace is refused BEFORE anything is launched (the walk's own overflow flags are a second line of
+// defence: not every launch helper tests them).  The dry walk's result is cached per (B, F, H, W).
+static int check_workspace(ctrlv_plan* p, const char* who, int B, int F, int H, int W, size_t have) {
+  size_t need = 0;
+  for (const auto& e : p->ws_cache)
+    if (e.B == B && e.F == F && e.H == H && e.W == W) need = e.bytes;
+  if (need == 0) {
+    need = ctrlv_plan_workspace_bytes(p, B, F, H, W);
+    if (need == 0) return CTRLV_E_BAD_SHAPE;           // (message set by the dry walk)
+    if (p->ws_cache.size() >= 16) p->ws_cache.clear();
+    p->ws_cache.push_back({B, F, H, W, need});
+  }
+  if (have < need) {
+    ctrlv_set_error("%s: workspace too small (%zu bytes, need >= %zu: ctrlv_plan_workspace_bytes)", who, have, need);
+    return CTRLV_E_WORKSPACE;
+  }
+  return CTRLV_OK;
+}
+
 extern "C" int ctrlv_unet_forward(ctrlv_plan* p, const void* sample, int dtype, const float* timestep, int n_timestep,
                                   const void* ehs, const float* added_time_ids, int n_ids, const void* const* down_res,
                                   const void* mid_res, void* residual_event, void* out, int B, int F, int H, int W,
@@ -1103,14 +1128,15 @@ extern "C" int ctrlv_unet_forward(ctrlv_plan* p, const void* sample, int dtype, 
   TRY(check_common(p, B, F, H, W));
   CTRLV_CHECK_ARG(p->cfg.kind == 0, "unet_forward: the plan is a ControlNet");
   CTRLV_CHECK_ARG(sample && timestep && ehs && added_time_ids && out && workspace, "unet_forward: null pointer");
-  CTRLV_CHECK_ARG(dtype >= 0 && dtype <= 2, "unet_forward: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)");
+  if (dtype < 0 || dtype > 2) { ctrlv_set_error("unet_forward: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)"); return CTRLV_E_BAD_DTYPE; }
   CTRLV_CHECK_ARG((down_res == nullptr) == (mid_res == nullptr), "unet_forward: pass both down_res and mid_res or neither");
+  TRY(check_workspace(p, "unet_forward", B, F, H, W, workspace_bytes));
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   Ctx c{p, (hipStream_t)stream, false, base, workspace_bytes - (size_t)(base - (char*)workspace)};
   c.B = B; c.F = F;
   const int rc = unet_forward(p, c, sample, dtype, timestep, n_timestep, ehs, added_time_ids, n_ids, down_res, mid_res,
                               residual_event, out, H, W);
-  if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("unet_forward: workspace too small (need >= %zu bytes)", c.peak + 256); return CTRLV_E_BAD_ARG; }
+  if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("unet_forward: workspace too small (need >= %zu bytes)", c.peak + 256); return CTRLV_E_WORKSPACE; }
   return rc;
 }
 
@@ -1123,12 +1149,13 @@ extern "C" int ctrlv_controlnet_forward(ctrlv_plan* p, const void* sample, const
   CTRLV_CHECK_ARG(p->cfg.kind == 1, "controlnet_forward: the plan is a UNet");
   CTRLV_CHECK_ARG(sample && control_cond && timestep && ehs && added_time_ids && out_down && out_mid && workspace,
                   "controlnet_forward: null pointer (control_cond is required, controlnet.py:289)");
-  CTRLV_CHECK_ARG(dtype >= 0 && dtype <= 2, "controlnet_forward: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)");
+  if (dtype < 0 || dtype > 2) { ctrlv_set_error("controlnet_forward: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)"); return CTRLV_E_BAD_DTYPE; }
+  TRY(check_workspace(p, "controlnet_forward", B, F, H, W, workspace_bytes));
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   Ctx c{p, (hipStream_t)stream, false, base, workspace_bytes - (size_t)(base - (char*)workspace)};
   c.B = B; c.F = F;
   const int rc = controlnet_forward(p, c, sample, control_cond, dtype, timestep, n_timestep, ehs, added_time_ids, n_ids,
                                     conditioning_scale, out_down, out_mid, H, W);
-  if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("controlnet_forward: workspace too small (need >= %zu bytes)", c.peak + 256); return CTRLV_E_BAD_ARG; }
+  if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("controlnet_forward: workspace too small (need >= %zu bytes)", c.peak + 256); return CTRLV_E_WORKSPACE; }
   return rc;
 }

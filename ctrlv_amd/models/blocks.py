@@ -319,9 +319,9 @@ class TransformerSpatioTemporalModel(nn.Module):
         # ---- spatial BasicTransformerBlock
         ops.layernorm(h0, pk["s_ln1"][0], pk["s_ln1"][1], 1e-5, t)
         qkv = ws.alloc((M, 3 * C))
-        ops.gemm(t, pk["s_qkv"], qkv, N=3 * C, cin=C)
+        ops.gemm(t, pk["s_qkv"], qkv, N=3 * C, cin=C, n_scale2=C, s_acc2=ops.Q_PRESCALE)   # q block pre-scaled
         a = ws.alloc((M, C))
-        ops.attention_spatial(qkv, a, N, S, C)
+        ops.attention_spatial(qkv, a, N, S, C, prescaled=True)
         h1 = ws.alloc((M, C))
         xs_vec = ctx.xattn[:, self.xattn_off[0]:]      # attn2 with one key == to_out(to_v(ehs[b])) for every query
         ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)

@@ -114,7 +114,7 @@ def geglu_bwd(raw, du, draw):
 
 def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
          R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
-         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, _dbg=0):
+         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0):
     """out = epilogue(gather-GEMM(A[, A2], W)).  `conv` = (H, W, Ho, Wo, stride, up); `temporal` = (F, S)."""
     _need_gpu(A, "A")
     d = GemmDesc()
@@ -141,6 +141,7 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     d.act, d.geglu, d.out_f32, d.tile = act, geglu, (_dbg if _dbg else (1 if out_f32 else 0)), tile
     if raw_out is not None:
         d.raw_out, d.ld_raw = _p(raw_out), raw_out.stride(0)
+    d.n_scale2, d.s_acc2 = n_scale2, s_acc2
     ev = _prof.begin()
     check(_lib.load().ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
     if ev is not None:
@@ -187,10 +188,15 @@ def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30):
     return y
 
 
-def attention_spatial(qkv, out, n_img, S, C):
+Q_PRESCALE = 0.125 * 1.44269504088896340736      # (1/sqrt(64)) * log2(e): the q block scale of the prescaled core
+
+
+def attention_spatial(qkv, out, n_img, S, C, prescaled=False):
+    """prescaled: the q columns already carry Q_PRESCALE (gemm(..., n_scale2=C, s_acc2=Q_PRESCALE))."""
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()
-    check(_lib.load().ctrlv_attention_spatial(_p(qkv), _p(out), n_img, S, C, _stream()), "ctrlv_attention_spatial")
+    fn = _lib.load().ctrlv_attention_spatial_prescaled if prescaled else _lib.load().ctrlv_attention_spatial
+    check(fn(_p(qkv), _p(out), n_img, S, C, _stream()), "ctrlv_attention_spatial")
     _prof.end(ev, "attention_spatial", 4.0 * n_img * (C // 64) * S * S * 64, 2.0 * 4 * n_img * S * C)
     return out
 

@@ -29,6 +29,8 @@ enum {
   CTRLV_E_BAD_ARG = -1,
   CTRLV_E_BAD_SHAPE = -2,
   CTRLV_E_HIP = -3,
+  CTRLV_E_BAD_DTYPE = -4,  /* a dtype code outside {0 fp32, 1 fp16, 2 bf16} at the model boundary */
+  CTRLV_E_WORKSPACE = -5,  /* caller-supplied workspace smaller than ctrlv_plan_workspace_bytes() */
 };
 
 /* Library ABI version (bumped on any signature change). */
@@ -87,12 +89,12 @@ typedef struct ctrlv_gemm_desc {
   void* raw_out;                      /* GEGLU only, optional (training forward): the projection BEFORE the gate,
                                          [M, ld_raw] bf16 in the packed (16 value | 16 gate) column-block order -- what
                                          ctrlv_geglu_bwd consumes -- written by the same launch (ping-pong tiles) */
+  int32_t n_scale2;                   /* output columns [0, n_scale2) take s_acc2 in place of s_acc (multiple of 32; 0 = */
+  float s_acc2;                       /* none).  The fused q|k|v projection scales its q block by (1/sqrt(64)) log2(e)
+                                         here, in fp32 before the one bf16 rounding: ctrlv_attention_spatial_prescaled */
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
-/* Diagnostic: resident workgroups per CU of the streamed short-K kernel (tile 9) on the current device; its schedule
- * relies on two (<= 80 KB LDS, <= 256 registers each).  -1 on a HIP error. */
-int ctrlv_gemm_st_occupancy(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * GroupNorm(32) (+SiLU), channels-last.  Replaces nn.GroupNorm + SiLU of ResnetBlock2D.norm1/norm2,
@@ -126,6 +128,11 @@ int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float
  *             (b f) s c <-> (b s) f c permutes of TemporalBasicTransformerBlock are index math, F <= 32.
  * ------------------------------------------------------------------------------------------------------------------ */
 int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream);
+/* The same core for q columns that are ALREADY scaled by (1/sqrt(64)) * log2(e) = 0.18033688 (ctrlv_gemm_desc.n_scale2 /
+ * s_acc2 on the q|k|v projection): softmax_2(q' k^T) v.  The scaled scores then come out of the K.Q^T MFMAs and the
+ * running max is subtracted through their C operand -- no per-score multiply-add on the vector ALU (the inference
+ * plans use this entry; training keeps the unscaled form and its LSE convention). */
+int ctrlv_attention_spatial_prescaled(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream);
 int ctrlv_attention_temporal(const void* qkv, void* out, int B, int F, int S, int C, ctrlv_stream_t stream);
 /* Training forward of the spatial core: additionally writes L = m + log2(l) of every softmax row (log2 domain of the
  * scaled scores), lse [n_img][C/64][S] fp32 (NULL = ctrlv_attention_spatial). */

@@ -42,7 +42,7 @@ def g(seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ gather-GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (1000, 256, 320), (77, 64, 64), (700, 640, 1280)])
 def test_gemm_plain_epilogue(ops, tile, M, N, K):
     """Every epilogue operand combination the models use.  Tiles 1-4 (2-stage kernels) take any combination incl. SiLU
@@ -82,6 +82,11 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
     assert parity_err(out, lin + V[vidx]) < 3e-3
     ops.gemm(Ad, Wd, out, N=N, cin=K, tile=tile)
     assert parity_err(out, lin - bias) < 3e-3
+    # a second scale for the leading column blocks (the pre-scaled q block of a fused q|k|v projection)
+    n2 = N // 64 * 32
+    sc = torch.where(torch.arange(N) < n2, 0.25, 1.5)
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, s_acc=1.5, n_scale2=n2, s_acc2=0.25, tile=tile)
+    assert parity_err(out, lin * sc) < 3e-3
     if tile <= 4:
         # all operands at once, SiLU, fp32 output
         ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7, V=Vd, vmode=1, vdiv=13,
@@ -95,7 +100,7 @@ def test_gemm_plain_epilogue(ops, tile, M, N, K):
             ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, act=1, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_geglu(ops, tile):
     from ctrlv_amd import packing
     M, C = 333, 320       # 8C = 2560: 8 tiles of 320 / 10 of 256; the ragged 333 rows span two 256-row tiles
@@ -200,33 +205,6 @@ def test_gemm_persistent_many_tiles(ops, tile):
     assert parity_err(outl, A.float() @ bf(wl).float().T + R1.float()) < 3e-3
 
 
-@pytest.mark.parametrize("geglu", [0, 1])
-def test_gemm_streamed_many_tiles_bit_identical(ops, geglu):
-    """Tile 9 (streamed 4-wave schedule, two workgroups per CU, 256 x 160): more tiles than workgroup slots, ragged
-    last M tile, N not a multiple of 160; same summation order and epilogue as the ping-pong tiles => identical bits."""
-    from ctrlv_amd import packing
-    M, K, N = 256 * 140 + 77, 320, 2560 if geglu else 1120      # 141 M-tiles x 16 / 7 N-tiles
-    A = bf(torch.randn(M, K, generator=g(1))).to(DEV)
-    wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
-    b = torch.randn(N, generator=g(3))
-    if geglu:
-        Wp, bp = packing.pack_geglu(wt, b)
-        kw = dict(N=N, cin=K, bias=bp.to(DEV), geglu=1)
-        n_out = N // 2
-    else:
-        Wp = packing.pack_linear(wt)
-        R1 = bf(torch.randn(M, N, generator=g(4))).to(DEV)
-        kw = dict(N=N, cin=K, bias=b.to(DEV), R1=R1, s1=0.75, s_acc=1.25)
-        n_out = N
-    outs = []
-    for tile in (9, 5):
-        out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=DEV)
-        ops.gemm(A, Wp.to(DEV), out, tile=tile, **kw)
-        outs.append(out)
-    assert not torch.isnan(outs[0].float()).any()
-    assert torch.equal(outs[0], outs[1])
-
-
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
@@ -325,57 +303,55 @@ def _sdpa_ref(q, k, v):        # [batch, heads, S, 64] fp32
     return F.scaled_dot_product_attention(q, k, v)
 
 
+def _spatial_attn(ops, qkv, n_img, S, C, prescaled):
+    """(out, fp32 reference) of the spatial core on bf16 `qkv` rows.  prescaled: the q columns are first multiplied by
+    (1/8) log2(e) and rounded to bf16 (what the q|k|v GEMM epilogue hands the prescaled entry point); the reference is then
+    the attention of THOSE q values divided by the factor again, so both forms are held to the same bound."""
+    from ctrlv_amd import ops as O
+    heads = C // 64
+    qkv = qkv.clone()
+    f = qkv.float().reshape(n_img, S, 3, heads, 64)
+    if prescaled:
+        qs = bf(f[:, :, 0] * O.Q_PRESCALE)
+        qkv = qkv.reshape(n_img, S, 3, heads, 64)
+        qkv[:, :, 0] = qs
+        qkv = qkv.reshape(n_img * S, 3 * C)
+        f = torch.stack([qs.float() / O.Q_PRESCALE, f[:, :, 1], f[:, :, 2]], dim=2)
+    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(n_img * S, C)
+    out = torch.empty(n_img * S, C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_spatial(qkv.to(DEV), out, n_img, S, C, prescaled=prescaled)
+    return out, ref
+
+
 # S >= 1024 runs the 64-rows-per-wave kernel (2304: full tiles; 1100: ragged last key tile and a partly empty last
 # 256-query block), shorter sequences the 32-row one
 @pytest.mark.parametrize("n_img,S,C", [(3, 200, 128), (2, 576, 64), (1, 2304, 320), (2, 1100, 128), (5, 16, 128),
                                        (2, 4, 64)])
-def test_attention_spatial(ops, n_img, S, C):
-    heads = C // 64
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_spatial(ops, n_img, S, C, prescaled):
     qkv = bf(torch.randn(n_img * S, 3 * C, generator=g(1)))
-    f = qkv.float().reshape(n_img, S, 3, heads, 64)
-    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(n_img * S, C)
-    out = torch.empty(n_img * S, C, dtype=torch.bfloat16, device=DEV)
-    ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
+    out, ref = _spatial_attn(ops, qkv, n_img, S, C, prescaled)
     assert parity_err(out, ref) < 5e-3
 
 
-def test_attention_spatial_experimental_kernels_still_correct():
-    """The opt-in schedules kept in-tree as documented experiments (CTRLV_ATTN_X=1: cross-tile pipelined kernel of
-    attention_pipe.hip; CTRLV_ATTN_PIPE=1: skewed row blocks) must stay correct: the spatial-attention tests of this file
-    re-run in a child process with each switch set (the switches are read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for var in ("CTRLV_ATTN_X", "CTRLV_ATTN_PIPE"):
-        env = dict(os.environ, **{var: "1"})
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-x", "-k",
-                            "attention_spatial and not experimental"], env=env, capture_output=True, text=True,
-                           timeout=600, cwd=root)
-        assert r.returncode == 0, (var, r.stdout[-1500:])
-
-
 @pytest.mark.parametrize("S,kpk", [(320, 300), (1280, 1200)])
-def test_attention_spatial_peaked(ops, S, kpk):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_spatial_peaked(ops, S, kpk, prescaled):
     """Online-softmax rescale path: one key dominates late in the sequence (running max jumps at a later tile); both the
     32-row (S = 320) and the 64-row (S = 1280) kernels."""
     n_img, C = 1, 64
     qkv = torch.randn(S, 3 * C, generator=g(1))
     qkv[:, :64] *= 3.0
     qkv[kpk, 64:128] = qkv[7, :64] * 4.0          # key kpk aligned with query 7
-    qkv = bf(qkv)
-    f = qkv.float().reshape(1, S, 3, 1, 64)
-    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(S, C)
-    out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
-    ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
+    out, ref = _spatial_attn(ops, bf(qkv), n_img, S, C, prescaled)
     assert parity_err(out, ref) < 5e-3
 
 
 @pytest.mark.parametrize("S", [448, 1216])
 @pytest.mark.parametrize("scale", [6.0, 40.0])
-def test_attention_spatial_large_scores(ops, S, scale):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_spatial_large_scores(ops, S, scale, prescaled):
     """Softmax robustness of the sum-triggered rescale (no per-element max pass): logits of magnitude ~scale^2 * 8 / 8
     (hundreds to thousands -- exp2 overflows without the max), drifting upwards along the key axis so that the running
     max has to be raised again and again, and long runs of near-equal large logits (row sums far above the 2^12 limit
@@ -386,12 +362,7 @@ def test_attention_spatial_large_scores(ops, S, scale):
     qkv[:, :64] *= scale
     qkv[:, 64:128] = (qkv[:, 64:128] * ramp + 0.5 * ramp) * scale          # keys grow along the sequence
     qkv[S // 2:S // 2 + 40, 64:128] = qkv[S // 2, 64:128]                  # 40 identical keys
-    qkv = bf(qkv)
-    f = qkv.float().reshape(1, S, 3, 1, 64)
-    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(S, C)
-    out = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
-    ops.attention_spatial(qkv.to(DEV), out, n_img, S, C)
+    out, ref = _spatial_attn(ops, bf(qkv), n_img, S, C, prescaled)
     assert torch.isfinite(out.float()).all()
     assert parity_err(out, ref) < 6e-3
 

@@ -39,7 +39,6 @@ def main():
     lib.ctrlv_gemm.argtypes = [ctypes.POINTER(_lib.GemmDesc), ctypes.c_void_p]
     dev = "cuda:0"
     torch.zeros(1, device=dev)
-    print("streamed kernel: resident workgroups per CU =", lib.ctrlv_gemm_st_occupancy())
     g = torch.Generator(device=dev).manual_seed(0)
     N0, N1 = 50 * 9216, 50 * 2304
     shapes = [("L0 qkv 320->960", N0, 960, 320, 1, 0, None, 6, 0),
