@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Developer aid: build variant copies of libctrlv_hip.so with extra -D flags (A/B in ONE gpurun session, same device).
-usage: python tools/ab_build.py NAME -DFOO=1 ...   -> gpurun_out/libctrlv_NAME.so ; select with CTRLV_HIP_LIB=<path>"""
+usage: python tools/ab_build.py NAME -DFOO=1 ...   -> ctrlv_amd/lib/ab/libctrlv_NAME.so ; select with CTRLV_HIP_LIB=<path>"""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 name, flags = sys.argv[1], sys.argv[2:]
-out_dir = os.path.join(ROOT, "gpurun_out")
+out_dir = os.path.join(ROOT, "ctrlv_amd", "lib", "ab")      # in-tree: travels to the GPU box (git-ignored *.so / *.o)
 os.makedirs(out_dir, exist_ok=True)
 procs, objs = [], []
 for s in g.HIP_SOURCES:

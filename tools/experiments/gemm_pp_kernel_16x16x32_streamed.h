@@ -23,6 +23,13 @@
 //     prologue per tile.  Group 1 stays one barrier slot behind group 0 across tiles.
 // Tiles: BN = 256 (waves 2x4, wave tile 128x64) and BN = 320 (waves 4x2, wave tile 64x160) -- the latter makes
 // N = 320 / 640 / 960 / 1920 exact multiples (the C = 320 / 640 levels of the UNet).
+// MFMA shape (round 3): v_mfma_f32_16x16x32_bf16 -- one instruction per 16 x 16 output block and 32-deep half-step.
+// Same fragment bytes per FLOP as the 32x32x16 form the kernel used before (14 ds_read_b128 per half-step for the
+// 64 x 160 wave tile either way) and the same matrix-pipe cycles, but the chip holds a HIGHER CLOCK on it under load:
+// tools/micro/mfma_shape.hip (this wave tile, fragments re-read from LDS, 2 waves per SIMD, random data, all CUs)
+// measured 1822 TFLOP/s at 1.90 GHz against 1620 at 1.71 GHz, 1395 vs 1412 cycles per half-step (MI355X_MICROARCH.md,
+// "DVFS give-back" item 7).  Result layout: lane l holds rows n = 4 (l >> 4) + r (r = 0..3) of column m = l & 15 of the
+// block, i.e. FOUR CONSECUTIVE output columns of one output row.
 #pragma once
 #include <type_traits>
 
@@ -33,9 +40,6 @@
 #define PP_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
 #define PP_SETPRIO(x)
-#endif
-#ifndef CTRLV_PP_SCHED
-#define CTRLV_PP_SCHED 0      // 0: ping-pong wave groups, 1: streamed (both documented at the kernel)
 #endif
 
 namespace {
@@ -102,15 +106,18 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
 }
 
 template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false>
-__device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
+__device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x4_t (&acc)[2 * TM][2 * TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3, const char* bias_lds, const char* gelu_tab) {
   constexpr unsigned kOOB = 0xFFFFFFFFu;
   constexpr int kFlags = 0x00020000;
-  const int r32 = lane & 31, hsel = lane >> 5, l4 = lane & 3;
-  // staging image: row r (0..31) lives in piece r>>3 at (r&7)*128 B; 16-B chunk c of a row is stored at c ^ (r&7)
-  char* const wpiece = (r32 < 8) ? p0 : (r32 < 16) ? p1 : (r32 < 24) ? p2 : p3;
-  char* const wrow = wpiece + (r32 & 7) * 128;
+  const int m16 = lane & 15, g4 = lane >> 4, l4 = lane & 3;
+  // staging image of one 32 x 32 fp32 sub-tile: row r (0..31) lives in piece r>>3 at (r&7)*128 B; 16-B chunk c of a row
+  // is stored at c ^ (r&7).  In the 16x16x32 result layout this lane holds, of block (a, b) of the sub-tile (a: 16-row
+  // half, b: 16-column half), row 16 a + m16, columns 16 b + 4 g4 .. + 3: chunk 4 b + g4.
+  char* const wrow0 = ((m16 < 8) ? p0 : p1) + (m16 & 7) * 128;      // rows 0..15  (a = 0)
+  char* const wrow1 = ((m16 < 8) ? p2 : p3) + (m16 & 7) * 128;      // rows 16..31 (a = 1)
+  const int wsw = m16 & 7;
   const int row_a = lane >> 2, row_b = 16 + row_a;   // rows read back in pass 0 / pass 1 (same r&7)
   const char* const rp_a = (row_a < 8 ? p0 : p1) + (row_a & 7) * 128;
   const char* const rp_b = (row_b < 24 ? p2 : p3) + (row_b & 7) * 128;
@@ -150,13 +157,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     struct Res { u32x4_t r1[2], r2[2]; };
     constexpr bool HAS_RES = (EPI & 6) != 0;
     // sub-tiles in flight before the first one is processed: bounded by what the 320-wide tile (252+ VGPRs) can hold
+#ifdef CTRLV_PP_P0
+    constexpr int P0 = TN > 2 ? CTRLV_PP_P0 : ((EPI & 4) ? 2 : 3);
+    constexpr int GROW = TN > 2 ? CTRLV_PP_GROW : ((EPI & 4) ? 1 : 2);
+#else
     constexpr int P0 = TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3);
     constexpr int GROW = (EPI & 4) ? 1 : (TN > 2 ? 2 : 2);          // additional sub-tiles issued per processed one
+#endif
     Res q[HAS_RES ? NSUB : 1];
     const int ocol0 = wbase_n + l4 * 8;
     // Addresses: ONE per-lane byte offset per operand (row m0, column ocol0) -- or out of range -- and the displacement
-    // of sub-tile (i, j) / pass as the SCALAR offset of the buffer access (only the per-lane part is range-checked):
-    // no per-(sub-tile, pass) lane offsets to compute or to keep in registers while all accumulators are still live.
+    // of sub-tile (i, j) / pass as the SCALAR offset of the buffer access (only the per-lane part is range-checked).
+    // Per-(sub-tile, pass) lane offsets cost two registers each while all accumulators are still live: the 320-wide tile
+    // spilled 30-60 of them per tile.
     const unsigned r1_base = (unsigned)m0 * (unsigned)(d.ldr1 * 2) + (unsigned)(ocol0 * 2);
     const unsigned r2_base = (unsigned)m0 * (unsigned)(d.ldr2 * 2) + (unsigned)(ocol0 * 2);
     const unsigned o_base = (unsigned)m0 * (unsigned)(d.ldo * 2) + (unsigned)(ocol0 * 2);
@@ -198,10 +211,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         }
       }
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int c = (2 * qd + hsel) ^ (r32 & 7);
-        *(float4*)(wrow + c * 16) =
-            make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+      for (int b = 0; b < 2; ++b) {
+        *(f32x4_t*)(wrow0 + (((4 * b + g4) ^ wsw) * 16)) = acc[2 * i][2 * j + b];
+        *(f32x4_t*)(wrow1 + (((4 * b + g4) ^ wsw) * 16)) = acc[2 * i + 1][2 * j + b];
       }
       __builtin_amdgcn_wave_barrier();     // compiler-only: the image is exchanged between lanes of this wave
       float4 img[2][2];
@@ -268,10 +280,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         const int i = s / TN, j = s % TN;
         const int ocol = wbase_n + j * 32 + l4 * 8;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int c = (2 * qd + hsel) ^ (r32 & 7);
-          *(float4*)(wrow + c * 16) =
-              make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+        for (int b = 0; b < 2; ++b) {
+          *(f32x4_t*)(wrow0 + (((4 * b + g4) ^ wsw) * 16)) = acc[2 * i][2 * j + b];
+          *(f32x4_t*)(wrow1 + (((4 * b + g4) ^ wsw) * 16)) = acc[2 * i + 1][2 * j + b];
         }
         __builtin_amdgcn_wave_barrier();
         float4 img[2][2];
@@ -294,11 +305,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         }
       }
     }
-    // GEGLU: weight rows come in 16-row (value, gate) blocks, so quads 0,1 of a 32x32 sub-tile are 16 values and
-    // quads 2,3 their gates, in the same lane: out = (a + ba) * gelu(g + bg) is computed in the MFMA layout (its bias
-    // is a per-column broadcast from the LDS strip) and two adjacent sub-tiles (16 outputs each) share one staged
+    // GEGLU: weight rows come in 16-row (value, gate) blocks, i.e. block 2 js of a 32-row sub-tile js holds 16 values and
+    // block 2 js + 1 their gates, in the same lane and register: out = (a + ba) * gelu(g + bg) is computed in the MFMA
+    // layout (the bias is already in the accumulators) and two adjacent sub-tiles (16 outputs each) share one staged
     // 32-column image; a lone last sub-tile fills only the left half.
     constexpr int NP = (TN + 1) / 2;
+    // (one per-lane output offset, row m0 / first output column of the wave tile; sub-tile displacements are scalar)
+    const unsigned og_base = (unsigned)m0 * (unsigned)(d.ldo * 2) + (unsigned)(((wbase_n >> 1) + l4 * 8) * 2);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -309,15 +322,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           const int js = j + half;
           if (js >= TN) continue;                          // compile time
 #pragma unroll
-          for (int qd = 0; qd < 2; ++qd) {
-            const f32x4_t g = {acc[i][js][4 * (qd + 2)], acc[i][js][4 * (qd + 2) + 1], acc[i][js][4 * (qd + 2) + 2],
-                               acc[i][js][4 * (qd + 2) + 3]};
-            const f32x4_t a = {acc[i][js][4 * qd], acc[i][js][4 * qd + 1], acc[i][js][4 * qd + 2], acc[i][js][4 * qd + 3]};
+          for (int a2 = 0; a2 < 2; ++a2) {
+            const f32x4_t a = acc[2 * i + a2][2 * js], g = acc[2 * i + a2][2 * js + 1];
             f32x4_t o;      // a * gelu(g), Phi from the LDS table (common.h: 8 VALU per gate instead of 20)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = geglu_tab(a[e], g[e], gelu_tab);
-            const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
-            *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
+            *(f32x4_t*)((a2 ? wrow1 : wrow0) + (((half * 4 + g4) ^ wsw) * 16)) = o;
           }
         }
         const int ocol = ((wbase_n + j * 32) >> 1) + l4 * 8;
@@ -339,8 +349,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           const int m = m0 + i * 32 + pass * 16;
           const uint4 pk = pack_bf16x8(o);
           const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
-          __builtin_amdgcn_raw_buffer_store_b128(
-              pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, (m < d.M && col_ok) ? og_base : kOOB,
+                                                 ((i * 32 + pass * 16) * d.ldo + j * 16) * 2, 0);
         }
       }
     }
@@ -361,18 +371,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   constexpr int A_Q = A_TOT / NW;                            // per wave (2)
   constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave (2 or 3; see the dummy piece below)
   static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
-  // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
-  // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue overlaps the matrix pipe).
-  // Whichever phase is longer sets the slot time, so NL balances them: A/B on one device (tools/ab_build.py
-  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 2 of 5 for the 320-wide one (20 MFMAs).
+  // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}; they are issued in the gaps
+  // between the MFMA groups of a half-step (see the K loop).
   constexpr int NPIECE = A_Q + B_Q;
-#ifdef CTRLV_PP_NL
-  constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
-#else
-  constexpr int NL = BN == 256 ? A_Q + 1 : A_Q;
-#endif
-  constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
-  static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
   // When B_TOT is not a multiple of the wave count (320-wide: 20 pieces, 8 waves) the waves without a real last piece
   // issue a DUMMY one -- out-of-range source (zeros, no memory traffic) into a private 1-KiB scratch strip -- so that
   // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
@@ -389,9 +390,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wid >> 2;                                  // waves w and w+4 share a SIMD -> different groups
   const int wr = wid / WN, wc = wid % WN;
-  const int r32 = lane & 31, hsel = lane >> 5;
+  const int m16 = lane & 15, g4 = lane >> 4;
 
   const int tiles_n = (d.N + BN - 1) / BN;
   const int tiles_m = (d.M + BM - 1) / BM;
@@ -413,7 +413,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // matrix pipe, so every bookkeeping instruction there is on the critical path (SQ counters: LDS and TA are < 20 %
   // busy, MFMA 40 % -- the loop was issue-bound, not bandwidth-bound).
   const int prow = lane >> 2, pslot = lane & 3;
-  const unsigned coff = (pslot ^ ((prow >> 2) & 3)) * 16;    // logical chunk this lane fetches (bytes); the piece
+  // 64-B LDS rows: physical 16-B chunk = logical ^ perm[(row >> 2) & 3], perm = {0, 2, 3, 1}.  A 16x16x32 fragment read
+  // has lane (m16, g4) on row m16 / logical chunk g4; this permutation puts the 16 lanes of every ds_read_b128 service
+  // group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... : MI355X_MICROARCH.md, LDS) on 16 distinct 16-B slots of the
+  // 256-B bank row.  Applied on the per-lane DMA SOURCE address (the LDS-DMA destination is lane-linear).
+  auto chunk_perm = [](int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; };
+  const unsigned coff = (pslot ^ chunk_perm(prow)) * 16;     // logical chunk this lane fetches (bytes); the piece
                                                              // base row is a multiple of 16, so (row>>2)&3 == (prow>>2)&3
   const unsigned kOOB = 0xFFFFFFFFu;
   const long a_rows = MODE == 1 ? (long)(d.M / (d.Ho * d.Wo)) * d.H * d.Wd : (long)d.M;
@@ -534,9 +539,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     is_cc = 0;
   };
 
-  const int sw = (r32 >> 2) & 3;
-  const int a_frag = (wr * WTM + r32) * 64;
-  const int b_frag = A_SLOT + (wc * WTN + r32) * 64;
+  const int fco = (g4 ^ chunk_perm(m16)) * 16;               // this lane's physical chunk of a fragment row
+  const int a_frag = (wr * WTM + m16) * 64 + fco;            // + 1024 per 16-row block
+  const int b_frag = A_SLOT + (wc * WTN + m16) * 64 + fco;
 
   // bias strip of this wave for the first tile (see pp_bias_load); its load is retired before any DMA is issued
   char* const bias_lds = smem + BIAS_OFF + wid * (WTN * 4);
@@ -545,22 +550,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
     pp_bias_store<WTN>(bias_lds, b, lane);
   }
-  // The first MFMAs of a tile start from the BIAS instead of zero: in the result layout a lane's 16 accumulators of a
-  // 32-column sub-tile are columns 8q + 4 hsel + r (q, r = 0..3), so the C operand is four ds_read_b128 from the strip.
-  // The epilogue then has no bias reads or adds at all (it was 12-17 % of its instructions, and the epilogue is what
-  // limits the K = 320 layers).
-  auto bias_c = [&](int n) {
-    f32x16 c;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *(const float4*)(bias_lds + (n * 32 + 8 * q + 4 * hsel) * 4);
-      c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-    }
-    return c;
-  };
+  // The first MFMA of every block of a tile starts from the BIAS instead of zero: in the result layout a lane's 4
+  // accumulators of a 16-column block are columns 4 g4 + r, so the C operand is one ds_read_b128 from the strip.  The
+  // epilogue then has no bias reads or adds at all (12-17 % of its instructions, and the epilogue is what limits the
+  // K = 320 layers).
+  auto bias_c = [&](int n16) { return *(const f32x4_t*)(bias_lds + (n16 * 16 + 4 * g4) * 4); };
   // Phi table: written here, read in the first epilogue -- every wave passes an `lgkmcnt(0)` + barrier of the K loop between
   if constexpr (GEGLU) gelu_table_fill(smem + TAB_OFF, threadIdx.x, NW * 64);
-  // ---- prologue: 3 half-steps in flight
+  // ---- prologue: 3 half-steps in flight; the fragments of half-step 0 in registers
   int is_tile = my_first;
   next_tile(is_tile);
   issue(0);
@@ -569,171 +566,89 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   wait_vmcnt<2 * NPIECE>();
   raw_barrier();
 
-  f32x16 acc[TM][TN];
+  // ================= K loop: STREAMED schedule with rolling fragment prefetch (round 3).
+  // v_mfma_f32_16x16x32_bf16 needs BOTH waves of a SIMD issuing to fill the matrix pipe: one wave alone sustains one
+  // every 26-33 cycles (tools/micro/mfma_shape.hip: 1256-1543 cycles per 40-MFMA half-step with one wave per SIMD against
+  // 1394 for the 80 MFMAs of two), so the ping-pong schedule this kernel had with the 32x32x16 shape -- one wave group in
+  // its MFMA phase while the other loads -- leaves the pipe half empty with this one.  Here all eight waves run the
+  // same stream, one raw s_barrier per half-step, and a wave's own 32-cycle MFMA cadence leaves the issue slots for its
+  // own memory instructions:
+  //   * the wave tile's blocks are walked along its LONGER side (the "rolling" operand: the 10 weight blocks of the
+  //     64 x 160 tile, the 8 row blocks of the 128 x 64 one): after the MFMA group of rolling block r -- the last use of
+  //     its fragment in this half-step -- the same registers are re-loaded with block r of half-step g+1 (ds_read_b128
+  //     from slot g+1), so the fragment reads of the next half-step ride inside this one's MFMA stream and cost no
+  //     registers; the shorter side's fragments (4 blocks) are double-buffered (16 registers);
+  //   * the LDS-DMA pieces of half-step g+3 go between the groups as well (slot (g+3)&3 = (g-1)&3 was last read
+  //     during half-step g-2);
+  //   * per half-step: retire this wave's own pieces of half-step g+1 (counted vmcnt: the pieces of g+2 stay in flight),
+  //     s_barrier (slot g+1 complete for every wave), then groups.  No lgkmcnt drain at the barrier: a fragment read
+  //     of slot g+1 is consumed by an MFMA of half-step g+1, i.e. it has returned long before slot g+1 is refilled
+  //     (DMA of g+5, two barriers later).
+  // The first half-step of a tile takes the bias as the C operand of its MFMAs (nothing is zeroed).
+  constexpr int TM16 = WTM / 16, TN16 = WTN / 16;            // 16 x 16 output blocks of the wave tile
+  constexpr bool ROLL_N = TN16 >= TM16;                      // rolling operand: weight blocks (else: row blocks)
+  constexpr int NR = ROLL_N ? TN16 : TM16, ND = ROLL_N ? TM16 : TN16;
+  const int roll_frag = ROLL_N ? b_frag : a_frag, dbl_frag = ROLL_N ? a_frag : b_frag;
+  f32x4_t acc[TM16][TN16];
+  bf16x8 rf[NR], df[2][ND];
+  {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rf[r] = *(const bf16x8*)(smem + roll_frag + r * 1024);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) df[0][q] = *(const bf16x8*)(smem + dbl_frag + q * 1024);
+  }
   int g = 0;
-  constexpr int HM = TM / 2;
-  // buffer stores a wave issues in one epilogue (straight-line code: out-of-range ones are issued and counted too)
-  constexpr int NSTORE = GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * 2;
-  static_assert(NPIECE + NPIECE + NSTORE <= 63, "vmcnt is a 6-bit counter");
-  bool after_epi = false;                                    // this workgroup has run an epilogue (tile > first)
 #ifdef CTRLV_PP_STAMP
   unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
   STAMP(t_begin);
 #endif
-#if CTRLV_PP_SCHED == 1
-  // ================= STREAMED schedule: no wave groups, one barrier per half-step, fragments double-buffered at
-  // k16 granularity (the same 2 x (TM + TN) fragment registers as the ping-pong loop, used as two k16 buffers).
-  //   first half  of half-step g: MFMAs on F0 = frag(g, k16 0) while F1 = frag(g, k16 1) streams in from slot g;
-  //   middle                    : retire own DMA(g+1), s_barrier  -> slot g+1 complete, slot g-1 no longer read;
-  //   second half               : MFMAs on F1 while F0 = frag(g+1, k16 0) streams in from slot g+1.
-  // The DMA pieces of half-step g+3 (into slot (g-1)&3, whose last reads every wave retired before the barrier of
-  // half-step g-1) sit in the gaps of the MFMA groups.  Both waves of a SIMD run this same loop, so the matrix pipe is
-  // fed by whichever has operands ready; nobody alternates phases.
-  auto read_frags = [&](const char* st, int ks, bf16x8 (&af)[TM], bf16x8 (&wf)[TN]) {
-    const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
-#pragma unroll
-    for (int n = 0; n < TN; ++n) wf[n] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
-  };
-  bf16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
-  read_frags(smem, 0, af0, wf0);
-  constexpr int N1 = (NPIECE + 1) / 2;                       // pieces issued in the first half
-  auto half_step = [&](int j, bool last_of_tile, auto first_tag) {
-    constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
-    const char* st = smem + (g & (NH - 1)) * SLOT;
-    read_frags(st, 1, af1, wf1);
-    issue_begin(g + 3);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i0 = h * HM;
-      PP_SETPRIO(1);
-      if (MAY_BE_FIRST && j == 0) {
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          const f32x16 bc = bias_c(n);
-#pragma unroll
-          for (int i = i0; i < i0 + HM; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], bc, 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], acc[i][n], 0, 0, 0);
-      }
-      PP_SETPRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < N1; ++k)
-        if (k * 2 / N1 == h) issue_piece(k);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // middle: own DMA(g+1) retired (DMA(g+2) and the N1 pieces just issued may stay in flight), F1 landed
-    wait_vmcnt<NPIECE + N1>();
-    lds_done_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last_of_tile) read_frags(smem + ((g + 1) & (NH - 1)) * SLOT, 0, af0, wf0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i0 = h * HM;
-      PP_SETPRIO(1);
-#pragma unroll
-      for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[n], af1[i], acc[i][n], 0, 0, 0);
-      PP_SETPRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NPIECE - N1; ++k)
-        if (k * 2 / (NPIECE - N1) == h) issue_piece(N1 + k);
-      if (h == 1) issue_end();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-#else
-  // ================= PING-PONG schedule (see the header of this file)
-  if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
-  auto half_step = [&](int j, bool /*last_of_tile*/, auto first_tag) {
-    constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
-    // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
-    const char* st = smem + (g & (NH - 1)) * SLOT;
-    bf16x8 af[TM][2], wf[TN][2];
+  auto half_step = [&](auto ph_tag, auto first_tag) {
+    constexpr int PH = decltype(ph_tag)::value;               // which half of the double buffer holds half-step g
+    constexpr bool FIRST = decltype(first_tag)::value;        // first half-step of a tile: C operand = bias
+    const char* nx = smem + ((g + 1) & (NH - 1)) * SLOT;      // slot of half-step g+1
     STAMP(t0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
-#pragma unroll
-      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
-    }
+    wait_vmcnt<NPIECE>();                                      // own pieces of half-step g+1 landed (g+2 may fly)
+    raw_barrier();
     STAMP(t1);
-    // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
-    // cluster below.  Then retire own DMA(g+1): the pieces of g+2 and the NL pieces just issued may stay in flight.
+    STAMP_ADD(c_lbar, t0, t1);
     issue_begin(g + 3);
-#pragma unroll
-    for (int pc = 0; pc < NL; ++pc) issue_piece(pc);
-    STAMP(t1b);
-    // `vmcnt` counts loads AND stores, in order.  The pieces retired here in the first two half-steps after an epilogue
-    // (half-steps g+1 of the new tile) were issued BEFORE that epilogue: its NSTORE stores are newer and may stay in
-    // flight -- with the steady-state count the wave would sit here until the tile's output has been acknowledged by
-    // HBM (stamps: 300-550 cycles per half-step on the K = 320 layers, averaged over the tile's ten).
-#ifdef CTRLV_PP_NO_EPI_VMCNT       // A/B handle (tools/ab_build.py)
-    if (false) {}
-#else
-    if (MAY_BE_FIRST && after_epi && j < 2) wait_vmcnt<NPIECE + NL + NSTORE>();
-#endif
-    else wait_vmcnt<NPIECE + NL>();
-    STAMP(t2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(t2b);
-    lds_done_barrier();
-    STAMP(t3);
-    STAMP_ADD(c_lread, t0, t1);
-    STAMP_ADD(c_lissue, t1, t1b);
-    STAMP_ADD(c_lwait, t1b, t2b);
-    STAMP_ADD(c_lbar, t2b, t3);
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
-    // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
 #pragma unroll
-    for (int grpi = 0; grpi < 4; ++grpi) {
-      const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
-      PP_SETPRIO(1);
-      if (MAY_BE_FIRST && j == 0 && ks == 0) {
+    for (int q = 0; q < ND; ++q) df[PH ^ 1][q] = *(const bf16x8*)(nx + dbl_frag + q * 1024);
 #pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          const f32x16 bc = bias_c(n);
+    for (int r = 0; r < NR; ++r) {
+      if constexpr (FIRST) {
+        if constexpr (ROLL_N) {
+          const f32x4_t bc = bias_c(r);
 #pragma unroll
-          for (int i = i0; i < i0 + HM; ++i)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], bc, 0, 0, 0);
+          for (int q = 0; q < ND; ++q) acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[r], df[PH][q], bc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < ND; ++q)
+            acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[PH][q], rf[r], bias_c(q), 0, 0, 0);
         }
       } else {
 #pragma unroll
-        for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+        for (int q = 0; q < ND; ++q) {
+          if constexpr (ROLL_N) acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[r], df[PH][q], acc[q][r], 0, 0, 0);
+          else acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[PH][q], rf[r], acc[r][q], 0, 0, 0);
+        }
       }
-      PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
+      rf[r] = *(const bf16x8*)(nx + roll_frag + r * 1024);
 #pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (k * 4 / NC == grpi) issue_piece(NL + k);
-      if (grpi == 3) issue_end();
+      for (int k = 0; k < NPIECE; ++k)
+        if ((2 * k + 1) * NR / (2 * NPIECE) == r) issue_piece(k);
+      if (r == NR - 1) issue_end();
       __builtin_amdgcn_sched_barrier(0);
     }
-    STAMP(t4);
-    // post-C barrier (pairs with the other group's post-L barrier)
-    raw_barrier();
-    STAMP(t5);
-    STAMP_ADD(c_mfma, t3, t4);
-    STAMP_ADD(c_cbar, t4, t5);
+    STAMP(t2);
+    STAMP_ADD(c_mfma, t1, t2);
   };
-#endif
+  // (J = taps * Cin / 32 is EVEN -- Cin is a multiple of 64 -- so every tile starts on double-buffer half 0 and the
+  // parity of a half-step inside the tile is static)
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
 
   for (int tr = 0; tr < my_ntiles; ++tr) {
     const int tile = my_first + tr * G;
@@ -741,22 +656,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     // The issue stream runs three half-steps ahead of the consuming one: it stays in this tile for J-3 half-steps and
     // then moves to the block's next tile (two K loops, so that the per-tile lane state is loop-invariant in each --
     // one loop with a conditional switch costs a dozen register copies per half-step).
-    // (the three-iteration tail is kept rolled: hipcc unrolls it fully, renames the accumulators between the copies and
-    // the 320-wide tile then needs 246-256 VGPRs instead of 233-240; the main loop keeps the compiler's own partial
-    // unrolling, which makes the ring-slot offsets constants: rolled it measured 3 % slower on the long-K convs)
-    for (int j = 0; j < J - 3; ++j, ++g) half_step(j, false, std::true_type{});
+    // (the loops are not unrolled: in unrolled copies hipcc writes the 16x16x32 MFMAs out of place -- D != C is legal
+    // for this shape -- and the renamed accumulators no longer fit: 16-byte scratch spills inside the K loop)
+    half_step(P0{}, std::true_type{}); ++g;
+#pragma clang loop unroll(disable)
+    for (int j = 1; j < J - 3; j += 2) {
+      half_step(P1{}, std::false_type{}); ++g;
+      half_step(P0{}, std::false_type{}); ++g;
+    }
     is_tile += G;
     next_tile(is_tile);
-#pragma clang loop unroll(disable)
-    for (int j = J - 3; j < J; ++j, ++g) half_step(j, j == J - 1, std::false_type{});
-#if CTRLV_PP_SCHED != 1
-    // Tile boundary.  Group 0 takes one EXTRA barrier before its epilogue (it pairs with group 1's last post-C
-    // barrier) and group 1 one after its epilogue (pairing with group 0's first post-L barrier of the next tile), so
-    // that the two epilogues run CONCURRENTLY instead of each group stalling at a barrier for the whole epilogue of
-    // the other (stamps: "C:barrier" was 1.3-2.5x the epilogue itself on the K = 320 layers).  The extra barrier also
-    // orders group 0's staging writes after group 1's last load phase, which still reads those ring pieces.
-    if (grp == 0) raw_barrier();
-#endif
+    half_step(P1{}, std::false_type{}); ++g;
+    half_step(P0{}, std::false_type{}); ++g;
+    half_step(P1{}, std::false_type{}); ++g;
+    // Tile boundary: all eight waves run their epilogues together.  The fragments of the next tile's first half-step
+    // are already in registers (or on their way: slot g) and its next two half-steps in flight.  The epilogue stages
+    // through this wave's own pieces of slot g-1; the barrier makes sure every wave has ISSUED the MFMAs of the tile's last
+    // half-step, i.e. has received every fragment it read from that slot.
+    raw_barrier();
     STAMP(t6);
     {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (every wave retired its reads
@@ -767,8 +684,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       u32x4_t nb = {0, 0, 0, 0};
       if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
       // The epilogue's lane constants (staging / read-back offsets, output column) do not depend on the tile: hipcc hoists
-      // them out of the persistent loop and keeps them live (or spills them) around the K loop, which has no registers to
-      // spare.  An opaque copy of the lane id makes them per-tile values: a dozen VALU instructions per tile instead.
+      // them out of the persistent loop and then SPILLS them around the K loop, which has no registers to spare
+      // (16-70 scratch accesses per tile).  An opaque copy of the lane id makes them per-tile values: a dozen VALU
+      // instructions per tile instead.
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, s0 + wid * 1024, s0 + (NW + wid) * 1024,
@@ -781,21 +699,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       // registers live through the epilogue.  An empty asm that "defines" them ends the old live ranges at their last
       // staging write: the epilogue's prefetch window and addresses then live in retired accumulator registers.
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM16; ++i)
 #pragma unroll
-        for (int n = 0; n < TN; ++n) asm volatile("" : "=v"(acc[i][n]));
+        for (int n = 0; n < TN16; ++n) asm volatile("" : "=v"(acc[i][n]));
     }
-    after_epi = true;
     STAMP(t7);
     STAMP_ADD(c_epi, t6, t7);
-#if CTRLV_PP_SCHED == 1
-    if (tr + 1 < my_ntiles) {     // first fragments of the next tile (its slot was completed by the last barrier)
-      read_frags(smem + (g & (NH - 1)) * SLOT, 0, af0, wf0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-#else
-    if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
-#endif
   }
   // the issue stream ran three half-steps past the end (zero-filled pieces): nothing may be in flight when the
   // workgroup's LDS is released

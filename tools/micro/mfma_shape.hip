@@ -15,10 +15,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kRows = 576, kSlot = kRows * 64, kSlots = 4;   // the 256x320 tile's ring: 4 x (256 + 320) rows of 64 B
 
-template <int SHAPE>
-__global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ src, float* out, unsigned long long* clk, int iters) {
+template <int SHAPE, int NT, int ORDER = 0>
+__global__ __launch_bounds__(NT) void k(const unsigned short* __restrict__ src, float* out, unsigned long long* clk, int iters) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  for (int i = threadIdx.x; i < kSlots * kSlot / 16; i += 512) ((uint4*)smem)[i] = ((const uint4*)src)[i];
+  for (int i = threadIdx.x; i < kSlots * kSlot / 16; i += NT) ((uint4*)smem)[i] = ((const uint4*)src)[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -78,10 +78,24 @@ __global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ src,
       for (int n = 0; n < 10; ++n) wf[n] = *(const bf16x8*)(st + b_frag + n * 1024);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(st + a_frag + i * 1024);
+      if constexpr (ORDER == 0) {          // i outer: 10 consecutive MFMAs share the B operand (af[i])
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int n = 0; n < 10; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[i], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 10; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[i], acc[i][n], 0, 0, 0);
+      } else if constexpr (ORDER == 1) {   // n outer: 4 consecutive MFMAs share the A operand (wf[n])
+#pragma unroll
+        for (int n = 0; n < 10; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[i], acc[i][n], 0, 0, 0);
+      } else {                             // diagonal: consecutive MFMAs share no operand
+#pragma unroll
+        for (int t = 0; t < 40; ++t) {
+          const int i = t & 3, n = (t + (t >> 2) * 3) % 10;
+          acc[i][(n + i * 0) % 10] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[i], acc[i][n], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -91,18 +105,18 @@ __global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ src,
         for (int e = 0; e < 4; ++e) s += acc[i][n][e];
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  out[blockIdx.x * 512 + threadIdx.x] = s;
+  out[blockIdx.x * NT + threadIdx.x] = s;
   if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <int SHAPE>
+template <int SHAPE, int NT, int ORDER = 0>
 double run(const unsigned short* src, float* out, unsigned long long* clk, int iters, bool print) {
   const int smem = kSlots * kSlot;
-  (void)hipFuncSetAttribute((const void*)k<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)hipFuncSetAttribute((const void*)k<SHAPE, NT, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipEvent_t s, e;
   (void)hipEventCreate(&s); (void)hipEventCreate(&e);
   (void)hipEventRecord(s);
-  hipLaunchKernelGGL(k<SHAPE>, dim3(256), dim3(512), smem, 0, src, out, clk, iters);
+  hipLaunchKernelGGL((k<SHAPE, NT, ORDER>), dim3(256), dim3(NT), smem, 0, src, out, clk, iters);
   (void)hipEventRecord(e);
   (void)hipEventSynchronize(e);
   float ms;
@@ -112,10 +126,10 @@ double run(const unsigned short* src, float* out, unsigned long long* clk, int i
   double ghz = 0;
   for (int b = 0; b < 256; ++b) ghz += (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;
   ghz /= 256;
-  const double flops = 2.0 * 64 * 160 * 32 * (double)iters * 8 * 256;
+  const double flops = 2.0 * 64 * 160 * 32 * (double)iters * (NT / 64) * 256;
   if (print)
-    printf("shape %2d: %8.3f ms  %7.0f TFLOP/s  in-kernel clock %.3f GHz  -> %.2f MFMA-pipe cycles per iteration per SIMD (ideal 1280)\n", SHAPE, ms,
-           flops / ms / 1e9, ghz, ms * 1e-3 * ghz * 1e9 / iters);
+    printf("shape %2d order %d, %d waves/SIMD: %8.3f ms  %7.0f TFLOP/s  in-kernel clock %.3f GHz  -> %.2f cycles per iteration per SIMD (matrix pipe alone: %d)\n", SHAPE,
+           NT / 256, ms, flops / ms / 1e9, ghz, ms * 1e-3 * ghz * 1e9 / iters, 640 * (NT / 256));
   return flops / ms / 1e9;
 }
 
@@ -132,10 +146,15 @@ int main(int argc, char** argv) {
   unsigned short* src; float* out; unsigned long long* clk;
   (void)hipMalloc(&src, n * 2); (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&clk, 512 * 8);
   (void)hipMemcpy(src, h, n * 2, hipMemcpyHostToDevice);
-  run<32>(src, out, clk, 2000, false); run<16>(src, out, clk, 2000, false);
-  for (int r = 0; r < 4; ++r) {      // interleaved rounds on one device (guide rule 24); each launch runs ~0.1-0.2 s
-    run<32>(src, out, clk, iters, true);
-    run<16>(src, out, clk, iters, true);
+  run<32, 512>(src, out, clk, 2000, false); run<16, 512>(src, out, clk, 2000, false);
+  for (int r = 0; r < 3; ++r) {      // interleaved rounds on one device (guide rule 24); each launch runs ~0.1-0.2 s
+    run<32, 512>(src, out, clk, iters, true);
+    run<16, 512>(src, out, clk, iters, true);
+    run<32, 256>(src, out, clk, iters, true);      // one wave per SIMD: what a ping-pong schedule's compute phase gets
+    run<16, 256>(src, out, clk, iters, true);
+    run<16, 256, 1>(src, out, clk, iters, true);
+    run<16, 256, 2>(src, out, clk, iters, true);
+    run<16, 512, 1>(src, out, clk, iters, true);
   }
   return 0;
 }
