@@ -692,10 +692,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     STAMP(t2b);
     lds_done_barrier();
     STAMP(t3);
+#if defined(CTRLV_PP_STAMP) && CTRLV_PP_STAMP == 2     // by position in the tile: whole L phase of half-step 0 / 1 / 2 / >= 3
+    if (j == 0) { STAMP_ADD(c_lread, t0, t3); } else if (j == 1) { STAMP_ADD(c_lissue, t0, t3); }
+    else if (j == 2) { STAMP_ADD(c_lwait, t0, t3); } else { STAMP_ADD(c_lbar, t0, t3); }
+#else
     STAMP_ADD(c_lread, t0, t1);
     STAMP_ADD(c_lissue, t1, t1b);
     STAMP_ADD(c_lwait, t1b, t2b);
     STAMP_ADD(c_lbar, t2b, t3);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- C phase: 4 MFMA groups from registers with the DMA pieces of half-step g+3 in the gaps
     // (first half-step of a tile starts from a literal-zero C operand instead of zeroing 128-160 registers)
@@ -730,8 +735,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     // post-C barrier (pairs with the other group's post-L barrier)
     raw_barrier();
     STAMP(t5);
+#if defined(CTRLV_PP_STAMP) && CTRLV_PP_STAMP == 2     // whole C phase of half-step 0 / 1-2 / >= 3 (c_epi: see the tile loop)
+    if (j == 0) { STAMP_ADD(c_mfma, t3, t5); } else if (j < 3) { STAMP_ADD(c_cbar, t3, t5); } else { STAMP_ADD(c_epi, t3, t5); }
+#else
     STAMP_ADD(c_mfma, t3, t4);
     STAMP_ADD(c_cbar, t4, t5);
+#endif
   };
 #endif
 
@@ -787,7 +796,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     }
     after_epi = true;
     STAMP(t7);
+#if !(defined(CTRLV_PP_STAMP) && CTRLV_PP_STAMP == 2)
     STAMP_ADD(c_epi, t6, t7);
+#endif
 #if CTRLV_PP_SCHED == 1
     if (tr + 1 < my_ntiles) {     // first fragments of the next tile (its slot was completed by the last barrier)
       read_frags(smem + (g & (NH - 1)) * SLOT, 0, af0, wf0);

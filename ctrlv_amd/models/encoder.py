@@ -86,6 +86,24 @@ class SpatioTemporalEncoderBase(HipModelMixin):
             object.__setattr__(self, "_plan", None)
         super().__setattr__(name, value)
 
+    def _param_fingerprint(self):
+        """Changes whenever a parameter is modified in place (optimizer.step(), copy_) or replaced: the packed weights of
+        both executors are keyed on it, so a forward after a training step runs on the UPDATED weights (the reference's
+        periodic validation call, tools/train_video_controlnet.py log_validation)."""
+        ver, first = 0, 0
+        for q in self.parameters():
+            ver += q._version
+            if first == 0:
+                first = q.data_ptr()
+        return ver, first
+
+    def _check_params_unchanged(self):
+        fp = self._param_fingerprint()
+        if getattr(self, "_packed_fp", None) != fp:
+            if getattr(self, "_packed_fp", None) is not None:
+                self._packed = False                     # (also drops the plan)
+            object.__setattr__(self, "_packed_fp", fp)
+
     # ------------------------------------------------------------------------------------------- C++ plan
     def _use_plan(self):
         return (self.executor == "plan" and getattr(self, "_trace", None) is None and _prof._active is None)
@@ -99,6 +117,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
                                      f"(got a {sample.device} input)")
         if self.device != sample.device:
             raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
+        self._check_params_unchanged()
         if self._plan is None:
             plan = Plan(self._plan_kind, self.config, sample.device, self.time_context_order)
             plan.load_state_dict(self.state_dict())
@@ -195,6 +214,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
                                      f"(got a {sample.device} input)")
         if self.device != sample.device:
             raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
+        self._check_params_unchanged()
         if not self._packed:
             self.pack()
         # one activation arena per execution lane: DenoiseStepper runs the two CFG halves of a step as concurrent

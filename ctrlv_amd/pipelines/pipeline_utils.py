@@ -195,6 +195,12 @@ def resolve_pretrained_dir(name_or_path):
         return None
 
 
+class ClipJob:
+    """Everything one pipeline call has prepared before its denoising loop (SVDPipelineBase.prepare_clip)."""
+    __slots__ = ("height", "width", "num_frames", "decode_chunk", "clips", "device", "clip_embeds", "cond_latents",
+                 "time_ids", "latents", "vae_was_fp16")
+
+
 class SVDPipelineBase:
     """Component registry + the inherited helpers + the HIP denoising loop."""
 
@@ -420,6 +426,67 @@ class SVDPipelineBase:
         return frames.float()
 
     # ---- the hot loop --------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------- call scaffolding
+    def prepare_clip(self, image, check, *, height, width, num_frames, decode_chunk_size, fps, motion_bucket_id,
+                     noise_aug_strength, num_videos_per_prompt, generator, latents, latent_channels,
+                     min_guidance_scale, max_guidance_scale, num_inference_steps):
+        """The part of a pipeline call that precedes the loop, shared by both pipelines: resolve sizes, validate
+        (`check(height, width)` = the pipeline's check_inputs), CLIP-embed the first frame, noise-augment and VAE-encode it,
+        micro-conditioning ids, timestep schedule, initial noise and the per-frame guidance ramp.  Behaviour follows
+        pipeline_video_control.py:196-292 / pipeline_video_diffusion.py:131-228; in particular the two random draws happen
+        in the reference's order (augmentation noise first, initial latents second), so a seeded generator gives the
+        reference's sample.  Returns a ClipJob."""
+        job = ClipJob()
+        unet_cfg = self.unet.config
+        job.height = height or unet_cfg.sample_size * self.vae_scale_factor
+        job.width = width or unet_cfg.sample_size * self.vae_scale_factor
+        job.num_frames = unet_cfg.num_frames if num_frames is None else num_frames
+        job.decode_chunk = job.num_frames if decode_chunk_size is None else decode_chunk_size
+        check(job.height, job.width)
+        if PIL is not None and isinstance(image, PIL.Image.Image):
+            job.clips = 1
+        else:
+            job.clips = len(image) if isinstance(image, list) else image.shape[0]
+        dev = job.device = self._execution_device
+        self._guidance_scale = max_guidance_scale              # scalar first: do_classifier_free_guidance reads it
+        cfg = self.do_classifier_free_guidance
+        job.clip_embeds = self._encode_image(image, dev, num_videos_per_prompt, cfg)
+        dt = job.clip_embeds.dtype
+        # first frame -> (noise-augmented) VAE latent, repeated over the frames
+        pixels = self.image_processor.preprocess(image, height=job.height, width=job.width).to(dev)
+        pixels = pixels + noise_aug_strength * randn_tensor(pixels.shape, generator=generator, device=dev,
+                                                             dtype=pixels.dtype)                  # random draw 1
+        job.vae_was_fp16 = self.vae.dtype == torch.float16 and getattr(self.vae.config, "force_upcast", False)
+        if job.vae_was_fp16:
+            self.vae.to(dtype=torch.float32)
+        first = self._encode_vae_image(pixels.to(self.vae.dtype), device=dev, num_videos_per_prompt=num_videos_per_prompt,
+                                       do_classifier_free_guidance=cfg)
+        job.cond_latents = first.to(dt).unsqueeze(1).repeat(1, job.num_frames, 1, 1, 1)
+        # SVD is conditioned on fps - 1
+        job.time_ids = self._get_add_time_ids(fps - 1, motion_bucket_id, noise_aug_strength, dt, job.clips,
+                                              num_videos_per_prompt, cfg).to(dev)
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        self._num_timesteps = len(self.scheduler.timesteps)
+        n = job.clips * num_videos_per_prompt
+        job.latents = self.prepare_latents(n, job.num_frames, latent_channels, job.height, job.width, dt, dev, generator,
+                                           latents)                                               # random draw 2
+        ramp = torch.linspace(min_guidance_scale, max_guidance_scale, job.num_frames, device="cpu")
+        self._guidance_scale = ramp.to(dev, job.latents.dtype).unsqueeze(0).repeat(n, 1)[:, :, None, None, None]
+        return job
+
+    def finish_clip(self, job, latents, output_type, return_dict, clamp=False):
+        """Decode (unless latents are asked for), post-process, restore the VAE dtype, wrap the output."""
+        frames = latents
+        if output_type != "latent":
+            frames = self.decode_latents(latents.to(self.vae.dtype), job.num_frames, job.decode_chunk)
+            if clamp:
+                frames = torch.clamp(frames, -1, 1)
+            frames = tensor2vid(frames, self.image_processor, output_type=output_type)
+        if job.vae_was_fp16:
+            self.vae.to(dtype=torch.float16)
+        self.maybe_free_model_hooks()
+        return StableVideoDiffusionPipelineOutput(frames=frames) if return_dict else frames
+
     def _denoise(self, latents, image_latents, image_embeddings, added_time_ids, cond_em, num_inference_steps,
                  min_guidance_scale, max_guidance_scale, control_condition_scale, callback_on_step_end,
                  callback_on_step_end_tensor_inputs, progress_bar):

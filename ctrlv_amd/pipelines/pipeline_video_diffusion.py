@@ -7,8 +7,7 @@ from typing import Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 
-from .pipeline_utils import (PIL, StableVideoDiffusionPipelineOutput, SVDPipelineBase, VaeImageProcessor,
-                             randn_tensor, tensor2vid)
+from .pipeline_utils import PIL, SVDPipelineBase, VaeImageProcessor
 
 
 class VideoDiffusionPipeline(SVDPipelineBase):
@@ -56,63 +55,19 @@ class VideoDiffusionPipeline(SVDPipelineBase):
         return_dict: bool = True,
         num_cond_bbox_frames: int = 3,
     ):
-        height = height or self.unet.config.sample_size * self.vae_scale_factor
-        width = width or self.unet.config.sample_size * self.vae_scale_factor
-        num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
-        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
-        self.check_inputs(image, height, width)
-        if PIL is not None and isinstance(image, PIL.Image.Image):
-            batch_size = 1
-        elif isinstance(image, list):
-            batch_size = len(image)
-        else:
-            batch_size = image.shape[0]
-        device = self._execution_device
-        self._guidance_scale = max_guidance_scale
-        image_embeddings = self._encode_image(image, device, num_videos_per_prompt, self.do_classifier_free_guidance)
-        fps = fps - 1
-        image = self.image_processor.preprocess(image, height=height, width=width).to(device)
-        noise = randn_tensor(image.shape, generator=generator, device=device, dtype=image.dtype)
-        image = image + noise_aug_strength * noise
-        needs_upcasting = self.vae.dtype == torch.float16 and getattr(self.vae.config, "force_upcast", False)
-        if needs_upcasting:
-            self.vae.to(dtype=torch.float32)
-        image_latents = self._encode_vae_image(image.to(self.vae.dtype), device=device,
-                                               num_videos_per_prompt=num_videos_per_prompt,
-                                               do_classifier_free_guidance=self.do_classifier_free_guidance)
-        image_latents = image_latents.to(image_embeddings.dtype)
-        image_latents = image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
-        added_time_ids = self._get_add_time_ids(fps, motion_bucket_id, noise_aug_strength, image_embeddings.dtype,
-                                                batch_size, num_videos_per_prompt, self.do_classifier_free_guidance)
-        added_time_ids = added_time_ids.to(device)
-        self.scheduler.set_timesteps(num_inference_steps, device=device)
-        timesteps = self.scheduler.timesteps
-        num_channels_latents = self.unet.config.in_channels
-        latents = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, num_channels_latents, height,
-                                       width, image_embeddings.dtype, device, generator, latents)
-        if bbox_images is not None:                                          # :200-206
-            cond_latents = self._encode_vae_condition(bbox_images, device, num_videos_per_prompt,
-                                                      self.do_classifier_free_guidance).to(image_latents.dtype)
-            image_latents[:, 0:num_cond_bbox_frames] = cond_latents[:, 0:num_cond_bbox_frames]
-            image_latents[:, -1] = cond_latents[:, -1]
-        guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames).unsqueeze(0)
-        guidance_scale = guidance_scale.to(device, latents.dtype)
-        guidance_scale = guidance_scale.repeat(batch_size * num_videos_per_prompt, 1)
-        self._guidance_scale = guidance_scale[:, :, None, None, None]
-        self._num_timesteps = len(timesteps)
-        with self.progress_bar(total=num_inference_steps) as progress_bar:
-            latents = self._denoise(latents, image_latents, image_embeddings, added_time_ids, None,
-                                    num_inference_steps, min_guidance_scale, max_guidance_scale, 1.0,
-                                    callback_on_step_end, callback_on_step_end_tensor_inputs, progress_bar)
-        if not output_type == "latent":
-            frames = self.decode_latents(latents.to(self.vae.dtype), num_frames, decode_chunk_size)
-            frames = torch.clamp(frames, -1, 1)                              # :297
-            frames = tensor2vid(frames, self.image_processor, output_type=output_type)
-        else:
-            frames = latents
-        if needs_upcasting:
-            self.vae.to(dtype=torch.float16)
-        self.maybe_free_model_hooks()
-        if not return_dict:
-            return frames
-        return StableVideoDiffusionPipelineOutput(frames=frames)
+        job = self.prepare_clip(
+            image, lambda h, w: self.check_inputs(image, h, w), height=height, width=width, num_frames=num_frames,
+            decode_chunk_size=decode_chunk_size, fps=fps, motion_bucket_id=motion_bucket_id,
+            noise_aug_strength=noise_aug_strength, num_videos_per_prompt=num_videos_per_prompt, generator=generator,
+            latents=latents, latent_channels=self.unet.config.in_channels, min_guidance_scale=min_guidance_scale,
+            max_guidance_scale=max_guidance_scale, num_inference_steps=num_inference_steps)
+        if bbox_images is not None:        # bbox-frame latents replace the first / last conditioning frames (:200-206)
+            boxes = self._encode_vae_condition(bbox_images, job.device, num_videos_per_prompt,
+                                               self.do_classifier_free_guidance).to(job.cond_latents.dtype)
+            job.cond_latents[:, 0:num_cond_bbox_frames] = boxes[:, 0:num_cond_bbox_frames]
+            job.cond_latents[:, -1] = boxes[:, -1]
+        with self.progress_bar(total=num_inference_steps) as bar:
+            out = self._denoise(job.latents, job.cond_latents, job.clip_embeds, job.time_ids, None,
+                                num_inference_steps, min_guidance_scale, max_guidance_scale, 1.0,
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, bar)
+        return self.finish_clip(job, out, output_type, return_dict, clamp=True)      # decoded frames clamped (:297)

@@ -34,21 +34,26 @@ from torch import nn
 # The marks sit where ctrlv_amd/models/blocks.py writes a kernel output; fused epilogues (residual adds, AlphaBlender,
 # the temb / frame-embedding / cross-attention row vectors) are therefore rounded once, after the fused sum.
 _STORE_DTYPE = [None]
+_TRUNK_DTYPE = ["same"]
 
 
-def store(x):
-    dt = _STORE_DTYPE[0]
+def store(x, trunk=False):
+    """Storage point of the HIP path.  trunk=True marks the RESIDUAL STREAM (block inputs / outputs, the tensors every
+    branch is added back into); `storage_rounding(dtype, trunk_dtype=...)` can give it its own storage precision
+    (tools/trunk_precision_study.py: what an fp32 residual trunk under bf16 branches would buy)."""
+    dt = _TRUNK_DTYPE[0] if (trunk and _TRUNK_DTYPE[0] != "same") else _STORE_DTYPE[0]
     return x if dt is None else x.to(dt).to(x.dtype)
 
 
 @contextlib.contextmanager
-def storage_rounding(dtype=torch.bfloat16):
-    prev = _STORE_DTYPE[0]
-    _STORE_DTYPE[0] = dtype
+def storage_rounding(dtype=torch.bfloat16, trunk_dtype="same"):
+    """trunk_dtype: "same" (default: like every other store), None (trunk kept in fp32) or a torch dtype."""
+    prev = _STORE_DTYPE[0], _TRUNK_DTYPE[0]
+    _STORE_DTYPE[0], _TRUNK_DTYPE[0] = dtype, trunk_dtype
     try:
         yield
     finally:
-        _STORE_DTYPE[0] = prev
+        _STORE_DTYPE[0], _TRUNK_DTYPE[0] = prev
 
 
 # --------------------------------------------------------------------------- embeddings (A.2)
@@ -108,8 +113,8 @@ class ResnetBlock2D(nn.Module):
         h = store(h + temb)
         h = self.conv2(store(self.nonlinearity(self.norm2(h))))
         if self.conv_shortcut is not None:
-            input_tensor = store(self.conv_shortcut(input_tensor))
-        return store(input_tensor + h)
+            input_tensor = store(self.conv_shortcut(input_tensor), trunk=True)
+        return store(input_tensor + h, trunk=True)
 
 
 class TemporalResnetBlock(nn.Module):
@@ -180,7 +185,7 @@ class SpatioTemporalResBlock(nn.Module):
         temb = temb.reshape(batch_size, num_frames, -1)
         hidden_states = self.temporal_res_block(hidden_states, temb)
         hidden_states = store(self.time_mixer(x_spatial=hidden_states_mix, x_temporal=hidden_states,
-                                              image_only_indicator=image_only_indicator))
+                                              image_only_indicator=image_only_indicator), trunk=True)
         return hidden_states.permute(0, 2, 1, 3, 4).reshape(batch_frames, channels, height, width)
 
 
@@ -246,8 +251,8 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states):
         hidden_states = self.attn1(store(self.norm1(hidden_states))) + hidden_states
-        hidden_states = store(self.attn2(self.norm2(hidden_states), encoder_hidden_states) + hidden_states)
-        hidden_states = store(self.ff(store(self.norm3(hidden_states))) + hidden_states)
+        hidden_states = store(self.attn2(self.norm2(hidden_states), encoder_hidden_states) + hidden_states, trunk=True)
+        hidden_states = store(self.ff(store(self.norm3(hidden_states))) + hidden_states, trunk=True)
         return hidden_states
 
 
@@ -275,10 +280,10 @@ class TemporalBasicTransformerBlock(nn.Module):
         hidden_states = self.ff_in(store(self.norm_in(hidden_states)))
         if self.is_res:
             hidden_states = hidden_states + residual
-        hidden_states = store(hidden_states)
+        hidden_states = store(hidden_states, trunk=True)
         hidden_states = self.attn1(store(self.norm1(hidden_states)), encoder_hidden_states=None) + hidden_states
         hidden_states = store(self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states)
-                              + hidden_states)
+                              + hidden_states, trunk=True)
         ff_output = self.ff(store(self.norm3(hidden_states)))
         hidden_states = ff_output + hidden_states if self.is_res else ff_output
 
@@ -330,7 +335,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         hidden_states = store(self.norm(hidden_states))
         inner_dim = hidden_states.shape[1]
         hidden_states = hidden_states.permute(0, 2, 3, 1).reshape(batch_frames, height * width, inner_dim)
-        hidden_states = store(self.proj_in(hidden_states))
+        hidden_states = store(self.proj_in(hidden_states), trunk=True)
 
         num_frames_emb = torch.arange(num_frames, device=hidden_states.device)
         num_frames_emb = num_frames_emb.repeat(batch_size, 1).reshape(-1)
@@ -343,11 +348,11 @@ class TransformerSpatioTemporalModel(nn.Module):
             hidden_states_mix = temporal_block(hidden_states_mix, num_frames=num_frames,
                                                encoder_hidden_states=time_context)
             hidden_states = store(self.time_mixer(x_spatial=hidden_states, x_temporal=hidden_states_mix,
-                                                  image_only_indicator=image_only_indicator))
+                                                  image_only_indicator=image_only_indicator), trunk=True)
 
         hidden_states = self.proj_out(hidden_states)
         hidden_states = hidden_states.reshape(batch_frames, height, width, inner_dim).permute(0, 3, 1, 2).contiguous()
-        return store(hidden_states + residual)
+        return store(hidden_states + residual, trunk=True)
 
 
 # --------------------------------------------------------------------------- resampling (A.5, a8)
@@ -357,7 +362,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return store(self.conv(x))
+        return store(self.conv(x), trunk=True)
 
 
 class Upsample2D(nn.Module):
@@ -372,7 +377,7 @@ class Upsample2D(nn.Module):
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if dtype == torch.bfloat16:
             x = x.to(dtype)
-        return store(self.conv(x))
+        return store(self.conv(x), trunk=True)
 
 
 # --------------------------------------------------------------------------- block wiring (A.5)

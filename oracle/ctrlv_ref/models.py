@@ -137,15 +137,15 @@ class UNetSpatioTemporalConditionModel(nn.Module, _EncoderMixin):
         sample = sample.flatten(0, 1)                                                        # :89
         emb = emb.repeat_interleave(num_frames, dim=0)                                       # :92
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)   # :94
-        sample = store(self.conv_in(sample))                                                 # :97
+        sample = store(self.conv_in(sample), trunk=True)                                                 # :97
         image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
         sample, down_block_res_samples = self._down(sample, emb, encoder_hidden_states, image_only_indicator)
         if is_controlnet:                                                                    # :119-127
-            down_block_res_samples = tuple(store(s + r) for s, r in zip(down_block_res_samples,
+            down_block_res_samples = tuple(store(s + r, trunk=True) for s, r in zip(down_block_res_samples,
                                                                         down_block_additional_residuals))
         sample = self.mid_block(sample, emb, encoder_hidden_states, image_only_indicator)   # :130-135
         if is_controlnet:
-            sample = store(sample + mid_block_additional_residuals)                          # :136-137
+            sample = store(sample + mid_block_additional_residuals, trunk=True)                          # :136-137
         for blk in self.up_blocks:                                                           # :140-158
             res_samples = down_block_res_samples[-len(blk.resnets):]
             down_block_res_samples = down_block_res_samples[: -len(blk.resnets)]
@@ -231,7 +231,7 @@ class ControlNetModel(nn.Module, _EncoderMixin):
         control_cond = control_cond.flatten(0, 1)
         emb = emb.repeat_interleave(num_frames, dim=0)
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)
-        sample = store(self.conv_in(sample) + self.control_conv_in(control_cond))            # :297-299
+        sample = store(self.conv_in(sample) + self.control_conv_in(control_cond), trunk=True)            # :297-299
         image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
         sample, down_block_res_samples = self._down(sample, emb, encoder_hidden_states, image_only_indicator)
         sample = self.mid_block(sample, emb, encoder_hidden_states, image_only_indicator)   # :322-327

@@ -53,6 +53,18 @@ def test_fullwidth_reference_default_latent_40x64(full_pair):
     check_tables(err)
 
 
+def test_fullwidth_full_latent_72x128(full_pair):
+    """The benchmark's own latent (576 x 1024 -> 72 x 128: S = 9216 / 2304 / 576 / 144 tokens per level -- the 64-row
+    spatial-attention kernel, the 256 x 320 GEMM tile on 18 432-row matrices, 36-chunk GroupNorms) at production widths
+    against the fp32 CPU oracle: 2 frames, no CFG, rel-L2 AND element bound (parity_err).  ~9 TFLOP for the oracle
+    (about 10 s on the GPU box's host cores); the whole-model comparison of tests/test_fullsize_gpu.py at this size is
+    property-based, this one is against the oracle."""
+    cfg, pair = full_pair
+    err = run_parity(cfg, DEV, B=1, F=2, h=72, w=128, time_context_order="sb", verbose=True, pair=pair,
+                     torch_bf16=False, with_unet_no_ctrl=False)
+    assert max(err["fp32"].values()) < 1.5e-2, err
+
+
 def test_fullwidth_error_growth_trace(full_pair):
     """Error after each of the 55 blocks at production widths (CFG batch 2): slow walk, no jump."""
     from tests.parity_utils import error_growth_trace, make_inputs, set_context_order
@@ -114,7 +126,7 @@ def test_fullwidth_train_step_matches_oracle_autograd(full_pair):
             print(f"  {v:.2e}  d/d {n}")
         print(f"  {len(got)} parameter gradients (680.9 M values), concatenated: rel-L2 {tot:.2e}   (torch bf16: {ytot:.2e})")
         assert tot < 3e-2 and tot < 1.5 * ytot
-        assert worst[0][0] < 1e-1, worst[:3]
+        assert worst[0][0] < 5e-2, worst[:3]
     finally:
         for m in (oc, hc):
             for p in m.parameters():

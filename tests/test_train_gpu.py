@@ -111,7 +111,7 @@ def test_train_step_matches_oracle_autograd(hip_lib):
             mix_worst = max(mix_worst, ae / mixmax)
             assert ae < 5e-2 * mixmax, (n, ae, mixmax)
         else:
-            assert v < 1e-1 and v < max(3.0 * yard[n], 2e-2), (n, v, yard[n])
+            assert v < 5e-2 and v < max(3.0 * yard[n], 2e-2), (n, v, yard[n])
     print(f"  mix factors: worst absolute error / largest mix-factor gradient = {mix_worst:.2e} (bound 5e-2)")
 
 
@@ -134,3 +134,41 @@ def test_adamw_step_moves_the_zero_convs(hip_lib):
     assert all(math.isfinite(v) for v in losses)
     assert float((hc.controlnet_down_blocks[0].weight.detach() - zc0).abs().max()) > 0.0      # zero-convs start to learn
     assert all(torch.equal(a, p) for a, p in zip(before_u, hu.parameters()))
+
+
+def test_forward_after_an_optimizer_step_uses_the_updated_weights(hip_lib):
+    """train_step updates the fp32 masters in place; the packed weights of BOTH inference executors (Python
+    packing and the library-owned C++ plan) must follow.  forward -> two AdamW steps -> forward again: the ControlNet's
+    output changes and matches the oracle evaluated with the updated parameters (the reference's periodic
+    log_validation call, tools/train_video_controlnet.py)."""
+    import ctrlv_ref as R
+    from tests.parity_utils import make_inputs, parity_err
+    from ctrlv_amd.training import train_step
+    config = dict(R.TINY_CONFIG)
+    ou, oc, hu, hc = make_pair(config, DEV, seed=6)
+    hc.float()
+    for p in hu.parameters():
+        p.requires_grad_(False)
+    sample, t, ehs, ids, cond = make_inputs(config, 1, 3, 16, 16)
+    dev = lambda x: x.to(device=DEV, dtype=torch.float32)   # noqa: E731
+
+    def fwd(executor):
+        hc.executor = executor
+        with torch.no_grad():
+            d, m = hc(dev(sample), t.to(DEV), dev(ehs), ids.to(DEV), control_cond=dev(cond), conditioning_scale=1.0,
+                      return_dict=False)
+        torch.cuda.synchronize()
+        return m.float().cpu()
+
+    before = {ex: fwd(ex) for ex in ("plan", "python")}
+    opt = torch.optim.AdamW([p for p in hc.parameters() if p.requires_grad], lr=3e-3, weight_decay=0.0)
+    bd = {k: v.to(DEV) for k, v in _batch(config, 1, 3, 16, 16, seed=9).items()}
+    for _ in range(2):
+        train_step(hc, hu, bd, optimizer=opt)
+    oc.load_state_dict({k: v.detach().float().cpu().to(torch.bfloat16).float() for k, v in hc.state_dict().items()})
+    with torch.no_grad():
+        _, ref = oc(sample, t, ehs, ids, control_cond=cond, conditioning_scale=1.0)
+    for ex in ("plan", "python"):
+        after = fwd(ex)
+        assert float((after - before[ex]).abs().max()) > 0.0, ex           # the forward saw the optimizer's update
+        assert parity_err(after, ref.float(), f"mid residual after training, {ex} executor") < 2e-2

@@ -23,7 +23,7 @@ def build():
             continue
         o = os.path.join(ROOT, "gpurun_out", s + ".stamp.o")
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                                       "-DCTRLV_PP_STAMP", "-c", os.path.join(CSRC, s), "-o", o]))
+                                       "-DCTRLV_PP_STAMP=" + os.environ.get("STAMP_MODE", "1"), "-c", os.path.join(CSRC, s), "-o", o]))
         objs.append(o)
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
@@ -52,6 +52,9 @@ def main():
               "epilogue"]
     names = ["total", "L:ds_read issue", "L:dma issue", "L:vmcnt+lgkm wait", "L:barrier", "C:mfma+dma", "C:barrier",
              "epilogue"]
+    if os.environ.get("STAMP_MODE") == "2":     # by position in the tile (sums over the tile's half-steps of that class)
+        names = ["total", "L phase, half-step 0", "L phase, half-step 1", "L phase, half-step 2", "L phase, half-steps >= 3",
+                 "C phase, half-step 0", "C phase, half-steps 1-2", "C phase, half-steps >= 3"]
     for name, M, N, K, taps, mode, geo, tile, r1 in shapes:
         A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, taps * K, generator=g, device=dev) / (taps * K) ** 0.5).to(torch.bfloat16)
@@ -85,7 +88,7 @@ def main():
         print(f"{name:28s} half-steps/wg {int(s[0, 8]):5d} tiles/wg {int(s[0, 9]):3d}  cycles/wave {tot:10.0f}")
         for i in range(1, 8):
             v = s[:, i].mean().item()
-            print(f"      {nm[i]:22s} {v:10.0f}  {100 * v / tot:5.1f}%   per half-step {v / s[0, 8].item():7.0f}")
+            print(f"      {nm[i]:26s} {v:10.0f}  {100 * v / tot:5.1f}%   per half-step {v / s[0, 8].item():7.0f}   per tile {v / s[0, 9].item():8.0f}")
 
 
 if __name__ == "__main__":
