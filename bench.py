@@ -217,7 +217,7 @@ def cpu_baseline_child(xdir):
         fwd(cpu_sample_inputs(F, 8, 8))          # thread-pool / allocator warm-up on a tiny latent
         sweep = {}
         if not threads:
-            cal = cpu_sample_inputs(2, max(8, h // 2), max(8, w // 2))
+            cal = cpu_sample_inputs(2, max(8, h // 16 * 8), max(8, w // 16 * 8))     # half the latent, a multiple of 8
             for thr in job["calibrate"]:
                 torch.set_num_threads(thr)
                 t0 = time.perf_counter()
@@ -492,7 +492,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         del st
         torch.cuda.empty_cache()
-        log("timing the CPU oracle baseline (bounded sample, same weights) and checking the HIP output against it ...")
+        log("timing the CPU oracle baseline (same weights; by default the complete no-CFG step, ~2-4 minutes) and checking the HIP output against it ...")
         line["cpu_baseline"], line["parity"] = cpu_baseline(args, unet, ctrl, device)
     print(json.dumps(line))
 

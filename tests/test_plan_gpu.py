@@ -139,7 +139,10 @@ def test_plan_from_a_foreign_host(hip_lib):
     small = torch.empty(1 << 16, dtype=torch.uint8, device=DEV)
     rc = lib.ctrlv_unet_forward(pu, s_d.data_ptr(), 2, t_d.data_ptr(), 1, e_d.data_ptr(), i_d.data_ptr(), 3, None, None,
                                 None, out.data_ptr(), B, F, h, w, small.data_ptr(), small.numel(), st)
-    assert rc == -1 and "workspace too small" in _lib.last_error()
+    assert rc == -5 and "workspace too small" in _lib.last_error()      # CTRLV_E_WORKSPACE, refused before any launch
+    rc = lib.ctrlv_unet_forward(pu, s_d.data_ptr(), 7, t_d.data_ptr(), 1, e_d.data_ptr(), i_d.data_ptr(), 3, None, None,
+                                None, out.data_ptr(), B, F, h, w, ws_u.data_ptr(), ws_u.numel(), st)
+    assert rc == -4 and "dtype" in _lib.last_error()                    # CTRLV_E_BAD_DTYPE
     rc = lib.ctrlv_unet_forward(pc, s_d.data_ptr(), 2, t_d.data_ptr(), 1, e_d.data_ptr(), i_d.data_ptr(), 3, None, None,
                                 None, out.data_ptr(), B, F, h, w, ws_u.data_ptr(), ws_u.numel(), st)
     assert rc == -1 and "ControlNet" in _lib.last_error()
