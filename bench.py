@@ -77,41 +77,11 @@ def log(*a):
 
 # ---------------------------------------------------------------------------------------------------- multi-GPU launch
 def launch_ranks(args):
-    """`--gpus N` without a torchrun environment: start N rank processes (one per GPU) from this process, which has
-    made no HIP call, and relay rank 0's output.  Children are ordinary subprocesses (never an exec of a process that
-    initialised the GPU)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    # rank 0's stdout is drained by a thread; the parent polls so that one dead rank ends the others (which would
-    # otherwise wait at a barrier forever) -- by PID, never by pattern
-    import threading
-    chunks = []
-    th = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    th.start()
-    failed = None
-    while any(p.poll() is None for p in procs):
-        bad = [p for p in procs if p.poll() not in (None, 0)]
-        if bad:
-            failed = bad[0].returncode
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            break
-        time.sleep(0.2)
-    rcs = [p.wait() for p in procs]
-    th.join(timeout=10)
-    sys.stdout.write("".join(c for c in chunks if c))
-    sys.stdout.flush()
-    if failed is not None or any(rcs):
-        log(f"rank exit codes {rcs}")
-        sys.exit(failed or next(rc for rc in rcs if rc))
+    """`--gpus N` without a torchrun environment: N rank processes from this (GPU-free) process
+    (ctrlv_amd.distributed.launch_local_ranks; importing it initialises no device)."""
+    sys.path.insert(0, ROOT)
+    from ctrlv_amd.distributed import launch_local_ranks
+    launch_local_ranks(__file__, sys.argv[1:], args.gpus, log)
 
 
 # ---------------------------------------------------------------------------------------------------- GPU side

@@ -62,6 +62,7 @@ SIGNATURES = {
                                       c_void_p, c_int, c_void_p, c_void_p]),
     "ctrlv_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
+    "ctrlv_softmax_rows": (c_int, [c_void_p, c_int, c_int, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_spatial_prescaled": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -72,6 +73,8 @@ SIGNATURES = {
     "ctrlv_attention_temporal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ctrlv_nchw_to_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ctrlv_rows_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctrlv_time_conv_rows_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_void_p]),
     "ctrlv_im2col3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ctrlv_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "ctrlv_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -99,6 +102,9 @@ SIGNATURES = {
     "ctrlv_unet_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                    ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_size_t, c_void_p]),
+    "ctrlv_unet_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                           ctypes.POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_size_t, c_void_p]),
     "ctrlv_controlnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                          c_float, ctypes.POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                          c_size_t, c_void_p]),
@@ -106,7 +112,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CtrlvHipError(RuntimeError):

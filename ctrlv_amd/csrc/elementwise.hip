@@ -34,6 +34,36 @@ __global__ void rows_to_nchw_kernel(const bf16_t* __restrict__ src, int ldc, int
   for (int c = 0; c < C; ++c) store_any(dst, dtype, (n * C + c) * HW + p, bf16_to_f32(s[c]));
 }
 
+// Conv3d(C, C, (3, 1, 1), padding (1, 0, 0)) over the frames of ONE clip on channels-last rows with C <= 4 channels, written
+// as NCHW: the `time_conv_out` that ends AutoencoderKLTemporalDecoder.decode (3 -> 3 channels).  One thread per
+// (frame, pixel): 3 taps x C inputs, C outputs, fp32 (the reference runs this conv in the VAE's dtype on NCHW tensors).
+__global__ void time_conv_rows_to_nchw_kernel(const bf16_t* __restrict__ src, int ldc, int n_frames, int C, int HW,
+                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                              void* __restrict__ dst, int dtype) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_frames * HW) return;
+  const int f = (int)(idx / HW);
+  const long p = idx % HW;
+  float acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = o < C ? bias[o] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int ff = f + t - 1;
+    if (ff < 0 || ff >= n_frames) continue;
+    const bf16_t* s = src + ((long)ff * HW + p) * ldc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= C) break;
+      const float x = bf16_to_f32(s[c]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < C) acc[o] = __builtin_fmaf(w[(o * C + c) * 3 + t], x, acc[o]);
+    }
+  }
+  for (int o = 0; o < C; ++o) store_any(dst, dtype, ((long)f * C + o) * HW + p, acc[o]);
+}
+
 // tiled transpose for wide tensors (foreign NCHW ControlNet residuals): 64 pixels x 64 channels per block
 __global__ __launch_bounds__(256) void nchw_to_rows_tiled_kernel(const void* __restrict__ src, int dtype, int C,
                                                                  int HW, bf16_t* __restrict__ dst, int ldc,
@@ -181,6 +211,17 @@ extern "C" int ctrlv_rows_to_nchw(const void* src, int ldc, int n_img, int C, in
     hipLaunchKernelGGL(rows_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, ldc, n_img, C, HW, dst, dst_dtype);
   }
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_time_conv_rows_to_nchw(const void* src, int ldc, int n_frames, int C, int HW, const float* weight,
+                                            const float* bias, void* dst, int dst_dtype, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(src && dst && weight && bias && dst_dtype >= 0 && dst_dtype <= 2, "time_conv_rows_to_nchw: bad arguments");
+  CTRLV_CHECK_SHAPE(n_frames > 0 && HW > 0 && C > 0 && C <= 4 && C <= ldc, "time_conv_rows_to_nchw: 1 <= C <= 4 channels");
+  const long total = (long)n_frames * HW;
+  hipLaunchKernelGGL(time_conv_rows_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, ldc, n_frames, C, HW, weight, bias, dst, dst_dtype);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

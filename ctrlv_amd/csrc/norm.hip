@@ -293,7 +293,62 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------ row softmax
+// p[r, :] = softmax(s[r, :]) for fp32 score rows, bf16 probabilities (the single-head, head-dim-512 attention of the VAE's
+// mid block: scores come from a GEMM, P feeds the P.V GEMM).  One workgroup per row, the row held in registers between the
+// max / sum passes (cols <= 256 x 64); base-2 exponentials of (s - max) * log2(e).
+constexpr int kSmxPer = 64;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int cols, long lds, bf16_t* __restrict__ p,
+                                                           long ldp) {
+  __shared__ float red[8];
+  const float* row = s + (long)blockIdx.x * lds;
+  bf16_t* out = p + (long)blockIdx.x * ldp;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float v[kSmxPer];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kSmxPer; k += 4) {
+    const int c = (k / 4 * 256 + tid) * 4;
+    float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (c < cols) q = *(const float4*)(row + c);
+    v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+    mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSmxPer; ++k) {
+    v[k] = __builtin_amdgcn_exp2f((v[k] - mx) * 1.44269504088896340736f);      // exp2(-inf) = 0 for the padding
+    sum += v[k];
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wid] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+  for (int k = 0; k < kSmxPer; k += 4) {
+    const int c = (k / 4 * 256 + tid) * 4;
+    if (c < cols)
+      *(uint2*)(out + c) = make_uint2(pack_bf16x2(v[k] * inv, v[k + 1] * inv), pack_bf16x2(v[k + 2] * inv, v[k + 3] * inv));
+  }
+}
+
 }  // namespace
+
+extern "C" int ctrlv_softmax_rows(const float* scores, int rows, int cols, long ld_scores, void* probs, long ld_probs,
+                                  ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(scores && probs, "softmax_rows: null pointer");
+  CTRLV_CHECK_SHAPE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= kSmxPer * 256 && ld_scores % 4 == 0 && ld_probs % 4 == 0,
+                    "softmax_rows: cols=%d must be a multiple of 4, <= %d", cols, kSmxPer * 256);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, cols, ld_scores,
+                     (bf16_t*)probs, ld_probs);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
 
 extern "C" int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat) {
   GnShape s;

@@ -1140,6 +1140,45 @@ extern "C" int ctrlv_unet_forward(ctrlv_plan* p, const void* sample, int dtype, 
   return rc;
 }
 
+// Down + mid path of the UNet only (the frozen-UNet half of the training step): the skip tensors and the mid output are
+// COPIED out of the arena into the caller's buffers (the caller adds the ControlNet residuals with autograd attached).
+static int unet_encoder(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const float* timestep, int n_t, const void* ehs,
+                        const float* ids, int n_ids, void* const* out_taps, void* out_mid, int h, int w) {
+  const int N = c.B * c.F;
+  TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
+  bf16_t* x;
+  TRY(run_input(c, dtype, sample, nullptr, h, w, &x));
+  std::vector<Tap> taps;
+  int H, W;
+  TRY(run_down_mid(c, x, h, w, taps, &x, &H, &W));
+  if (!c.dry) {
+    for (size_t i = 0; i < taps.size(); ++i) {
+      CTRLV_CHECK_ARG(out_taps[i] != nullptr, "unet_encoder_forward: out_taps[%zu] is null", i);
+      TRY(ctrlv_axpby(taps[i].x, taps[i].x, 1.0f, 0.0f, out_taps[i], (size_t)N * taps[i].H * taps[i].W * taps[i].C, c.st));
+    }
+    TRY(ctrlv_axpby(x, x, 1.0f, 0.0f, out_mid, (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1], c.st));
+  }
+  return CTRLV_OK;
+}
+
+extern "C" int ctrlv_unet_encoder_forward(ctrlv_plan* p, const void* sample, int dtype, const float* timestep, int n_timestep,
+                                          const void* ehs, const float* added_time_ids, int n_ids, void* const* out_taps,
+                                          void* out_mid, int B, int F, int H, int W, void* workspace,
+                                          size_t workspace_bytes, ctrlv_stream_t stream) {
+  TRY(check_common(p, B, F, H, W));
+  CTRLV_CHECK_ARG(p->cfg.kind == 0, "unet_encoder_forward: the plan is a ControlNet");
+  CTRLV_CHECK_ARG(sample && timestep && ehs && added_time_ids && out_taps && out_mid && workspace,
+                  "unet_encoder_forward: null pointer");
+  if (dtype < 0 || dtype > 2) { ctrlv_set_error("unet_encoder_forward: dtype must be 0 (fp32), 1 (fp16) or 2 (bf16)"); return CTRLV_E_BAD_DTYPE; }
+  TRY(check_workspace(p, "unet_encoder_forward", B, F, H, W, workspace_bytes));     // (sized for the whole forward)
+  char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  Ctx c{p, (hipStream_t)stream, false, base, workspace_bytes - (size_t)(base - (char*)workspace)};
+  c.B = B; c.F = F;
+  const int rc = unet_encoder(p, c, sample, dtype, timestep, n_timestep, ehs, added_time_ids, n_ids, out_taps, out_mid, H, W);
+  if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("unet_encoder_forward: workspace too small"); return CTRLV_E_WORKSPACE; }
+  return rc;
+}
+
 extern "C" int ctrlv_controlnet_forward(ctrlv_plan* p, const void* sample, const void* control_cond, int dtype,
                                         const float* timestep, int n_timestep, const void* ehs,
                                         const float* added_time_ids, int n_ids, float conditioning_scale,

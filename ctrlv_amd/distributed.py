@@ -100,3 +100,47 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def launch_local_ranks(script, argv, n, log=None):
+    """Start `n` rank processes of `script` (one per GPU of this node) from a process that has made NO HIP call, relay
+    rank 0's stdout and end the other ranks if one dies (by PID, never by pattern).  The children are ordinary
+    subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would give them -- so `python bench.py --gpus 8` or
+    `python tools/train_bench.py --gpus 8` is one command for a driver.  Exits the calling process with the first
+    non-zero rank exit code."""
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    chunks = []
+    th = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    th.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    if failed is not None or any(rcs):
+        if log is not None:
+            log(f"rank exit codes {rcs}")
+        sys.exit(failed or next(rc for rc in rcs if rc))

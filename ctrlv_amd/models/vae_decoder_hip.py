@@ -65,10 +65,7 @@ def _pack(dec):
     pk["cin"] = (cp, kp, packing.pack_conv_in([dec.conv_in.weight], cp, kp), packing.pad_bias(dec.conv_in.bias))
     pk["mid_res"] = [_pack_res(r) for r in dec.mid_block.resnets]
     a = dec.mid_block.attentions[0]
-    pk["attn"] = dict(g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), eps=a.group_norm.eps, heads=a.heads,
-                      wqkv=packing.pack_linear(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0)),
-                      bqkv=_f32(torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], 0)),
-                      wo=packing.pack_linear(a.to_out[0].weight), bo=_f32(a.to_out[0].bias))
+    pk["attn"] = pack_attn(a)
     pk["up"] = []
     for blk in dec.up_blocks:
         up = None
@@ -138,16 +135,45 @@ def _res(pk, x, n, H, W, sc):
     return out
 
 
+def pack_attn(a):
+    """Mid-block attention of the VAE (one head of dim C = 512).  q and k projections as separate GEMMs (the scores GEMM
+    takes the k rows as its weight operand: contiguous [S, C]); the v projection is produced TRANSPOSED by a GEMM with
+    swapped roles (V^T = W_v . t^T), and its bias joins the output projection's: rows of P sum to one, so
+    P (V + 1 b_v^T) W_o^T = P V W_o^T + W_o b_v."""
+    if a.heads != 1:
+        raise ValueError("the HIP VAE attention is specialised for the SVD VAE's single head")
+    wo = a.to_out[0].weight.detach().float()
+    bo = a.to_out[0].bias.detach().float() + wo @ a.to_v.bias.detach().float()
+    return dict(g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), eps=a.group_norm.eps,
+                wq=packing.pack_linear(a.to_q.weight), bq=_f32(a.to_q.bias),
+                wk=packing.pack_linear(a.to_k.weight), bk=_f32(a.to_k.bias),
+                wv_rows=a.to_v.weight.detach().to(torch.bfloat16).contiguous(),            # [C, C]: the A operand of V^T
+                wo=packing.pack_linear(a.to_out[0].weight), bo=bo.contiguous())
+
+
 def _attn(pk, x, n, H, W, sc):
-    """VAE mid-block attention: GroupNorm -> q, k, v (bias) -> softmax(q k^T / sqrt(d)) v per frame -> to_out -> + x."""
+    """VAE mid-block attention: GroupNorm -> q, k (bias), V^T -> per frame softmax(q k^T / sqrt(C)) v -> to_out -> + x, all on
+    the HIP kernels: the scores are a GEMM with fp32 output (scale folded in), the softmax a row kernel (bf16 P), P.V a
+    GEMM with K = S.  S must be a multiple of 64 (GEMM K granularity)."""
     S, M, C, dev = H * W, n * H * W, x.shape[1], x.device
+    if S % 64 or S > 16384:
+        raise ValueError(f"HIP VAE attention: {H}x{W} latent pixels per frame must be a multiple of 64 and <= 16384")
     t = _rows(M, C, dev)
     ops.groupnorm(x, None, n, S, C, 1, pk["g"], pk["b"], pk["eps"], False, t, sc.get(n, S, C, 1))
-    qkv = _rows(M, 3 * C, dev)
-    ops.gemm(t, pk["wqkv"], qkv, N=3 * C, cin=C, bias=pk["bqkv"])
-    heads = pk["heads"]
-    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(n, S, heads, C // heads).transpose(1, 2) for i in range(3))
-    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(M, C).contiguous()
+    q, k = _rows(M, C, dev), _rows(M, C, dev)
+    ops.gemm(t, pk["wq"], q, N=C, cin=C, bias=pk["bq"])
+    ops.gemm(t, pk["wk"], k, N=C, cin=C, bias=pk["bk"])
+    o = _rows(M, C, dev)
+    scores = torch.empty(S, S, dtype=torch.float32, device=dev)
+    probs = torch.empty(S, S, dtype=torch.bfloat16, device=dev)
+    vt = torch.empty(C, S, dtype=torch.bfloat16, device=dev)
+    for f in range(n):
+        r0, r1 = f * S, (f + 1) * S
+        ops.gemm(q[r0:r1], k[r0:r1], scores, N=S, cin=C, s_acc=C ** -0.5, out_f32=True)      # q k^T / sqrt(C), fp32
+        ops.softmax_rows(scores, probs)
+        ops.gemm(pk["wv_rows"], t[r0:r1], vt, N=S, cin=C)                                     # V^T = W_v t^T  [C, S]
+        ops.gemm(probs, vt, o[r0:r1], N=C, cin=S)                                             # P V
+    del scores, probs, vt, q, k
     out = _rows(M, C, dev)
     ops.gemm(o, pk["wo"], out, N=C, cin=C, bias=pk["bo"], R1=x)
     return out
@@ -166,6 +192,10 @@ def supports(z, num_frames, dec=None):
             return False
         levels = [(blk.resnets[0].spatial_res_block.conv1.weight.shape[0], 2 ** i) for i, blk in enumerate(dec.up_blocks)]
     h, w = z.shape[2], z.shape[3]
+    if (h * w) % 64 or h * w > 16384:          # mid-block attention: scores GEMM with K = h * w, row softmax <= 16384 keys
+        return False
+    if dec is not None and dec.mid_block.attentions[0].heads != 1:
+        return False
     return all(num_frames * h * w * f * f * c * 2 < _LIMIT for c, f in levels)
 
 
@@ -223,13 +253,9 @@ def _decode_clip(dec, z):
     y = _rows(M, co_p, dev)
     ops.gemm(xn, wco, y, N=wco.shape[0], cin=C, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=bco, n_store=co_p)
     del xn
-    frames = torch.empty(n, co, H, W, dtype=torch.float32, device=dev)
-    ops.rows_to_nchw(y, frames)
-    # time_conv_out: Conv3d(co, co, (3, 1, 1), padding (1, 0, 0)) over the clip's frames -- three 3x3 channel mixes
-    wt = dec.time_conv_out.weight.detach().float()[:, :, :, 0, 0]           # [o, c, t]
-    out = dec.time_conv_out.bias.detach().float().view(1, co, 1, 1).expand(n, co, H, W).clone()
-    for t in range(3):
-        lo, hi = max(0, 1 - t), min(n, n + 1 - t)                           # output frames whose tap t is inside the clip
-        if hi > lo:
-            out[lo:hi] += torch.einsum("oc,fchw->fohw", wt[:, :, t], frames[lo + t - 1:hi + t - 1])
+    # time_conv_out: Conv3d(co, co, (3, 1, 1), padding (1, 0, 0)) over the clip's frames, fused with rows -> NCHW
+    wt = dec.time_conv_out.weight.detach().float()[:, :, :, 0, 0].contiguous()          # [o, c, t]
+    out = torch.empty(n, co, H, W, dtype=z.dtype if z.dtype in (torch.float32, torch.float16, torch.bfloat16)
+                      else torch.float32, device=dev)
+    ops.time_conv_rows_to_nchw(y, n, co, H * W, wt, dec.time_conv_out.bias.detach().float().contiguous(), out)
     return out.to(z.dtype)

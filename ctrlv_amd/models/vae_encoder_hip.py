@@ -47,10 +47,8 @@ def _pack(enc):
         pk["down"].append(([_pack_res(r) for r in blk.resnets], ds))
     pk["mid"] = [_pack_res(r) for r in enc.mid_block.resnets]
     a = enc.mid_block.attentions[0]
-    pk["attn"] = dict(g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias), eps=a.group_norm.eps, heads=a.heads,
-                      wqkv=packing.pack_linear(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0)),
-                      bqkv=_f32(torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], 0)),
-                      wo=packing.pack_linear(a.to_out[0].weight), bo=_f32(a.to_out[0].bias))
+    from .vae_decoder_hip import pack_attn
+    pk["attn"] = pack_attn(a)
     pk["gno"] = (_f32(enc.conv_norm_out.weight), _f32(enc.conv_norm_out.bias), enc.conv_norm_out.eps)
     pk["cout"] = (packing.pack_conv3x3(enc.conv_out.weight), packing.pad_bias(enc.conv_out.bias), enc.conv_out.weight.shape[0])
     _CACHE[key] = (ver, weakref.ref(enc), pk)
@@ -87,6 +85,9 @@ def supports(x, enc=None):
         if any(c % 64 for c in chans) or len(enc.down_blocks) != 4:
             return False
         c0 = chans[0]
+    s_lat = (x.shape[2] // 8) * (x.shape[3] // 8)             # mid-block attention (see vae_decoder_hip._attn)
+    if s_lat % 64 or s_lat > 16384 or (enc is not None and enc.mid_block.attentions[0].heads != 1):
+        return False
     return x.shape[0] * x.shape[2] * x.shape[3] * c0 * 2 < (1 << 32) - (1 << 24)
 
 

@@ -297,3 +297,20 @@ def cfg_euler_step(latents, noise_pred, guidance, sigma, sigma_next, scaled_next
                                            F, chw, float(sigma), float(sigma_next), _p(scaled_next), _stream()),
           "ctrlv_cfg_euler_step")
     return latents
+
+
+def time_conv_rows_to_nchw(rows, n_frames, C, HW, weight, bias, out):
+    """Conv3d(C, C, (3,1,1)) over the frames of one clip on channels-last rows, written as NCHW `out` (the VAE decoder's
+    time_conv_out)."""
+    _need_gpu(rows, "rows")
+    check(_lib.load().ctrlv_time_conv_rows_to_nchw(_p(rows), rows.stride(0), n_frames, C, HW, _p(weight), _p(bias), _p(out),
+                                                   _DT[out.dtype], _stream()), "ctrlv_time_conv_rows_to_nchw")
+    return out
+
+
+def softmax_rows(scores, probs):
+    """probs (bf16) = row softmax of fp32 `scores` (both 2-D, unit inner stride)."""
+    _need_gpu(scores, "scores")
+    check(_lib.load().ctrlv_softmax_rows(_p(scores), scores.shape[0], scores.shape[1], scores.stride(0), _p(probs),
+                                         probs.stride(0), _stream()), "ctrlv_softmax_rows")
+    return probs

@@ -137,6 +137,16 @@ class Plan:
             out.data_ptr(), B, F, H, W, ws.data_ptr(), ws.numel(), self._stream()), "ctrlv_unet_forward")
         return out
 
+    def unet_encoder_forward(self, sample, t32, ehs, ids32, out_taps, out_mid, lane=0):
+        """Down + mid path only: writes the skip tensors / mid output into caller-owned row tensors (training step)."""
+        B, F, _, H, W = sample.shape
+        ws = self.workspace(B, F, H, W, lane)
+        outs = (ctypes.c_void_p * len(out_taps))(*[r.data_ptr() for r in out_taps])
+        check(self._lib.ctrlv_unet_encoder_forward(
+            self._h, sample.data_ptr(), _DT[sample.dtype], t32.data_ptr(), t32.numel(), ehs.data_ptr(),
+            ids32.data_ptr(), ids32.shape[1], outs, out_mid.data_ptr(), B, F, H, W, ws.data_ptr(), ws.numel(),
+            self._stream()), "ctrlv_unet_encoder_forward")
+
     def controlnet_forward(self, sample, control, t32, ehs, ids32, scale, out_down, out_mid, lane=0):
         B, F, _, H, W = sample.shape
         ws = self.workspace(B, F, H, W, lane)

@@ -152,10 +152,26 @@ def unet_train_forward(unet, sample, timestep, encoder_hidden_states, added_time
     N, dev = B * F, sample.device
     order = unet.time_context_order
     with torch.no_grad():
-        ws = unet._ensure_ready(sample)
-        ctx = unet._context(ws, sample, timestep, encoder_hidden_states, added_time_ids)
-        x = unet._input_rows(ws, [sample.reshape(N, Cin, h, w)], N, h, w)
-        x, H, W, taps = unet._run_down_mid(ctx, x, h, w)
+        if unet._use_plan():
+            # the library-owned C++ plan walks the frozen encoder (ctrlv_unet_encoder_forward): one host call
+            plan = unet._ensure_plan(sample)
+            t32, ehs_p, ids32 = unet._plan_inputs(sample, timestep, encoder_hidden_states, added_time_ids)
+            shapes = [plan.residual_shape(i, B, F, h, w) for i in range(plan.n_down + 1)]
+            rows = [torch.empty(M, C, dtype=torch.bfloat16, device=dev) for M, C in shapes]
+            plan.unet_encoder_forward(sample.contiguous(), t32, ehs_p, ids32, rows[:-1], rows[-1])
+            hw = [(h, w)]
+            for M, _ in shapes[1:]:
+                hh, ww = hw[-1]
+                while hh * ww * N != M:
+                    hh, ww = (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1
+                hw.append((hh, ww))
+            taps = [(r, a, b) for r, (a, b) in zip(rows[:-1], hw[:-1])]
+            x, (H, W) = rows[-1], hw[-1]
+        else:                        # per-op executor (profiling / tracing modes)
+            ws = unet._ensure_ready(sample)
+            ctx = unet._context(ws, sample, timestep, encoder_hidden_states, added_time_ids)
+            x = unet._input_rows(ws, [sample.reshape(N, Cin, h, w)], N, h, w)
+            x, H, W, taps = unet._run_down_mid(ctx, x, h, w)
         emb_s = clip_embeddings(unet, timestep, added_time_ids, B, dev)
     ehs = encoder_hidden_states.reshape(B, -1).float()
     if len(down_res) != len(taps):

@@ -120,6 +120,12 @@ int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img,
 int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps,
                     const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream);
 
+/* Row softmax of fp32 scores into bf16 probabilities: probs[r, :cols] = softmax(scores[r, :cols]) (cols a multiple of 4,
+ * <= 16384).  The VAE mid block's single-head attention (head dim 512; AutoencoderKLTemporalDecoder, called by
+ * pipeline_video_control.py:235,278,346) runs as scores GEMM -> this -> P.V GEMM. */
+int ctrlv_softmax_rows(const float* scores, int rows, int cols, long ld_scores, void* probs, long ld_probs,
+                       ctrlv_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Self-attention cores (diffusers AttnProcessor2_0 = F.scaled_dot_product_attention, head_dim 64, no mask).
  * qkv: [rows, 3*C] bf16 with q | k | v column blocks (fused to_q/to_k/to_v output), heads = C/64; out: [rows, C].
@@ -157,6 +163,12 @@ int ctrlv_nchw_to_rows(const void* src, int src_dtype, int n_img, int C, int HW,
 /* channels-last bf16 rows [n_img*HW, ldc] (first C columns) -> NCHW of dst_dtype (0 fp32, 1 fp16, 2 bf16). */
 int ctrlv_rows_to_nchw(const void* src, int ldc, int n_img, int C, int HW, void* dst, int dst_dtype,
                        ctrlv_stream_t stream);
+/* The (3, 1, 1) time convolution that ends AutoencoderKLTemporalDecoder.decode (`time_conv_out`, C -> C channels, C <= 4,
+ * zero padding over the frames of ONE clip; pipeline_video_control.py:346 calls decode per chunk) fused with the
+ * rows -> NCHW conversion: src = conv_out rows [n_frames*HW, ldc] bf16, weight fp32 [C][C][3] (out, in, tap), bias
+ * fp32 [C]; dst (n_frames, C, H, W) in dst_dtype. */
+int ctrlv_time_conv_rows_to_nchw(const void* src, int ldc, int n_frames, int C, int HW, const float* weight,
+                                 const float* bias, void* dst, int dst_dtype, ctrlv_stream_t stream);
 /* im2col for the tiny-channel 3x3 input convs (conv_in, control_conv_in): rows [n_img*H*W, Cp] -> [.., 9*Cp (+pad to Kp)] */
 int ctrlv_im2col3x3(const void* x, int n_img, int H, int W, int Cp, void* col, int Kp, ctrlv_stream_t stream);
 /* y = a*x + b*r  (bf16 rows, n elements) -- the ControlNet residual add of
@@ -288,6 +300,14 @@ int ctrlv_unet_forward(ctrlv_plan* plan, const void* sample, int dtype, const fl
                        const void* ehs, const float* added_time_ids, int n_ids, const void* const* down_res,
                        const void* mid_res, void* residual_event, void* out, int B, int F, int H, int W,
                        void* workspace, size_t workspace_bytes, ctrlv_stream_t stream);
+/* The down + mid half of the same forward (unet_spatio_temporal_condition.py:64-117,130-135), for the training step of
+ * tools/train_video_controlnet.py:451-466: the frozen UNet's encoder has no gradient path (the ControlNet residuals are
+ * added to its OUTPUTS, :119-137), so it runs here and hands the n skip tensors and the mid block output back as
+ * channels-last bf16 rows (shapes: ctrlv_plan_residual_shape; out_taps[i] / out_mid are caller-owned). */
+int ctrlv_unet_encoder_forward(ctrlv_plan* plan, const void* sample, int dtype, const float* timestep, int n_timestep,
+                               const void* ehs, const float* added_time_ids, int n_ids, void* const* out_taps,
+                               void* out_mid, int B, int F, int H, int W, void* workspace, size_t workspace_bytes,
+                               ctrlv_stream_t stream);
 /* ControlNetModel.forward (controlnet.py:226-351): control_cond (B, F, in_channels/2, H, W) dtype as sample;
  * writes out_down[i] / out_mid as channels-last bf16 rows (shapes: ctrlv_plan_residual_shape), already multiplied by
  * conditioning_scale (:343-344, folded into the zero-conv epilogue). */

@@ -10,3 +10,5 @@ from .models import (SVD_CONFIG, TINY_CONFIG, ControlNetModel, UNetSpatioTempora
                      seeded_init_, zero_module)
 from .scheduler import (SVD_SCHEDULER_CONFIG, EulerDiscreteScheduler, guidance_scale_tensor,  # noqa: F401
                         sample_loop)
+
+from . import vae  # noqa: F401,E402  (SVD VAE restatement: checker of the HIP VAE paths)

@@ -276,3 +276,45 @@ def test_fullsize_graph_replay_matches_eager(models):
         assert torch.isfinite(st.latents).all()
         res.append(st.latents.clone())
     assert torch.equal(res[0], res[1])
+
+
+def test_cfg5_training_step_at_the_reference_size(models):
+    """BASELINE config 5 at its real size (B = 1, 25 frames, 72 x 128 latent, full SVD widths -- what
+    tools/train_bench.py times): the forward loss is finite and bit-identical run to run (no atomics on the forward path),
+    three AdamW steps on the fp32 ControlNet masters give finite gradients / losses and the loss goes down, and the frozen
+    UNet does not move.  ~100 GB of device memory, ~3 s."""
+    from ctrlv_amd import training
+    from ctrlv_amd.models import ControlNetModel
+    from ctrlv_amd.utils import build_on_device, random_init_
+    unet, _ = models
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    ctrl = random_init_(build_on_device(ControlNetModel, DEV, dtype=torch.float32, num_frames=FR), seed=1, zero_conv_std=0.02)
+    params = [p for p in ctrl.parameters() if p.requires_grad]
+    rn = lambda *s, seed: torch.randn(*s, generator=g(seed), device=DEV)      # noqa: E731
+    batch = dict(latents=rn(1, FR, 4, H, W, seed=401), noise=rn(1, FR, 4, H, W, seed=402),
+                 sigmas=torch.tensor([1.5], device=DEV), image_latents=rn(1, 1, 4, H, W, seed=403).repeat(1, FR, 1, 1, 1),
+                 control_cond=rn(1, FR, 4, H, W, seed=404), encoder_hidden_states=rn(1, 1, 1024, seed=405),
+                 added_time_ids=torch.tensor([[6.0, 127.0, 0.02]], device=DEV))
+    u0 = next(unet.parameters()).detach().clone()
+    # forward determinism: two loss evaluations from the same state (gradients of the first are discarded)
+    l0 = [training.train_step(ctrl, unet, batch, optimizer=None) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0[0]) and torch.equal(l0[0], l0[1]), l0
+    for p in params:
+        p.grad = None
+    opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=1e-2, fused=True)
+    losses = []
+    for i in range(3):
+        loss = training.train_step(ctrl, unet, batch, optimizer=None)
+        if i == 0:      # every trainable parameter the step reaches has a finite gradient
+            n_grad = sum(1 for p in params if p.grad is not None)
+            assert n_grad > 500 and all(bool(torch.isfinite(p.grad).all()) for p in params if p.grad is not None)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss))
+    print("  cfg5 full-size losses:", [round(v, 5) for v in losses])
+    assert all(math.isfinite(v) for v in losses) and losses[2] < losses[1] < losses[0], losses
+    assert torch.equal(u0, next(unet.parameters()).detach())
+    del ctrl, opt, params
+    torch.cuda.empty_cache()

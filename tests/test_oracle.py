@@ -200,3 +200,25 @@ def test_golden_sampling_trajectory():
                   torch.tensor([[6.0, 127.0, 0.02]] * 2), torch.cat([torch.zeros_like(c), c]), 3, record=rec)
     for i, r in enumerate(rec):
         np.testing.assert_allclose(r.numpy(), gold[f"traj_step{i}"], rtol=1e-3, atol=1e-3)
+
+
+def test_vae_oracle_agrees_with_the_product_module():
+    """oracle/ctrlv_ref/vae.py (pure functions over a diffusers-layout state dict) and the product's nn.Module form
+    (ctrlv_amd/models/autoencoder_kl_temporal_decoder.py) are two independent restatements of the SVD VAE: same weights,
+    same inputs => the same encoder moments and decoded frames (fp32, CPU)."""
+    import torch
+    import ctrlv_ref as R
+    from ctrlv_amd.models import AutoencoderKLTemporalDecoder
+    torch.manual_seed(5)
+    m = AutoencoderKLTemporalDecoder().eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("mix_factor"):
+                p.fill_(0.4)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    z = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+    x = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    with torch.no_grad():
+        assert float((m.decoder(z, 3) - R.vae.decode(sd, z, 3)).abs().max()) < 1e-4
+        assert float((m.quant_conv(m.encoder(x)) - R.vae.encode_moments(sd, x)).abs().max()) < 1e-5
+        assert float((m.encode(x).latent_dist.mode() - R.vae.encode_moments(sd, x)[:, :4]).abs().max()) < 1e-5

@@ -1,7 +1,8 @@
-"""VAE temporal decoder on the HIP kernels (ctrlv_amd/models/vae_decoder_hip.py) against the plain-torch
-module it executes (fp32 on the CPU: the same parameters rounded to bf16), production widths (128/256/512/512), 3 frames
-of a 16x24 latent -> 128x192 pixels.  Tolerance: 18 res blocks + attention of bf16-stored activations, parity_err <= 2.5e-2
-(measured value printed).  The torch module is itself an unpinned restatement of diffusers' AutoencoderKLTemporalDecoder."""
+"""VAE temporal decoder / encoder on the HIP kernels (ctrlv_amd/models/vae_decoder_hip.py, vae_encoder_hip.py; SURVEY 8 row
+f4) against the CPU ORACLE of the VAE (oracle/ctrlv_ref/vae.py, fp32, the same parameters rounded to bf16), production
+widths (128/256/512/512), e.g. 3 frames of a 16x24 latent -> 128x192 pixels.  Tolerance: 18 res blocks + attention of
+bf16-stored activations, parity_err <= 2.5e-2 (measured value printed).  The oracle is an unpinned restatement of
+diffusers' AutoencoderKLTemporalDecoder (tests/test_oracle.py checks it against the product's nn.Module form)."""
 import pytest
 import torch
 
@@ -29,8 +30,9 @@ def test_vae_decode_hip_matches_torch_module(vae, n, h, w):
     import copy
     from ctrlv_amd.models import vae_decoder_hip as vh
     z = torch.randn(n, 4, h, w, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).float()
+    import ctrlv_ref as R
     with torch.no_grad():
-        ref = vae.decoder(z, n)                                   # torch modules, fp32, CPU
+        ref = R.vae.decode({k: v.detach() for k, v in vae.state_dict().items()}, z, n)        # the oracle, fp32, CPU
     dev_vae = copy.deepcopy(vae).to(DEV, torch.bfloat16)
     zd = z.to(DEV, torch.bfloat16)
     assert vh.supports(zd, n)
@@ -76,9 +78,11 @@ def test_vae_encode_hip_matches_torch_module(vae, n, H, W):
     import copy
     from ctrlv_amd.models import vae_encoder_hip as ve
     x = (torch.rand(n, 3, H, W, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(torch.bfloat16).float()
+    import ctrlv_ref as R
+    sd = {k: v.detach() for k, v in vae.state_dict().items()}
     with torch.no_grad():
-        ref_m = vae.encoder(x)
-        ref_lat = vae.encode(x).latent_dist.mode()
+        ref_m = R.vae.encode_moments(sd, x, quant=False)          # the oracle, fp32, CPU
+        ref_lat = R.vae.encode_moments(sd, x)[:, :4]              # latent_dist.mode() = the mean half
     dev_vae = copy.deepcopy(vae).to(DEV, torch.bfloat16)
     xd = x.to(DEV, torch.bfloat16)
     with torch.no_grad():

@@ -5,8 +5,9 @@ ms per optimisation step, its split (forward / backward / optimizer, HIP events)
 work of SURVEY.md 8 a11 (219 TFLOP: ControlNet fwd 29.3 + UNet fwd 80.0 + ControlNet bwd 58.6 + UNet decoder dgrad 51).
 Synthetic data, random-init weights (there are no checkpoints in this image).
 usage: python tools/train_bench.py [--steps 3] [--warmup 1] [--frames 25] [--height 576] [--width 1024]
-Data parallel (one process per GPU, RCCL): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
-127.0.0.1 --master-port P tools/train_bench.py ...  -- every rank trains on its own clip, the fp32 gradients are
+Data parallel (one process per GPU, RCCL): `python tools/train_bench.py --gpus N` starts the N ranks itself from a GPU-free
+parent; or python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+tools/train_bench.py --gpus N ...  -- every rank trains on its own clip, the fp32 gradients are
 all-reduced in 25 MB buckets launched from autograd hooks while the backward runs (ctrlv_amd.training.GradientBuckets);
 the time is the MAX over ranks, `samples_per_s` the whole-job rate."""
 import argparse
@@ -29,8 +30,16 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--fused-adamw", type=int, default=1, help="torch.optim.AdamW(fused=...)")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="N > 1 without a torchrun environment: start N rank processes (one per GPU) from this GPU-free parent")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from ctrlv_amd.distributed import launch_local_ranks
+        launch_local_ranks(__file__, sys.argv[1:], args.gpus)
+        return
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    if args.gpus and args.gpus != world:
+        raise SystemExit(f"train_bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
