@@ -205,13 +205,38 @@ class GroupNormSiLU(torch.autograd.Function):
         return dx, dg.to(pdt), db.to(pdt), None, None, None, None, None
 
 
+_MIX_CACHE = {}      # id(mix_factor parameter) -> (version, sigmoid value); filled by prefetch_mix_factors()
+
+
+def prefetch_mix_factors(*models):
+    """ONE device-to-host copy for all AlphaBlender mix factors of the given models (about 60 scalars).  BlendGemm /
+    BlendLinear fold sigmoid(mix_factor) into GEMM epilogue scalars, i.e. need it on the host: read one by one, that was a
+    blocking sync per res block / transformer (it drained the queue ~60 times per step and serialised the backward /
+    all-reduce overlap).  training.train_step calls this once per step."""
+    ps = [p for m in models for n, p in m.named_parameters() if n.endswith("mix_factor")]
+    if not ps:
+        return
+    vals = torch.sigmoid(torch.stack([p.detach().float().reshape(()) for p in ps])).cpu().tolist()
+    _MIX_CACHE.clear()
+    for p, v in zip(ps, vals):
+        _MIX_CACHE[id(p)] = (p._version, p.data_ptr(), float(v))
+
+
+def _mix_alpha(mix_factor):
+    """sigmoid(mix_factor) as a python float: from the per-step cache if it is current, else one (blocking) read."""
+    hit = _MIX_CACHE.get(id(mix_factor))
+    if hit is not None and hit[0] == mix_factor._version and hit[1] == mix_factor.data_ptr():
+        return hit[2]
+    return 1.0 / (1.0 + math.exp(-float(mix_factor.detach().float().cpu())))
+
+
 class BlendGemm(torch.autograd.Function):
     """AlphaBlender folded into the last temporal conv: out = xs + (1 - a) * (conv(hn) + bias), a = sigmoid(mix_factor)
     (a * xs + (1 - a) * (xs + conv) of SURVEY A.3).  Gradients for hn, the conv parameters, xs AND mix_factor."""
 
     @staticmethod
     def forward(ctx, hn, weight, bias, xs, mix_factor, geom):
-        a = 1.0 / (1.0 + math.exp(-float(mix_factor.detach().float().cpu())))
+        a = _mix_alpha(mix_factor)
         out = GatherGemm.apply(hn, weight, bias, xs, None, 1.0 - a, geom)        # (no graph: forward runs under no_grad)
         ctx.save_for_backward(hn, weight, xs, out, mix_factor)
         ctx.geom, ctx.a = geom, a
@@ -391,7 +416,7 @@ class BlendLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, weight, bias, g1, h2, mix_factor):
-        a = 1.0 / (1.0 + math.exp(-float(mix_factor.detach().float().cpu())))
+        a = _mix_alpha(mix_factor)
         N, cin = weight.shape
         out = _rows(u.shape[0], N, u)
         ops.gemm(u, _pack_fwd(weight, 0), out, N=N, cin=cin, bias=packing.pad_bias(bias), s_acc=1.0 - a,

@@ -245,6 +245,8 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     const bool wide_ok = d.n_store % 8 == 0 && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) &&
                          (!d.R2 || d.ldr2 % 8 == 0) && (!d.vmode || d.ldv % 8 == 0);
     if (!wide_ok || !ctrlv_gemm_pp_supports(d)) {
+      // (the 2-stage kernels do not write raw_out: falling back would leave the caller's tensor uninitialised)
+      CTRLV_CHECK_SHAPE(!d.raw_out, "ctrlv_gemm: raw_out needs n_store / ldo to be multiples of 8 (ping-pong tiles only)");
       CTRLV_CHECK_SHAPE(d.tile == 0, "ctrlv_gemm: tiles 5-8 need n_store / ldo / ldr / ldv to be multiples of 8 and an "
                                      "epilogue of {bias, V, R1, R1+V, R1+R2} without SiLU / fp32 output");
       tile = 1;

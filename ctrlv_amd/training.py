@@ -214,7 +214,9 @@ def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, 
     with accumulate=True and loss_scale=1/steps for every micro-batch but the last -- gradients add up locally, nothing is
     all-reduced and the optimizer does not step; the last micro-batch (accumulate=False) reduces the sums and steps.  batch: dict(latents (B,F,4,h,w) clean, noise, sigmas [B], image_latents (B,F,4,h,w)
     (conditioning frame repeated), control_cond (B,F,4,h,w), encoder_hidden_states (B,1,D), added_time_ids (B,3)).
-    Returns the loss (python float is NOT taken: no host sync inside)."""
+    Returns the loss as a device tensor; the one host read of the step is the batched mix-factor fetch at its start."""
+    from .autograd import prefetch_mix_factors
+    prefetch_mix_factors(controlnet, unet)          # the step's only device-to-host read (about 60 scalars, one copy)
     lat, noise, sig = batch["latents"].float(), batch["noise"].float(), batch["sigmas"].float()
     B = lat.shape[0]
     s5 = sig.reshape(B, 1, 1, 1, 1)
@@ -236,6 +238,11 @@ def train_step(controlnet, unet, batch, optimizer=None, conditioning_scale=1.0, 
         buckets.finish()
     elif world_size > 1:
         allreduce_gradients([p for p in controlnet.parameters() if p.requires_grad])
+    # parameters without a gradient path get ZERO gradients (what the reference's autograd gives them: weight decay then
+    # applies), whatever the world size -- the data-parallel paths write zeros for them, so does the single-GPU one
+    for p in controlnet.parameters():
+        if p.requires_grad and p.grad is None:
+            p.grad = torch.zeros_like(p)
     if optimizer is not None:
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
@@ -270,13 +277,18 @@ class GradientBuckets:
         self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self.enabled = True               # False = accumulate locally (accelerate's no_sync micro-batches): no collective
         self.launch_order = []
+        self.unused = set()               # ids of parameters without a gradient path, learnt in the first step
         self._arm()
         self.handles = [p.register_post_accumulate_grad_hook(self._hook) for b in self.buckets for p in b] if self.active else []
 
     def _arm(self):
-        self.pending = [len(b) for b in self.buckets]
+        # parameters that received no gradient in the previous step (the one-key cross-attentions' to_q / to_k / norm2:
+        # softmax over one key is constant) never fire their hook: they are not waited for, so their buckets are
+        # all-reduced DURING the backward pass like every other one (their slots carry zeros)
+        self.pending = [len(b) - sum(1 for p in b if id(p) in self.unused) for b in self.buckets]
         self.inflight = [None] * len(self.buckets)
         self.launch_order = []
+        self.fired = set()
 
     def _launch(self, i):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).float().reshape(-1) for p in self.buckets[i]])
@@ -287,8 +299,12 @@ class GradientBuckets:
         if not self.enabled:
             return
         i = self.bucket_of[id(p)]
+        self.fired.add(id(p))
+        if id(p) in self.unused:          # (it has a gradient after all: count it again from the next step on)
+            self.unused.discard(id(p))
+            return
         self.pending[i] -= 1
-        if self.pending[i] == 0:
+        if self.pending[i] == 0 and self.inflight[i] is None:
             self._launch(i)
 
     def finish(self):
@@ -311,6 +327,7 @@ class GradientBuckets:
                     p.grad.copy_(g)
                 off += n
         n = len(self.buckets)
+        self.unused = {id(p) for b in self.buckets for p in b if id(p) not in self.fired}
         self._arm()
         return n
 
