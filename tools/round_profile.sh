@@ -20,3 +20,10 @@ cd $R
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_hbm_traffic_summary.json > $OUT/pmc_summary.txt 2>&1
 tail -12 $OUT/pmc_summary.txt
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/prof/p_kernel_trace.csv
+# 4. the other configurations of the same build (no CPU leg): SVD UNet only (cfg2), the reference's default 320x512 size,
+#    the cfg5 training step, the end-to-end clip latency through the pipeline
+python3 bench.py --steps 8 --warmup 2 --workload svd_unet --no-cpu-baseline > $OUT/bench_svd_unet.json 2>> $OUT/bench.err
+python3 bench.py --steps 12 --warmup 3 --height 320 --width 512 --no-cpu-baseline > $OUT/bench_320x512.json 2>> $OUT/bench.err
+python3 tools/train_bench.py --steps 3 --warmup 1 > $OUT/train_step.json 2>> $OUT/bench.err
+python3 tools/pipeline_bench.py > $OUT/pipeline_clip_latency.json 2>> $OUT/bench.err
+tail -1 $OUT/bench_svd_unet.json | cut -c1-160; tail -1 $OUT/bench_320x512.json | cut -c1-160; tail -1 $OUT/train_step.json | cut -c1-200; tail -2 $OUT/pipeline_clip_latency.json | cut -c1-300
