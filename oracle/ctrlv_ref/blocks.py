@@ -40,7 +40,7 @@ _TRUNK_DTYPE = ["same"]
 def store(x, trunk=False):
     """Storage point of the HIP path.  trunk=True marks the RESIDUAL STREAM (block inputs / outputs, the tensors every
     branch is added back into); `storage_rounding(dtype, trunk_dtype=...)` can give it its own storage precision
-    (tools/trunk_precision_study.py: what an fp32 residual trunk under bf16 branches would buy)."""
+    (tests/trunk_precision_study.py: what an fp32 residual trunk under bf16 branches would buy)."""
     dt = _TRUNK_DTYPE[0] if (trunk and _TRUNK_DTYPE[0] != "same") else _STORE_DTYPE[0]
     return x if dt is None else x.to(dt).to(x.dtype)
 

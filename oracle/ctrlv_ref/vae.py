@@ -2,7 +2,7 @@
 vae.py `Encoder`, unet_3d_blocks.py `MidBlockTemporalDecoder` / `UpBlockTemporalDecoder`, resnet.py
 `SpatioTemporalResBlock` / `TemporalResnetBlock`, attention_processor.py `Attention` with `AttnProcessor2_0`).
 
-TEST INFRASTRUCTURE ONLY (see oracle/README): the checker of ctrlv_amd's HIP VAE paths (tests/test_vae_gpu.py).
+TEST INFRASTRUCTURE ONLY (oracle/ctrlv_ref/__init__.py): the checker of ctrlv_amd's HIP VAE paths (tests/test_vae_gpu.py).
 PARITY UNPINNED: diffusers is absent from the image and the reference repository holds no VAE vectors; this is a
 restatement of the published architecture, written independently of ctrlv_amd/models/autoencoder_kl_temporal_decoder.py
 (that one is an nn.Module tree for checkpoint loading; this one is a set of pure functions over a diffusers-layout state

@@ -1,14 +1,15 @@
 #!/usr/bin/env python
 """What would an fp32 (or two-term bf16) RESIDUAL TRUNK under bf16 branch activations buy?  
 
-CPU only, oracle only (test infrastructure): the oracle's `store()` marks sit exactly where the HIP path writes an activation
+CPU only, oracle only (test infrastructure; it lives under tests/ because only tests/, smoke() and the
+benchmark's checker leg may import the oracle): the oracle's `store()` marks sit exactly where the HIP path writes an activation
 to HBM; the marks of the residual stream (block inputs / outputs, every tensor a branch result is added back into) are
 tagged `trunk=True`.  This script runs the ControlNet -> UNet pair of the oracle three times on the same weights / inputs --
   fp32                    no storage rounding (the reference),
   bf16 everywhere         every store rounded to bf16 (what the HIP path does; this realisation's error ~ the HIP error),
   fp32 trunk              trunk stores kept in fp32, every branch store (norm outputs, conv1 / q / k / v / attention / GEGLU
                           intermediates, ControlNet residual outputs across the API) rounded to bf16,
-and prints the model-level relative L2 errors.  usage: python tools/trunk_precision_study.py [--full]
+and prints the model-level relative L2 errors.  usage: python tests/trunk_precision_study.py [--full]
 (--full: SVD widths at 2 frames x 32 x 32, ~1 minute; default: tiny config)"""
 import argparse
 import os
