@@ -34,9 +34,6 @@
 #else
 #define PP_SETPRIO(x)
 #endif
-#ifndef CTRLV_PP_SCHED
-#define CTRLV_PP_SCHED 0      // 0: ping-pong wave groups, 1: streamed (both documented at the kernel)
-#endif
 
 namespace {
 
@@ -580,80 +577,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
   STAMP(t_begin);
 #endif
-#if CTRLV_PP_SCHED == 1
-  // ================= STREAMED schedule: no wave groups, one barrier per half-step, fragments double-buffered at
-  // k16 granularity (the same 2 x (TM + TN) fragment registers as the ping-pong loop, used as two k16 buffers).
-  //   first half  of half-step g: MFMAs on F0 = frag(g, k16 0) while F1 = frag(g, k16 1) streams in from slot g;
-  //   middle                    : retire own DMA(g+1), s_barrier  -> slot g+1 complete, slot g-1 no longer read;
-  //   second half               : MFMAs on F1 while F0 = frag(g+1, k16 0) streams in from slot g+1.
-  // The DMA pieces of half-step g+3 (into slot (g-1)&3, whose last reads every wave retired before the barrier of
-  // half-step g-1) sit in the gaps of the MFMA groups.  Both waves of a SIMD run this same loop, so the matrix pipe is
-  // fed by whichever has operands ready; nobody alternates phases.
-  auto read_frags = [&](const char* st, int ks, bf16x8 (&af)[TM], bf16x8 (&wf)[TN]) {
-    const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
-#pragma unroll
-    for (int n = 0; n < TN; ++n) wf[n] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
-  };
-  bf16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
-  read_frags(smem, 0, af0, wf0);
-  constexpr int N1 = (NPIECE + 1) / 2;                       // pieces issued in the first half
-  auto half_step = [&](int j, bool last_of_tile, auto first_tag) {
-    constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
-    const char* st = smem + (g & (NH - 1)) * SLOT;
-    read_frags(st, 1, af1, wf1);
-    issue_begin(g + 3);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i0 = h * HM;
-      PP_SETPRIO(1);
-      if (MAY_BE_FIRST && j == 0) {
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          const f32x16 bc = bias_c(n);
-#pragma unroll
-          for (int i = i0; i < i0 + HM; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], bc, 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[n], af0[i], acc[i][n], 0, 0, 0);
-      }
-      PP_SETPRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < N1; ++k)
-        if (k * 2 / N1 == h) issue_piece(k);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // middle: own DMA(g+1) retired (DMA(g+2) and the N1 pieces just issued may stay in flight), F1 landed
-    wait_vmcnt<NPIECE + N1>();
-    lds_done_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last_of_tile) read_frags(smem + ((g + 1) & (NH - 1)) * SLOT, 0, af0, wf0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i0 = h * HM;
-      PP_SETPRIO(1);
-#pragma unroll
-      for (int i = i0; i < i0 + HM; ++i)
-#pragma unroll
-        for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[n], af1[i], acc[i][n], 0, 0, 0);
-      PP_SETPRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NPIECE - N1; ++k)
-        if (k * 2 / (NPIECE - N1) == h) issue_piece(N1 + k);
-      if (h == 1) issue_end();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-#else
   // ================= PING-PONG schedule (see the header of this file)
   if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
   auto half_step = [&](int j, bool /*last_of_tile*/, auto first_tag) {
@@ -742,7 +665,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     STAMP_ADD(c_cbar, t4, t5);
 #endif
   };
-#endif
 
   for (int tr = 0; tr < my_ntiles; ++tr) {
     const int tile = my_first + tr * G;
@@ -758,14 +680,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
     next_tile(is_tile);
 #pragma clang loop unroll(disable)
     for (int j = J - 3; j < J; ++j, ++g) half_step(j, j == J - 1, std::false_type{});
-#if CTRLV_PP_SCHED != 1
     // Tile boundary.  Group 0 takes one EXTRA barrier before its epilogue (it pairs with group 1's last post-C
     // barrier) and group 1 one after its epilogue (pairing with group 0's first post-L barrier of the next tile), so
     // that the two epilogues run CONCURRENTLY instead of each group stalling at a barrier for the whole epilogue of
     // the other (stamps: "C:barrier" was 1.3-2.5x the epilogue itself on the K = 320 layers).  The extra barrier also
     // orders group 0's staging writes after group 1's last load phase, which still reads those ring pieces.
     if (grp == 0) raw_barrier();
-#endif
     STAMP(t6);
     {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (every wave retired its reads
@@ -799,14 +719,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 #if !(defined(CTRLV_PP_STAMP) && CTRLV_PP_STAMP == 2)
     STAMP_ADD(c_epi, t6, t7);
 #endif
-#if CTRLV_PP_SCHED == 1
-    if (tr + 1 < my_ntiles) {     // first fragments of the next tile (its slot was completed by the last barrier)
-      read_frags(smem + (g & (NH - 1)) * SLOT, 0, af0, wf0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-#else
     if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
-#endif
   }
   // the issue stream ran three half-steps past the end (zero-filled pieces): nothing may be in flight when the
   // workgroup's LDS is released

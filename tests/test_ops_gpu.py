@@ -447,3 +447,32 @@ def test_cfg_euler_step(ops, cfg):
     ops.cfg_euler_step(lat_d, pred.to(DEV), guid.to(DEV), float(sched.sigmas[3]), float(sched.sigmas[4]), scaled)
     assert parity_err(lat_d, ref) < 1e-5
     assert parity_err(scaled, ref / (float(sched.sigmas[4]) ** 2 + 1) ** 0.5) < 3e-3
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 64), (3, 9216), (2, 1000), (1, 16384)])
+def test_softmax_rows(ops, rows, cols):
+    """Row softmax of fp32 scores into bf16 probabilities (the VAE's head-dim-512 attention): large logits, a ragged
+    column count, the maximum row length."""
+    s = torch.randn(rows, cols, generator=g(1)) * 6.0
+    s[0, cols // 2] = 40.0
+    p = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_rows(s.to(DEV), p)
+    ref = torch.softmax(s.double(), dim=-1).float()
+    assert torch.isfinite(p.float()).all()
+    assert float((p.float().cpu().sum(-1) - 1).abs().max()) < 1e-2
+    assert parity_err(p, ref) < 3e-3
+
+
+def test_time_conv_rows_to_nchw(ops):
+    """time_conv_out of the VAE decoder: Conv3d(3, 3, (3, 1, 1), padding (1, 0, 0)) over the frames of one clip, from
+    channels-last rows (padded to 4 columns) straight to NCHW."""
+    n, co, H, W = 5, 3, 6, 10
+    y = bf(torch.randn(n * H * W, 4, generator=g(2)))
+    wt = torch.randn(co, co, 3, generator=g(3))
+    b = torch.randn(co, generator=g(4))
+    x5 = y.float()[:, :co].reshape(1, n, H, W, co).permute(0, 4, 1, 2, 3)            # (1, C, F, H, W)
+    ref = F.conv3d(x5, wt[:, :, :, None, None], b, padding=(1, 0, 0))[0].permute(1, 0, 2, 3)
+    for dt in (torch.float32, torch.bfloat16):
+        out = torch.empty(n, co, H, W, dtype=dt, device=DEV)
+        ops.time_conv_rows_to_nchw(y.to(DEV), n, co, H * W, wt.to(DEV), b.to(DEV), out)
+        assert parity_err(out, ref) < (1e-5 if dt == torch.float32 else 3e-3)

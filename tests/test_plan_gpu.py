@@ -151,3 +151,32 @@ def test_plan_from_a_foreign_host(hip_lib):
     assert rc == -2 and "divisible by 8" in _lib.last_error()
     torch.cuda.synchronize()
     assert lib.ctrlv_plan_destroy(pc) == 0 and lib.ctrlv_plan_destroy(pu) == 0
+
+
+@torch.no_grad()
+def test_unet_encoder_forward_matches_the_python_executor(hip_lib):
+    """ctrlv_unet_encoder_forward (the frozen UNet's down + mid path of the training step) hands back exactly the skip
+    tensors / mid output the per-op Python executor computes (bit for bit), in the shapes of ctrlv_plan_residual_shape."""
+    import ctrlv_ref as R
+    from tests.parity_utils import make_inputs, make_pair
+    cfg = dict(R.TINY_CONFIG)
+    _, _, hu, _ = make_pair(cfg, DEV)
+    B, F, h, w = 2, 3, 16, 24
+    sample, t, ehs, ids, _ = make_inputs(cfg, B, F, h, w)
+    sample = sample.to(DEV, torch.bfloat16)
+    ehs, ids, t = ehs.to(DEV, torch.bfloat16), ids.to(DEV), t.to(DEV)
+    N = B * F
+    ws = hu._ensure_ready(sample)
+    ctx = hu._context(ws, sample, t, ehs, ids)
+    x = hu._input_rows(ws, [sample.reshape(N, -1, h, w)], N, h, w)
+    x, H, W, taps = hu._run_down_mid(ctx, x, h, w)
+    want = [tp[0].clone() for tp in taps] + [x.clone()]
+    plan = hu._ensure_plan(sample)
+    t32, ehs_p, ids32 = hu._plan_inputs(sample, t, ehs, ids)
+    shapes = [plan.residual_shape(i, B, F, h, w) for i in range(plan.n_down + 1)]
+    rows = [torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV) for M, C in shapes]
+    plan.unet_encoder_forward(sample.contiguous(), t32, ehs_p, ids32, rows[:-1], rows[-1])
+    torch.cuda.synchronize()
+    assert len(rows) == len(want)
+    for got, ref in zip(rows, want):
+        assert got.shape == ref.shape and torch.equal(got, ref)
