@@ -148,6 +148,23 @@ __device__ __forceinline__ float geglu_tab(float a, float g, const char* tab) {
 #pragma clang fp contract(off)
   return a * (g * gelu_phi_tab(g, tab));
 }
+// The same operations in two halves, for epilogues that keep a batch of table reads in flight: geglu_tab(a, g, tab) ==
+// geglu_tab_finish(a, g, fr, e) after gelu_tab_lookup(g, tab, fr, e), bit for bit.
+__device__ __forceinline__ void gelu_tab_lookup(float x, const char* tab, float& fr, float2& e) {
+#pragma clang fp contract(off)
+  float t = __builtin_fmaf(x, 100.0f, 512.0f);
+  t = __builtin_amdgcn_fmed3f(t, 0.0f, 1023.99994f);
+  fr = __builtin_amdgcn_fractf(t);
+  e = *(const float2*)(tab + (int)t * 8);
+}
+__device__ __forceinline__ float geglu_tab_finish(float a, float g, float fr, float2 e) {
+#pragma clang fp contract(off)
+  // the interpolation as an ordered instruction: left to the compiler it is hoisted to right behind the table read (the
+  // wait then sits there too) and paired into v_pk_fma_f32, which takes three v_mov per pair to line the operands up
+  float phi;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(phi) : "v"(fr), "v"(e.y), "v"(e.x));
+  return a * (g * phi);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -93,6 +93,21 @@ __device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wb
   return __builtin_amdgcn_raw_buffer_load_b128(rsB, lane < WTN / 4 ? (unsigned)((wbase_n + lane * 4) * 4) : 0xFFFFFFFFu,
                                                0, 0);
 }
+// A/B handles of the epilogue's output stores (tools/ab_build.py): CTRLV_PP_STORE_AUX = cache-policy bits of the
+// buffer store (0 default, 2 = nt); CTRLV_PP_NOSTORE = compute the packed output and drop it (timing diagnosis only).
+#ifndef CTRLV_PP_STORE_AUX
+#define CTRLV_PP_STORE_AUX 0
+#endif
+__device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+#ifdef CTRLV_PP_NOSTORE
+  asm volatile("" ::"v"(pv), "v"(voff), "s"(soff));
+#elif defined(CTRLV_PP_STORE_L2)   // TIMING EXPERIMENT ONLY: every store lands in a window of CTRLV_PP_STORE_L2 bytes (power of two) of the output
+  __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff == 0xFFFFFFFFu ? voff : ((voff + (unsigned)soff) & (unsigned)(CTRLV_PP_STORE_L2 - 16)), 0, 0);
+#else
+  __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff, soff, CTRLV_PP_STORE_AUX);
+#endif
+}
+
 template <int WTN>
 __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, int lane) {
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
@@ -247,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         }
         const uint4 pk = pack_bf16x8(o);
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
-        __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2, 0);
+        pp_store_out(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
       }
       // keep the machine scheduler from hoisting the later sub-tiles' loads up here: the prefetch window is sized to
       // the registers that are free at each point, hoisting turns it into hundreds of spills
@@ -295,50 +310,74 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     // quads 2,3 their gates, in the same lane: out = (a + ba) * gelu(g + bg) is computed in the MFMA layout (its bias
     // is a per-column broadcast from the LDS strip) and two adjacent sub-tiles (16 outputs each) share one staged
     // 32-column image; a lone last sub-tile fills only the left half.
-    constexpr int NP = (TN + 1) / 2;
+    // The table reads of block b + 1 (16 gates: one staged image) are issued before block b's image goes through the
+    // staging round trip, so neither latency is paid per group of four gates (the staging writes and the table reads are
+    // both LDS accesses: the compiler keeps them in source order, so the order below is the order that runs).
+    constexpr int NP = (TN + 1) / 2, NB = TM * NP;
+    float fr[16];
+    float2 tb[16];
+    auto lookup = [&](int b) {
+      const int i = b / NP, j = (b % NP) * 2;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int half = 0; half < 2; ++half) {
+        const int js = j + half;
+        if (js >= TN) continue;                            // compile time
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) {
-        const int j = jp * 2;
+        for (int qd = 0; qd < 2; ++qd)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int js = j + half;
-          if (js >= TN) continue;                          // compile time
+          for (int e = 0; e < 4; ++e)
+            gelu_tab_lookup(acc[i][js][4 * (qd + 2) + e], gelu_tab, fr[half * 8 + qd * 4 + e], tb[half * 8 + qd * 4 + e]);
+      }
+    };
+    lookup(0);
 #pragma unroll
-          for (int qd = 0; qd < 2; ++qd) {
-            const f32x4_t g = {acc[i][js][4 * (qd + 2)], acc[i][js][4 * (qd + 2) + 1], acc[i][js][4 * (qd + 2) + 2],
-                               acc[i][js][4 * (qd + 2) + 3]};
-            const f32x4_t a = {acc[i][js][4 * qd], acc[i][js][4 * qd + 1], acc[i][js][4 * qd + 2], acc[i][js][4 * qd + 3]};
-            f32x4_t o;      // a * gelu(g), Phi from the LDS table (common.h: 8 VALU per gate instead of 20)
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / NP, jp = b % NP, j = jp * 2;
+      float o[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = geglu_tab(a[e], g[e], gelu_tab);
-            const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7);
-            *(float4*)(wrow + c * 16) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int half = 0; half < 2; ++half) {
+        const int js = j + half;
+        if (js >= TN) continue;                            // compile time
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = half * 8 + qd * 4 + e;           // a * gelu(g), Phi from the LDS table (common.h)
+            o[k] = geglu_tab_finish(acc[i][js][4 * qd + e], acc[i][js][4 * (qd + 2) + e], fr[k], tb[k]);
           }
-        }
-        const int ocol = ((wbase_n + j * 32) >> 1) + l4 * 8;
-        // columns of the right half exist only if sub-tile j+1 does (inside the wave tile and inside N)
-        const bool col_ok = ocol < d.n_store && (l4 < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N));
-        __builtin_amdgcn_wave_barrier();   // compiler-only: the image is exchanged between lanes of this wave
-        float4 img[2][2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (b + 1 < NB) lookup(b + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const char* rp = pass ? rp_b : rp_a;
-          img[pass][0] = *(const float4*)(rp + rx0);
-          img[pass][1] = *(const float4*)(rp + rx1);
-        }
-        __builtin_amdgcn_wave_barrier();
+      for (int half = 0; half < 2; ++half) {
+        if (j + half >= TN) continue;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const float4 v0 = img[pass][0], v1 = img[pass][1];
-          const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const int m = m0 + i * 32 + pass * 16;
-          const uint4 pk = pack_bf16x8(o);
-          const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
-          __builtin_amdgcn_raw_buffer_store_b128(
-              pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+        for (int qd = 0; qd < 2; ++qd) {
+          const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7), k = half * 8 + qd * 4;
+          *(float4*)(wrow + c * 16) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
         }
+      }
+      const int ocol = ((wbase_n + j * 32) >> 1) + l4 * 8;
+      // columns of the right half exist only if sub-tile j+1 does (inside the wave tile and inside N)
+      const bool col_ok = ocol < d.n_store && (l4 < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N));
+      __builtin_amdgcn_wave_barrier();   // compiler-only: the image is exchanged between lanes of this wave
+      float4 img[2][2];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const char* rp = pass ? rp_b : rp_a;
+        img[pass][0] = *(const float4*)(rp + rx0);
+        img[pass][1] = *(const float4*)(rp + rx1);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const float4 v0 = img[pass][0], v1 = img[pass][1];
+        const float ov[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const int m = m0 + i * 32 + pass * 16;
+        const uint4 pk = pack_bf16x8(ov);
+        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+        pp_store_out(pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0);
       }
     }
   }
@@ -750,7 +789,12 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[dev] = true;
   }
-  const int num_cu = ctrlv_num_cu(dev);
+  int num_cu = ctrlv_num_cu(dev);
+  {
+    static int cap = -1;                 // A/B handle: CTRLV_PP_MAX_WG = persistent workgroups per launch (default: one per CU)
+    if (cap < 0) { const char* e = getenv("CTRLV_PP_MAX_WG"); cap = e ? atoi(e) : 0; }
+    if (cap > 0 && cap < num_cu) num_cu = cap;
+  }
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
   const int grid = (persistent && tiles > num_cu) ? num_cu : tiles;   // persistent: one 512-thread workgroup per CU
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);

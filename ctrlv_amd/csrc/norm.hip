@@ -16,6 +16,7 @@ namespace {
 
 struct GnShape {
   int n_img, S, C, imgs_per_stat, c_split, n_chunks, rows_per_chunk, CV, RPP;
+  int rev_stats, rev_apply;       // walk the images / chunks from the END (which workgroup reads what first; results unchanged)
 };
 
 __device__ __forceinline__ uint4 gn_load(const bf16_t* x, const bf16_t* x2, int c_split, int C, long row, int c0) {
@@ -34,7 +35,8 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   extern __shared__ float red[];  // [RPP][C][2] sums, then [C] pilots
   const int tid = threadIdx.x;
   const int col = tid % s.CV, rsub = tid / s.CV;
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int n = s.rev_stats ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int chunk = s.rev_stats ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
@@ -152,7 +154,8 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int silu, bf16_t* __restrict__ y) {
   const int tid = threadIdx.x;
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int n = s.rev_apply ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int chunk = s.rev_apply ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int stat = n / s.imgs_per_stat;
   const int col = tid % s.CV, rsub = tid / s.CV;
   const int c0 = col * 8, cpg = s.C / 32;
@@ -195,6 +198,16 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
   s->n_img = n_img; s->S = S; s->C = C; s->imgs_per_stat = imgs_per_stat; s->c_split = c_split;
   s->CV = C / 8;
   s->RPP = s->CV >= 256 ? 1 : 256 / s->CV;
+  {
+    // The statistics pass walks the tensor from its END and the apply pass from its start: each pass begins with the part of
+    // the tensor the pass (or producer) before it touched last, i.e. what the 256 MB Infinity Cache still holds (L0,
+    // 295 MB: 195.6 -> 186.9 us per norm; 14.7 -> 14.4 ms per step; same directions for both passes: no gain).  Which
+    // workgroup reads what first does not change any partial sum.  A/B handle: CTRLV_GN_REV bit 0 = statistics pass
+    // from the end, bit 1 = apply pass from the end.
+    static int rev = -1;
+    if (rev < 0) { const char* e = getenv("CTRLV_GN_REV"); rev = e ? atoi(e) : 1; }
+    s->rev_stats = rev & 1; s->rev_apply = (rev >> 1) & 1;
+  }
   // The row chunking -- and with it the order of every partial sum -- depends on the image size only, never on how
   // many images are in the batch: a clip's statistics are bit-identical whether it is normalised alone or in a batch
   // (clip independence, tests/test_fullsize_gpu.py).  ~1000-2000 workgroups at the cfg3 batch of 50 images:

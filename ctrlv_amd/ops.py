@@ -147,7 +147,13 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     if ev is not None:
         n_alg = d.N if geglu else min(d.N, d.n_store)
         fam = "gemm_conv3x3" if mode == 1 else ("gemm_conv_temporal" if mode == 2 else "gemm_linear")
-        _prof.end(ev, fam, 2.0 * d.M * n_alg * taps * cin)
+        esz = 4 if out_f32 else 2
+        n_out = d.n_store if not geglu else min(d.n_store, d.N // 2)
+        nbytes = (d.M * cin * 2 * (1 if mode == 0 else 1) + d.M * n_out * esz + d.N * taps * cin * 2
+                  + (d.M * n_out * 2 if R1 is not None else 0) + (d.M * n_out * 2 if R2 is not None else 0)
+                  + (d.M * n_out * 2 if raw_out is not None else 0))
+        _prof.end(ev, fam, 2.0 * d.M * n_alg * taps * cin, float(nbytes),
+                  detail=(fam, d.M, d.N, taps * cin, int(geglu), int(R1 is not None) + int(R2 is not None), d.vmode, act))
     return out
 
 

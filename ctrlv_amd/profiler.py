@@ -10,6 +10,7 @@ _active = None
 class KernelTimer:
     def __init__(self):
         self.records = []          # (family, flops, bytes, start_event, end_event)
+        self.details = []          # per record: a shape key (tools/shape_table.py) or None
 
     def __enter__(self):
         global _active
@@ -41,9 +42,10 @@ def begin():
     return ev
 
 
-def end(start, family, flops=0.0, nbytes=0.0):
+def end(start, family, flops=0.0, nbytes=0.0, detail=None):
     if start is None:
         return
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     _active.records.append((family, flops, nbytes, start, ev))
+    _active.details.append(detail)

@@ -83,6 +83,14 @@ def main():
             assert rc == 0, rc
         torch.cuda.synchronize()
         s = stamps.view(-1, 10).double()
+        if os.environ.get("STAMP_BY_WAVE"):       # rows are (workgroup, wave): the same table per wave id
+            sw = s.view(-1, 8, 10)
+            sw = sw[sw[:, 0, 8] > 0]
+            print(f"{name}: per wave id, cycles per half-step: " + " | ".join(nm[1:8]))
+            for w in range(8):
+                hs = sw[:, w, 8].mean().item()
+                print(f"   wave {w}: " + " ".join(f"{sw[:, w, i].mean().item() / hs:7.0f}" for i in range(1, 8))
+                      + f"   total/tile {sw[:, w, 0].mean().item() / sw[:, w, 9].mean().item():8.0f}")
         s = s[s[:, 8] > 0]
         tot = s[:, 0].mean().item()
         print(f"{name:28s} half-steps/wg {int(s[0, 8]):5d} tiles/wg {int(s[0, 9]):3d}  cycles/wave {tot:10.0f}")
