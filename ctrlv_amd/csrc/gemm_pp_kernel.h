@@ -796,7 +796,16 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     if (cap > 0 && cap < num_cu) num_cu = cap;
   }
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
-  const int grid = (persistent && tiles > num_cu) ? num_cu : tiles;   // persistent: one 512-thread workgroup per CU
+  // persistent: one 512-thread workgroup per CU, every workgroup the same number of tiles.  1800 tiles (the N = 320 layers of
+  // the 72 x 128 level) are 8 rounds on 256 CUs with 8 workgroups in the last one: 225 workgroups finish at the same time
+  // and leave 31 CUs to the other stream's kernels (and their power to the clock) for the whole launch, not for its tail.
+  int grid = tiles;
+  if (persistent && tiles > num_cu) {
+    const int rounds = (tiles + num_cu - 1) / num_cu;
+    static int balanced = -1;            // A/B handle: CTRLV_PP_BALANCED=0 -> one workgroup per CU whatever the tile count
+    if (balanced < 0) { const char* e = getenv("CTRLV_PP_BALANCED"); balanced = e ? atoi(e) : 1; }
+    grid = balanced ? (tiles + rounds - 1) / rounds : num_cu;
+  }
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
