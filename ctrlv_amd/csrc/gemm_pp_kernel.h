@@ -387,7 +387,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 // combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
 // output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, const int cgrp) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -433,6 +433,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   const int tiles_m = (d.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
   const int G = gridDim.x;
+  // Tile order.  Tile numbers run over COLUMN GROUPS of `cgrp` column tiles: all row blocks of group 0 (row-major inside the
+  // group), then group 1, ...  The 32 CUs of an XCD work on 32 consecutive numbers, i.e. on (32 / cgrp) row blocks x cgrp
+  // column tiles: cgrp weight tiles stay in that XCD's 4 MB L2 for the whole sweep over the rows while every activation
+  // tile is fetched once per group.  cgrp = tiles_n is the plain row-major order (right when the whole weight matrix fits
+  // L2: C = 320); launch_one() picks it from the weight tile's size.  Before: the C = 1280 GEGLU projection (26 MB of
+  // weights, 40 column tiles) re-read all of them for each of its 113 row blocks -- 3.2 GB per launch for 100 MB of operands.
+  const int grp_full = tiles_n / cgrp, grp_tiles = tiles_m * cgrp;
+  auto tile_mn = [&](int t, int& mt, int& nt) {
+    const int gi = t / grp_tiles;
+    if (gi < grp_full) {
+      const int rem = t - gi * grp_tiles;
+      mt = rem / cgrp; nt = gi * cgrp + (rem - mt * cgrp);
+    } else {
+      // (also reached by the issue stream's look-ahead past the last tile: any row block >= tiles_m reads zeros)
+      const int rem = t - grp_full * grp_tiles, w = tiles_n - grp_full * cgrp;
+      if (w > 0) { mt = rem / w; nt = grp_full * cgrp + (rem - mt * w); }
+      else { mt = tiles_m; nt = 0; }
+    }
+  };
   // tile of round r for this block: XCD-contiguous inside every window of G tiles
   const int my_first = xcd_remap(blockIdx.x, G);
   const int my_ntiles = (ntiles - my_first + G - 1) / G;       // >= 1 (grid <= ntiles)
@@ -466,7 +485,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   unsigned a_mask[A_Q];                                      // modes 1/2, bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
   unsigned b_voff[B_Q];                                      // byte offset of the weight row (+chunk), kOOB if out of range
   auto setup = [&](int tile) {
-    const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
+    int mt_, nt_;
+    tile_mn(tile, mt_, nt_);
+    const int bm = mt_ * BM, bn = nt_ * BN;
 #pragma unroll
     for (int q = 0; q < A_Q; ++q) {
       const int m = bm + (q * NW + wid) * 16 + prow;
@@ -577,7 +598,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
   // bias strip of this wave for the first tile (see pp_bias_load); its load is retired before any DMA is issued
   char* const bias_lds = smem + BIAS_OFF + wid * (WTN * 4);
   {
-    const int bn0 = (my_first % tiles_n) * BN;
+    int mt0, nt0;
+    tile_mn(my_first, mt0, nt0);
+    const int bn0 = nt0 * BN;
     const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
     pp_bias_store<WTN>(bias_lds, b, lane);
   }
@@ -707,7 +730,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
 
   for (int tr = 0; tr < my_ntiles; ++tr) {
     const int tile = my_first + tr * G;
-    const int bm = (tile / tiles_n) * BM, bn = (tile % tiles_n) * BN;
+    int mt_, nt_;
+    tile_mn(tile, mt_, nt_);
+    const int bm = mt_ * BM, bn = nt_ * BN;
     // The issue stream runs three half-steps ahead of the consuming one: it stays in this tile for J-3 half-steps and
     // then moves to the block's next tile (two K loops, so that the per-tile lane state is loop-invariant in each --
     // one loop with a conditional switch costs a dozen register copies per half-step).
@@ -733,7 +758,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d) {
       // bias columns of the next tile: loaded now, parked in the LDS strip after this epilogue's last bias read
       const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
       u32x4_t nb = {0, 0, 0, 0};
-      if (refill) nb = pp_bias_load<WTN>(d, ((tile + G) % tiles_n) * BN + wc * WTN, lane);
+      if (refill) {
+        int mtn, ntn;
+        tile_mn(tile + G, mtn, ntn);
+        nb = pp_bias_load<WTN>(d, ntn * BN + wc * WTN, lane);
+      }
       // The epilogue's lane constants (staging / read-back offsets, output column) do not depend on the tile: hipcc hoists
       // them out of the persistent loop and keeps them live (or spills them) around the K loop, which has no registers to
       // spare.  An opaque copy of the lane id makes them per-tile values: a dozen VALU instructions per tile instead.
@@ -806,7 +835,31 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     if (balanced < 0) { const char* e = getenv("CTRLV_PP_BALANCED"); balanced = e ? atoi(e) : 1; }
     grid = balanced ? (tiles + rounds - 1) / rounds : num_cu;
   }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d);
+  // Column-group width of the tile order (see the kernel), from a traffic model of the L2 <-> fabric reads (checked against
+  // TCC_EA0_RDREQ, tools/pmc_fetch.sh): an XCD's 32 CUs work on 32 consecutive tile numbers.
+  //   row-major (cgrp = tiles_n): A once; the weights once per XCD if they fit its L2, else once per 32-tile window
+  //   groups of c column tiles (c weight tiles resident, <= 2.5 MB): A once per group, the weights once per XCD
+  // The 3x3 / temporal gathers keep the row-major order (their weight tiles are streamed along K by CUs that run in step).
+  const int tiles_n = (d.N + BN - 1) / BN;
+  int cgrp = tiles_n;
+  {
+    static int forced = -2;              // A/B handle: CTRLV_PP_CGRP = -1 row-major, 0 model (default), n = fixed width
+    if (forced == -2) { const char* e = getenv("CTRLV_PP_CGRP"); forced = e ? atoi(e) : 0; }
+    const double w_tile = (double)BN * d.taps * d.Cin * 2, w_all = (double)d.N * d.taps * d.Cin * 2;
+    const double a_all = (double)d.M * d.Cin * 2, budget = 2.5 * 1048576.0;
+    if (forced > 0) cgrp = forced < tiles_n ? forced : tiles_n;
+    else if (forced == 0 && MODE == 0 && tiles_n > 1) {
+      const double windows = (double)tiles / 32.0;
+      const double w_per_window = w_tile * (tiles_n < 32 ? tiles_n : 32);
+      const double cost_row = a_all + (w_all <= 3.5 * 1048576.0 ? 8.0 * w_all : windows * w_per_window);
+      const int cmax = (int)(budget / w_tile);
+      if (cmax >= 1 && cmax < tiles_n) {
+        const double cost_grp = a_all * ((tiles_n + cmax - 1) / cmax) + 8.0 * w_all;
+        if (cost_grp < 0.8 * cost_row) cgrp = cmax;
+      }
+    }
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, stream, d, cgrp);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

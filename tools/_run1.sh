@@ -1,1 +1,4 @@
-for r in 0 240 224 192 0; do echo "=== CTRLV_PP_MAX_WG=$r"; CTRLV_PP_MAX_WG=$r python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python tools/show_bench.py /dev/stdin | grep "value"; done
+for rep in 1 2; do
+python tools/attn_bench.py 2>&1 | grep -v amdgpu | grep "L0\|L1"
+CTRLV_HIP_LIB=$PWD/ctrlv_amd/lib/ab/libctrlv_head.so python tools/attn_bench.py 2>&1 | grep -v amdgpu | grep "L0\|L1"
+done
