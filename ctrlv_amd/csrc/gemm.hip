@@ -92,8 +92,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
+    // K order: tap outermost (gemm_pp_kernel.h issue_end: the same order, so the same bits; the block-major alternative
+    // behind the same macro)
+#ifdef CTRLV_CONV_BLOCK_MAJOR
+    const int cb = kt / d.taps;
+    const int tap = kt - cb * d.taps;
+    int cc = cb << 6;
+#else
     const int tap = kt / kpt;
     int cc = (kt - tap * kpt) << 6;
+#endif
+    const int wcol = tap * d.Cin + cc;
     const bf16_t* src = (const bf16_t*)d.A;
     int ld = d.lda;
     if (d.A2 != nullptr && cc >= d.c_split) {
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
       const char* p = ok ? (const char*)(src + row * ld + cc + a_coff[q]) : zsrc;
       __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
     }
-    const bf16_t* wsrc = (const bf16_t*)d.W + (long)kt * 64;
+    const bf16_t* wsrc = (const bf16_t*)d.W + wcol;
 #pragma unroll
     for (int q = 0; q < B_INSTR; ++q) {
       const char* p = b_ok[q] ? (const char*)(wsrc + b_row[q] + b_coff[q]) : zsrc;

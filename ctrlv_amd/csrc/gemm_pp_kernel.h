@@ -575,7 +575,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   auto issue_piece = [&](int pc) {
     if (pc < A_Q) issue_a(pc); else issue_b(pc - A_Q);
   };
+  // K traversal of the 3x3 / temporal gathers: tap outermost, the channels inside it (the 2-stage kernel's order too --
+  // gemm.hip -- so the bits do not depend on the kernel).  Every tap then re-reads its A rows from the fabric (the re-use
+  // distance is a whole sweep over the channels, more than an XCD's L2 holds: 2.5 GB of L2 <-> fabric reads per launch for
+  // the 295 MB input of the 320 -> 320 conv of the 72 x 128 level, 8.3 GB for its 960 -> 320 one; TCC_EA0_RDREQ,
+  // tools/pmc_fetch.sh).  The alternative -- 64-channel block outermost, taps inside, -DCTRLV_CONV_BLOCK_MAJOR -- fetches
+  // every line once (0.47 / 1.3 GB, L2 hit rate 0.77 -> 0.95) and is 7-9 % faster on the C = 640 / 1280 convs when the same
+  // launch is repeated, but 1.5-2.5 % SLOWER on every conv shape inside the model (tools/shape_table.py, both orders in
+  // one session; 63.6 vs 64.8 ms of conv kernels per step): the reads it saves come out of the Infinity Cache, which is
+  // not what these kernels wait for, and its weight reads jump by Cin between consecutive half-steps.  Not the default.
   auto issue_end = [&]() {
+#ifdef CTRLV_CONV_BLOCK_MAJOR
+    if (MODE != 0) {
+      if (is_cc & 32) {
+        ++is_tap;
+        if (is_tap == d.taps) { is_tap = 0; is_cc += 32; } else { is_cc -= 32; }
+      } else {
+        is_cc += 32;
+      }
+      return;
+    }
+#endif
     is_cc += 32;
     if (MODE != 0 && is_cc == d.Cin) { is_cc = 0; ++is_tap; }   // (plain GEMM: one tap, next_tile() rewinds)
   };
@@ -838,7 +858,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // Column-group width of the tile order (see the kernel), from a traffic model of the L2 <-> fabric reads (checked against
   // TCC_EA0_RDREQ, tools/pmc_fetch.sh): an XCD's 32 CUs work on 32 consecutive tile numbers.
   //   row-major (cgrp = tiles_n): A once; the weights once per XCD if they fit its L2, else once per 32-tile window
-  //   groups of c column tiles (c weight tiles resident, <= 2.5 MB): A once per group, the weights once per XCD
+  //   groups of c column tiles (c weight tiles resident, <= 3 MB): A once per group, the weights once per XCD
   // The 3x3 / temporal gathers keep the row-major order (their weight tiles are streamed along K by CUs that run in step).
   const int tiles_n = (d.N + BN - 1) / BN;
   int cgrp = tiles_n;
@@ -846,7 +866,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     static int forced = -2;              // A/B handle: CTRLV_PP_CGRP = -1 row-major, 0 model (default), n = fixed width
     if (forced == -2) { const char* e = getenv("CTRLV_PP_CGRP"); forced = e ? atoi(e) : 0; }
     const double w_tile = (double)BN * d.taps * d.Cin * 2, w_all = (double)d.N * d.taps * d.Cin * 2;
-    const double a_all = (double)d.M * d.Cin * 2, budget = 2.5 * 1048576.0;
+    const double a_all = (double)d.M * d.Cin * 2, budget = 3.0 * 1048576.0;
     if (forced > 0) cgrp = forced < tiles_n ? forced : tiles_n;
     else if (forced == 0 && MODE == 0 && tiles_n > 1) {
       const double windows = (double)tiles / 32.0;
