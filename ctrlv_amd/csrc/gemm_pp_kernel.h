@@ -876,6 +876,11 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
       if (cmax >= 1 && cmax < tiles_n) {
         const double cost_grp = a_all * ((tiles_n + cmax - 1) / cmax) + 8.0 * w_all;
         if (cost_grp < 0.8 * cost_row) cgrp = cmax;
+        // measured inside the model (tools/shape_table.py, CTRLV_PP_CGRP = 1..8 in one session): the C = 640 GEGLU projection
+        // on the 320-wide tile is fastest in PAIRS of column tiles (15.3 ms per step against 16.3 row-major, 15.9-16.4 at
+        // widths 3..8) -- a pair's output rows are five whole 128-B lines, a single tile's 2.5; the 256-wide tile of the
+        // C = 1280 projections gains up to the widest group that fits (13.5 against 14.5 ms)
+        if (GEGLU && BN == 320 && cgrp != tiles_n) cgrp = 2;
       }
     }
   }
