@@ -242,6 +242,11 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     else if (d.N <= 128 && d.mode != 0) tile = 10;     // 256x128 ping-pong tile (profiles/r02_vae_decode.txt)
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
+    {
+      static int force = -1;             // A/B handle (tools/shape_table.py): CTRLV_GEMM_FORCE_TILE = 5 / 6 for every large launch
+      if (force < 0) { const char* e = getenv("CTRLV_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }
+      if ((force == 5 || force == 6) && tile >= 5 && tile <= 6) tile = force;
+    }
   }
   if (d.raw_out) {      // second output of the GEGLU projection (training forward): ping-pong tiles only
     CTRLV_CHECK_ARG(d.geglu && d.ld_raw >= d.N, "ctrlv_gemm: raw_out needs geglu = 1 and ld_raw >= N");

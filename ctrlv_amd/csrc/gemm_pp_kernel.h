@@ -400,12 +400,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
   // the LOAD phase, the others in the four gaps of the MFMA cluster (where an LDS-DMA issue overlaps the matrix pipe).
   // Whichever phase is longer sets the slot time, so NL balances them: A/B on one device (tools/ab_build.py
-  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase), 2 of 5 for the 320-wide one (20 MFMAs).
+  // -DCTRLV_PP_NL=n): 3 of 4 for the 256-wide tile (16 MFMAs per phase); for the 320-wide one (20 MFMAs) 2 of 5 won the
+  // single-kernel sweeps of round 1, but inside the model 4 of 5 is the faster one (234.5 -> 233.2 ms per step, three
+  // alternations on one device; 1 of 5: 243 ms): repeated launches of one kernel flatter whatever leans on the caches.
   constexpr int NPIECE = A_Q + B_Q;
 #ifdef CTRLV_PP_NL
   constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
 #else
-  constexpr int NL = BN == 256 ? A_Q + 1 : A_Q;
+  constexpr int NL = BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q);
 #endif
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
   static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");

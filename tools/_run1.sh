@@ -1,1 +1,5 @@
-for rep in 1 2; do for r in -1 0; do echo "=== CTRLV_PP_CGRP=$r"; CTRLV_PP_CGRP=$r python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python tools/show_bench.py /dev/stdin | grep "value\|gemm_linear"; done; done
+for rep in 1 2 3; do for v in "" nl4; do
+  if [ -n "$v" ]; then export CTRLV_HIP_LIB=$PWD/ctrlv_amd/lib/ab/libctrlv_$v.so; else unset CTRLV_HIP_LIB; fi
+  echo "=== variant: ${v:-default}"
+  python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python tools/show_bench.py /dev/stdin | grep "value"
+done; done
