@@ -43,7 +43,7 @@ extern "C" int ctrlv_last_error(char* buf, size_t n) {
   return (int)strlen(g_err);
 }
 
-extern "C" int ctrlv_abi_version(void) { return 13; }
+extern "C" int ctrlv_abi_version(void) { return 14; }
 
 // sha256 prefix of ctrlv_amd/csrc/* + include/*.h at build time (stamped by __graft_entry__.build()): the host layer
 // refuses a library whose id differs from the sources next to it.

@@ -116,7 +116,11 @@ struct ResBlock {
   int temb_off[2] = {0, 0};
   std::string name;
 };
-struct FeedFwd { Linear proj, out; };
+struct FeedFwd {
+  Linear proj, out;
+  bf16_t* w1f = nullptr;      // C = 320 only: the fragment-major forms of ctrlv_ff_fused (ff_fused.hip), else null
+  bf16_t* w2f = nullptr;
+};
 struct Transformer {
   int C = 0;
   double alpha = 0.5;
@@ -345,7 +349,13 @@ struct Loader {
   }
   int ff(const std::string& mod, int C, int C_out, FeedFwd& f) {     // FeedForward: GEGLU(C -> 8C) then Linear(4C -> C_out)
     TRY(linear(mod + ".net.0.proj", 8 * C, C, f.proj, true, 1));
-    return linear(mod + ".net.2", C_out, 4 * C, f.out);
+    TRY(linear(mod + ".net.2", C_out, 4 * C, f.out));
+    if (C == 320 && C_out == 320 && f.proj.n == 2560 && f.proj.k == 320 && f.out.n == 320 && f.out.k == 1280) {
+      TRY(alloc((size_t)2560 * 320 * 2, (void**)&f.w1f, false));
+      TRY(alloc((size_t)320 * 1280 * 2, (void**)&f.w2f, false));
+      TRY(ctrlv_ff_fused_pack(f.proj.w, f.out.w, f.w1f, f.w2f, st));
+    }
+    return CTRLV_OK;
   }
   int qkv(const std::string& mod, int C, Linear& l) {
     TRY(new_linear(l, 3 * C, pad_to(C, 64), false));
@@ -577,7 +587,16 @@ int ff_rows_per_chunk(long M, int C) {
   const long n = (u_bytes + (160L << 20) - 1) / (160L << 20);
   return (int)(((M + n - 1) / n + 255) / 256 * 256);
 }
-int ff_pair(Ctx& c, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C) {
+int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C) {
+  // C = 320, OPT-IN (CTRLV_FF_FUSED=1): one fused launch, the 4C-wide intermediate stays on chip (ff_fused.hip).  Measured
+  // equal to the two launches in the model (232.9 vs 233.3 ms per step, three alternations), so the default stays the pair.
+  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return e && atoi(e) != 0; }();
+  if (fuse && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
+                                             outd.R2 != nullptr)) {
+    if (c.dry) return CTRLV_OK;
+    if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, proj.bias, f.w2f, &outd, c.st);
+  }
   const int M = proj.M, rows = ff_rows_per_chunk(M, C);
   for (int m0 = 0; m0 < M; m0 += rows) {
     const int mc = M - m0 < rows ? M - m0 : rows;
@@ -636,21 +655,18 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
     d.R1 = h1; d.ldr1 = C;
-    TRY(ff_pair(c, dp, d, C));
+    TRY(ff_pair(c, t.s_ff, dp, d, C));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
   TRY(layernorm(c, h2, (int)M, C, t.t_lnin, tt, emb, S, F, C));
-  {
-    ctrlv_gemm_desc d = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
-    d.geglu = 1;
-    TRY(gemm(c, d));
-  }
   bf16_t* g0 = h1;      // h1 is dead
   {
+    ctrlv_gemm_desc dp = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
+    dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0, C, (int)M, C, 4 * C, C);
     d.R1 = h2; d.ldr1 = C;
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
-    TRY(gemm(c, d));
+    TRY(ff_pair(c, t.t_ffin, dp, d, C));
   }
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
@@ -672,7 +688,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
     d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
     d.s2 = (float)t.alpha;
-    TRY(ff_pair(c, dp, d, C));
+    TRY(ff_pair(c, t.t_ff, dp, d, C));
   }
   {
     ctrlv_gemm_desc d = gd(h3, C, t.pout, out, C, (int)M, C, C, C);

@@ -136,8 +136,18 @@ def _ff_rows_per_chunk(M, C):
     return ((M + n - 1) // n + 255) // 256 * 256
 
 
-def _ff_pair(x, wproj, bproj, u, wout, bout, out, C, **epi):
-    """u = GEGLU(x); out = epilogue(u @ wout^T): issued as M-chunked pairs (same arithmetic, same bits)."""
+_FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ff_pair)
+
+
+def _ff_pair(x, ffp, u, out, C, **epi):
+    """u = GEGLU(x); out = epilogue(u @ wout^T).  ffp = (wproj, bproj, wout, bout[, w1f, w2f]): at C = 320 one fused launch
+    that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs, issued as
+    M-chunked pairs (same arithmetic, same bits)."""
+    wproj, bproj, wout, bout = ffp[:4]
+    if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(C, 4 * C, epi.get("vmode", 0) if "V" in epi else 0,
+                                                           epi.get("vdiv", 1), epi.get("s_acc", 1.0), "R1" in epi, "R2" in epi):
+        ops.ff_fused(x, ffp[4], bproj, ffp[5], out, bias=bout, **epi)
+        return
     M = x.shape[0]
     rows = _ff_rows_per_chunk(M, C)
     for m0 in range(0, M, rows):
@@ -258,7 +268,10 @@ class TransformerSpatioTemporalModel(nn.Module):
 
         def ff(f):
             w, b = packing.pack_geglu(f.net[0].proj.weight, f.net[0].proj.bias)
-            return w, b, packing.pack_linear(f.net[2].weight), _f32(f.net[2].bias)
+            w2 = packing.pack_linear(f.net[2].weight)
+            if tuple(w.shape) == (2560, 320) and tuple(w2.shape) == (320, 1280) and w.is_cuda:
+                return (w, b, w2, _f32(f.net[2].bias)) + ops.ff_fused_pack(w.contiguous(), w2.contiguous())
+            return w, b, w2, _f32(f.net[2].bias)
 
         def ln(n):
             return _f32(n.weight), _f32(n.bias)
@@ -328,12 +341,11 @@ class TransformerSpatioTemporalModel(nn.Module):
         ops.layernorm(h1, pk["s_ln3"][0], pk["s_ln3"][1], 1e-5, t)
         u = ws.alloc((M, 4 * C))
         h2 = h0                                         # h0 is dead from here on
-        _ff_pair(t, pk["s_ff"][0], pk["s_ff"][1], u, pk["s_ff"][2], pk["s_ff"][3], h2, C, R1=h1)
+        _ff_pair(t, pk["s_ff"], u, h2, C, R1=h1)
         # ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
         ops.layernorm(h2, pk["t_lnin"][0], pk["t_lnin"][1], 1e-5, t, V=emb, vdiv=S, vmod=F)
-        ops.gemm(t, pk["t_ffin"][0], u, N=8 * C, cin=C, bias=pk["t_ffin"][1], geglu=1)
         g0 = h1                                         # h1 is dead
-        ops.gemm(u, pk["t_ffin"][2], g0, N=C, cin=4 * C, bias=pk["t_ffin"][3], R1=h2, V=emb, vmode=1, vdiv=S, vmod=F)
+        _ff_pair(t, pk["t_ffin"], u, g0, C, R1=h2, V=emb, vmode=1, vdiv=S, vmod=F)
         ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
         ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
         ops.attention_temporal(qkv, a, B, F, S, C)
@@ -348,8 +360,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
-        _ff_pair(t, pk["t_ff"][0], pk["t_ff"][1], u, pk["t_ff"][2], pk["t_ff"][3], h3, C, s_acc=1.0 - al, R1=g1,
-                 s1=1.0 - al, R2=h2, s2=al)
+        _ff_pair(t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
         if ctx.trace is not None:

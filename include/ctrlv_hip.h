@@ -120,6 +120,20 @@ int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img,
 int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps,
                     const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream);
 
+/* Fused feed-forward pair at C = 320:  out = epilogue( GEGLU(x . W1^T + b1) . W2^T )  with the second projection's
+ * epilogue operands taken from `out_desc` (out, bias = b2, R1 / R2 / V, s_acc, s1, s2, M, N = 320, Cin = 1280, mode 0):
+ * the two ctrlv_gemm launches of BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff [DIFF-0.27.2
+ * attention.py FeedForward(GEGLU)] without the 4C-wide intermediate in HBM.  x: bf16 [M][ldx]; b1: fp32 [2560] in the
+ * GEGLU-interleaved row order of the packed W1; w1f / w2f: the fragment-major forms written by ctrlv_ff_fused_pack from
+ * the packed weights ([2560][320] interleaved, [320][1280]).  Results: same arithmetic as the two launches up to the
+ * summation order of the second projection (csrc/ff_fused.hip). */
+int ctrlv_ff_fused_pack(const void* w1_packed, const void* w2_packed, void* w1f, void* w2f, ctrlv_stream_t stream);
+int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const float* b1, const void* w2f,
+                   const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream);
+/* 1 if ctrlv_ff_fused serves these settings of the second projection (N = 320, Cin = 1280; epilogue bias, +R1 or +R1+R2;
+ * a row-vector operand only with vmode 1, vdiv a multiple of 256 and s_acc == 1), 0 = use the two ctrlv_gemm launches. */
+int ctrlv_ff_fused_serves(int n, int cin, int vmode, int vdiv, float s_acc, int has_r1, int has_r2);
+
 /* Row softmax of fp32 scores into bf16 probabilities: probs[r, :cols] = softmax(scores[r, :cols]) (cols a multiple of 4,
  * <= 16384).  The VAE mid block's single-head attention (head dim 512; AutoencoderKLTemporalDecoder, called by
  * pipeline_video_control.py:235,278,346) runs as scores GEMM -> this -> P.V GEMM. */

@@ -476,3 +476,62 @@ def test_time_conv_rows_to_nchw(ops):
         out = torch.empty(n, co, H, W, dtype=dt, device=DEV)
         ops.time_conv_rows_to_nchw(y.to(DEV), n, co, H * W, wt.to(DEV), b.to(DEV), out)
         assert parity_err(out, ref) < (1e-5 if dt == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize("M,epi", [(256, "r1"), (1000, "r1"), (2048 + 72, "r1r2"), (777, "r1v"), (512, "none"), (256 * 70, "r1v")])
+def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
+    """ctrlv_ff_fused (C = 320 feed-forward with the 4C-wide intermediate on chip) against the two ctrlv_gemm launches it
+    replaces, same packed weights: GEMM 1, the GELU table and the bf16 rounding of u are the same operations, GEMM 2 sums in
+    a different order -- so the two agree to fp32 summation noise on the bf16 output -- and against an fp64 reference."""
+    from ctrlv_amd import packing
+    C, I = 320, 1280
+    w1 = torch.randn(2 * I, C, generator=g(1)) / C ** 0.5
+    b1 = torch.randn(2 * I, generator=g(2)) * 0.5
+    w2 = torch.randn(C, I, generator=g(3)) / I ** 0.5
+    b2 = torch.randn(C, generator=g(4))
+    x = bf(torch.randn(M, C, generator=g(5)))
+    r1 = bf(torch.randn(M, C, generator=g(6)))
+    r2 = bf(torch.randn(M, C, generator=g(7)))
+    V = torch.randn(5, C, generator=g(8))
+    w1p, b1p = packing.pack_geglu(w1.to(DEV), b1.to(DEV))
+    w2p = packing.pack_linear(w2.to(DEV))
+    w1f, w2f = ops.ff_fused_pack(w1p, w2p)
+    kw = {}
+    if epi in ("r1", "r1r2", "r1v"):
+        kw.update(R1=r1.to(DEV), s1=1.0)
+    if epi == "r1r2":
+        kw.update(R2=r2.to(DEV), s2=0.25, s_acc=0.75, s1=0.75)
+    if epi == "r1v":        # a row vector per 512 rows (vdiv must be a multiple of the 256-row tile: ff_fused_serves)
+        kw.update(V=V.to(DEV), vmode=1, vdiv=512, vmod=5)
+        assert ops.ff_fused_serves(320, 1280, vmode=1, vdiv=512, has_r1=True)
+        assert not ops.ff_fused_serves(320, 1280, vmode=1, vdiv=200, has_r1=True)
+        assert not ops.ff_fused_serves(320, 1280, vmode=2, vdiv=512, has_r1=True)
+    xd = x.to(DEV)
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.ff_fused(xd, w1f, b1p.float().contiguous(), w2f, out, bias=b2.to(DEV), **kw)
+    # the two launches
+    u = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(xd, w1p, u, N=2 * I, cin=C, bias=b1p.float().contiguous(), geglu=1)
+    ref2 = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(u, w2p, ref2, N=C, cin=I, bias=b2.to(DEV), **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    # fp64 reference with u rounded to bf16 like both paths do
+    a, gt = (x.double() @ bf(w1).double().t() + b1.double()).chunk(2, dim=-1)
+    uu = bf((a * torch.nn.functional.gelu(gt)).float()).double()
+    ref = uu @ bf(w2).double().t() + b2.double()
+    ref = kw.get("s_acc", 1.0) * ref
+    if "R1" in kw:
+        ref = ref + kw["s1"] * r1.double()
+    if "R2" in kw:
+        ref = ref + kw["s2"] * r2.double()
+    if "V" in kw:
+        ref = ref + V.double()[(torch.arange(M) // 512) % 5]
+    assert parity_err(ref2, ref.float()) < 3e-3
+    assert parity_err(out, ref.float()) < 3e-3
+    assert parity_err(out, ref2.float().cpu()) < 3e-3
+    # run-to-run: the kernel is deterministic, so any difference between repeats is a race
+    for _ in range(10):
+        again = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.ff_fused(xd, w1f, b1p.float().contiguous(), w2f, again, bias=b2.to(DEV), **kw)
+        assert torch.equal(again, out)
