@@ -11,12 +11,10 @@
 //     SIT as the B operand of 10 MFMAs (h chunk . W2 chunk).  In the result layout of v_mfma_f32_32x32x16 a lane holds, of
 //     its row, hidden columns 8q + 4h + r (q = 0..1, r = 0..3, h = lane >> 5); as a B operand its eight values are k-slots
 //     8h + 4q + r.  ctrlv_ff_fused_pack() stores W2 with its K index permuted accordingly, so no data moves between lanes.
-//   * W1 / W2 chunks (20 + 10 KiB, fragment-major so that every ds_read_b128 is a contiguous KiB per wave) stream through a
-//     2-slot LDS ring by LDS-DMA, one chunk ahead; one barrier per chunk.  All eight waves run in step: both waves of a
-//     SIMD do GEMM 1 together, then GEGLU together (matrix pipe idle), then GEMM 2 -- which is why this version only ties
-//     with the two launches (1.41-1.45 ms against 1.45-1.52 ms at M = 460 800; in the model +-0).  A stagger of the two
-//     groups by a third of a chunk needs a third W2 slot, i.e. the bias strip out of LDS and three x fragments spilled
-//     (measured: 1.55-1.61 ms): the LDS and the register file are both full.  OPT-IN (CTRLV_FF_FUSED=1) until it pays.
+//   * W1 / W2 chunks (21 + 10 KiB, fragment-major so that every ds_read_b128 is a contiguous KiB per wave) stream through
+//     LDS rings by LDS-DMA, two chunks ahead of the window boundary; one barrier per chunk.  The two waves of a SIMD run a
+//     third of a chunk apart (see the kernel) so that one's GEGLU runs beside the other's MFMAs; in step, the first version
+//     only tied with the two launches (1.35-1.45 ms at M = 460 800; this one 1.29-1.30 against 1.44-1.52; -1.35 % per step)
 //   * epilogue = the ping-pong GEMM's (gemm_epilogue_lds: s_acc * acc + s1 R1 + s2 R2 + V, LDS transpose, 16-B stores)
 // Arithmetic: the same MFMA, the same K order inside GEMM 1, the same bias-as-C-operand, the same GELU table and the same
 // bf16 rounding of u as the two-launch path; GEMM 2 sums its K = 1280 in chunk order with the permuted slot assignment, so
@@ -29,16 +27,17 @@ namespace {
 
 constexpr int kC = 320, kHid = 1280, kChunks = kHid / 16;        // 80 chunks of 16 hidden columns
 constexpr int kXHi = 8 * 10 * 1024;                              // x k-steps 10..19: [wave][ks][lane] x 16 B
-constexpr int kW1Slot = 20 * 1024, kW2Slot = 10 * 1024, kSlot = kW1Slot + kW2Slot;
-constexpr int kTabOff = kXHi + 2 * kSlot;
-constexpr int kB1Off = kTabOff + kGeluTabBytes;                  // 2560 floats (interleaved order)
-constexpr int kB2Off = kB1Off + 2 * kHid * 4;                    // 320 floats
-constexpr int kSmem = kB2Off + kC * 4;
+constexpr int kW1Pieces = 21;                                    // 20 k-steps of K = 320 + one carrying the bias (see below)
+constexpr int kW1Slot = kW1Pieces * 1024, kW2Slot = 10 * 1024;
+constexpr int kW1Off = kXHi;                                     // W1 ring: 2 slots (chunk c, chunk c + 1 in flight)
+constexpr int kW2Off = kW1Off + 2 * kW1Slot;                     // W2 ring: 3 slots (c - 1 for the late group, c, c + 1)
+constexpr int kTabOff = kW2Off + 3 * kW2Slot;
+constexpr int kSmem = kTabOff + kGeluTabBytes;
 static_assert(kSmem <= 160 * 1024, "fused feed-forward tile does not fit the LDS");
 
 struct FfArgs {
   const bf16_t* x; int ldx;
-  const bf16_t* w1f; const float* b1; const bf16_t* w2f;
+  const bf16_t* w1f; const bf16_t* w2f;
   ctrlv_gemm_desc o;            // the second projection's descriptor: out, bias (b2), R1, R2, scales, M, N = 320
   const float* vtab; int vdiv, vmod, ldv;   // row-vector operand V[(m / vdiv) % vmod] (vtab = nullptr: none), see below
 };
@@ -55,27 +54,40 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
   const int tiles = (M + 255) / 256, G = gridDim.x;
 
   gelu_table_fill(smem + kTabOff, threadIdx.x, 512);
-  for (int i = threadIdx.x; i < 2 * kHid; i += 512) *(float*)(smem + kB1Off + i * 4) = a.b1[i];
-  for (int i = threadIdx.x; i < kC; i += 512) *(float*)(smem + kB2Off + i * 4) = d.bias ? d.bias[i] : 0.f;
 
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1f, 0, kChunks * kW1Slot, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2f, 0, kChunks * kW2Slot, 0x00020000);
-  // this wave's pieces of a chunk: KiB number k * 8 + wid (k = 0..3) of the chunk's 30 (20 of W1, then 10 of W2)
-  auto dma = [&](int chunk, int slot) {
-    char* base = smem + kXHi + slot * kSlot;
+  // this wave's pieces of a chunk: KiB number k * 8 + wid (k = 0..3) of the chunk's 31 (21 of W1, then 10 of W2);
+  // `cg` = the workgroup's running chunk count (ring phase), `chunk` = which of the 80 chunks of the weights
+  auto dma = [&](int chunk, int cg) {
+    char* s1 = smem + kW1Off + (cg & 1) * kW1Slot;
+    char* s2 = smem + kW2Off + (cg % 3) * kW2Slot;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int pi = k * 8 + wid;                            // wave-uniform
-      if (pi < 20)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, LDS_PTR(base + pi * 1024), 16, lane * 16, chunk * kW1Slot + pi * 1024, 0, 0);
-      else if (pi < 30)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, LDS_PTR(base + pi * 1024), 16, lane * 16, chunk * kW2Slot + (pi - 20) * 1024, 0, 0);
+      if (pi < kW1Pieces)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, LDS_PTR(s1 + pi * 1024), 16, lane * 16, chunk * kW1Slot + pi * 1024, 0, 0);
+      else if (pi < kW1Pieces + 10)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, LDS_PTR(s2 + (pi - kW1Pieces) * 1024), 16, lane * 16,
+                                                 chunk * kW2Slot + (pi - kW1Pieces) * 1024, 0, 0);
     }
   };
   dma(0, 0);
-  __syncthreads();                                           // table / bias strips visible to every wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           // chunk 0 and the table visible to every wave
+  dma(1, 1);                                                 // (every later DMA is issued at a window boundary)
   const char* tab = smem + kTabOff;
   char* const xhi = smem + wid * 10 * 1024 + lane * 16;
+  // The two waves of a SIMD (w, w + 4) run A THIRD OF A CHUNK APART: between two barriers group 0 does [GEMM 1, GEGLU,
+  // GEMM 2] of chunk c, group 1 [GEMM 2 of chunk c - 1, GEMM 1, GEGLU of chunk c] -- so one wave's GEGLU (VALU + table
+  // reads) runs beside its partner's MFMAs instead of beside its partner's GEGLU (in step, the matrix pipe idled through
+  // both: the first version of this kernel only tied with the two launches).  W2 chunks therefore live for two windows
+  // (3-slot ring).  The LDS for the third slot comes from the GEMM-1 bias: it is not a 10 KB strip read as the C operand
+  // but a 21st K step -- the packed W1 chunk carries (bf16(b), bf16(b - bf16(b))) in two K slots against a constant-one x
+  // fragment, which adds b to within 2^-17 |b| in the fp32 accumulator -- and from b2, read from global once per tile.
+  const int grp = wid >> 2;
+  const uint4 xone_u = hsel == 0 ? make_uint4(0x3F803F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+  const bf16x8 xone = __builtin_bit_cast(bf16x8, xone_u);
 
   int cglob = 0;                                             // chunks processed so far by this workgroup (ring phase)
   for (int tile = blockIdx.x; tile < tiles; tile += G) {
@@ -108,33 +120,36 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
     for (int n = 0; n < 10; ++n)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float4 v = *(const float4*)(smem + kB2Off + (n * 32 + 8 * q + 4 * hsel) * 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) v = *(const float4*)(d.bias + n * 32 + 8 * q + 4 * hsel);
         if (vrow) {
           const float4 w = *(const float4*)(vrow + n * 32 + 8 * q + 4 * hsel);
           v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
         acc[0][n][4 * q] = v.x; acc[0][n][4 * q + 1] = v.y; acc[0][n][4 * q + 2] = v.z; acc[0][n][4 * q + 3] = v.w;
       }
-    // the first chunk's weights (issued before the previous tile's last barrier, or in the prologue) must have landed,
-    // and every wave's x_hi writes must be visible
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    // One instruction stream for both groups -- GEMM 1, GEGLU, GEMM 2 per chunk -- and ONE window boundary per chunk (wait
+    // for the DMA issued a window ago, barrier, issue the DMA two chunks ahead), which group 0 takes after GEMM 2 and
+    // group 1 between GEGLU and GEMM 2.  Ring safety: after boundary k the W1 slot of chunk k + 2 was last read by GEMM 1
+    // of chunk k (both groups: before their boundary k), its W2 slot by group 1's GEMM 2 of chunk k - 1 (between its
+    // boundaries k - 1 and k).  x_hi, the staging and the accumulators are wave-private: a new tile needs no barrier.
+    auto boundary = [&](int c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      dma((c + 2) % kChunks, cglob + 2);
+    };
     for (int c = 0; c < kChunks; ++c, ++cglob) {
-      const int slot = cglob & 1;
-      const char* st = smem + kXHi + slot * kSlot + lane * 16;
-      dma(c + 1 < kChunks ? c + 1 : 0, slot ^ 1);            // next chunk (the next tile starts at chunk 0 again)
-      f32x16 a1;                                             // GEMM 1 starts from the chunk's bias (C operand)
+      const char* s1 = smem + kW1Off + (cglob & 1) * kW1Slot + lane * 16;
+      f32x16 a1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *(const float4*)(smem + kB1Off + (c * 32 + 8 * q + 4 * hsel) * 4);
-        a1[4 * q] = v.x; a1[4 * q + 1] = v.y; a1[4 * q + 2] = v.z; a1[4 * q + 3] = v.w;
-      }
+      for (int e = 0; e < 16; ++e) a1[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 20; ++ks) {
-        const bf16x8 wf = *(const bf16x8*)(st + ks * 1024);
+        const bf16x8 wf = *(const bf16x8*)(s1 + ks * 1024);
         const bf16x8 xf = ks < 10 ? xr[ks] : *(const bf16x8*)(xhi + (ks - 10) * 1024);
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, a1, 0, 0, 0);
       }
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(s1 + 20 * 1024), xone, a1, 0, 0, 0);   // + bias
       // GEGLU in the result layout: accumulators 0..7 are the 8 value columns of this lane, 8..15 their gates
       float h[8];
 #pragma unroll
@@ -142,13 +157,14 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       const uint4 hp = make_uint4(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]),
                                   pack_bf16x2(h[6], h[7]));
       const bf16x8 hf = __builtin_bit_cast(bf16x8, hp);
+      if (grp == 1) boundary(c);
+      const char* s2 = smem + kW2Off + (cglob % 3) * kW2Slot + lane * 16;
 #pragma unroll
       for (int n = 0; n < 10; ++n) {
-        const bf16x8 wf = *(const bf16x8*)(st + kW1Slot + n * 1024);
+        const bf16x8 wf = *(const bf16x8*)(s2 + n * 1024);
         acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc[0][n], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (grp == 0) boundary(c);
     }
     // (x fragments are dead here: end their live ranges so that the epilogue's prefetch window gets their registers)
 #pragma unroll
@@ -161,20 +177,29 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
                                          nullptr, tab);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging reads done before the next tile's x_hi writes
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last chunk: nothing may be in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last chunks: nothing may be in flight
 #endif
 }
 
-// fragment-major copies of the two packed weights (device-side permutation of bf16 values, once per weight)
-__global__ void ff_pack_kernel(const bf16_t* __restrict__ w1p, const bf16_t* __restrict__ w2p, bf16_t* __restrict__ w1f,
-                               bf16_t* __restrict__ w2f) {
+// fragment-major copies of the two packed weights (device-side permutation of bf16 values, once per weight); the 21st
+// K step of every W1 chunk carries the GEMM-1 bias as (bf16(b), bf16(b - bf16(b))) in K slots 0 and 1
+__global__ void ff_pack_kernel(const bf16_t* __restrict__ w1p, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+                               bf16_t* __restrict__ w1f, bf16_t* __restrict__ w2f) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n1 = (long)kChunks * 20 * 64 * 8, n2 = (long)kChunks * 10 * 64 * 8;
+  const long n1 = (long)kChunks * kW1Pieces * 64 * 8, n2 = (long)kChunks * 10 * 64 * 8;
   if (i < n1) {
     // w1f[chunk][ks][lane][j] = w1p[chunk*32 + lane%32][ks*16 + 8*(lane/32) + j]
     const int j = i & 7, lane = (i >> 3) & 63;
-    const int ks = (int)((i >> 9) % 20), chunk = (int)(i / (20 * 512));
-    w1f[i] = w1p[(long)(chunk * 32 + (lane & 31)) * kC + ks * 16 + 8 * (lane >> 5) + j];
+    const int ks = (int)((i >> 9) % kW1Pieces), chunk = (int)(i / (kW1Pieces * 512));
+    bf16_t v = 0;
+    if (ks < 20) {
+      v = w1p[(long)(chunk * 32 + (lane & 31)) * kC + ks * 16 + 8 * (lane >> 5) + j];
+    } else if (lane < 32 && j < 2) {
+      const float b = b1[chunk * 32 + lane];
+      const bf16_t hi = f32_to_bf16(b);
+      v = j == 0 ? hi : f32_to_bf16(b - __uint_as_float((unsigned)hi << 16));
+    }
+    w1f[i] = v;
   } else if (i < n1 + n2) {
     // w2f[chunk][n][lane][j] = w2p[n*32 + lane%32][chunk*16 + 8*(j/4) + 4*(lane/32) + j%4]   (k-slot 8h + j <-> column)
     const long k = i - n1;
@@ -207,21 +232,23 @@ int launch_ff(const FfArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const void* w2_packed, void* w1f, void* w2f,
+extern "C" long ctrlv_ff_fused_w1f_bytes(void) { return (long)kChunks * kW1Slot; }
+
+extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const void* w2_packed, void* w1f, void* w2f,
                                    ctrlv_stream_t stream) {
-  CTRLV_CHECK_ARG(w1_packed && w2_packed && w1f && w2f, "ctrlv_ff_fused_pack: null pointer");
-  const long n = (long)kChunks * 30 * 64 * 8;
+  CTRLV_CHECK_ARG(w1_packed && b1 && w2_packed && w1f && w2f, "ctrlv_ff_fused_pack: null pointer");
+  const long n = (long)kChunks * (kW1Pieces + 10) * 64 * 8;
   hipLaunchKernelGGL(ff_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)w1_packed, (const bf16_t*)w2_packed, (bf16_t*)w1f, (bf16_t*)w2f);
+                     (const bf16_t*)w1_packed, b1, (const bf16_t*)w2_packed, (bf16_t*)w1f, (bf16_t*)w2f);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
 
-extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const float* b1, const void* w2f,
+extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f,
                               const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
-  CTRLV_CHECK_ARG(x && w1f && b1 && w2f && out_desc && out_desc->out, "ctrlv_ff_fused: null pointer");
+  CTRLV_CHECK_ARG(x && w1f && w2f && out_desc && out_desc->out, "ctrlv_ff_fused: null pointer");
   FfArgs a;
-  a.x = (const bf16_t*)x; a.ldx = ldx; a.w1f = (const bf16_t*)w1f; a.b1 = b1; a.w2f = (const bf16_t*)w2f;
+  a.x = (const bf16_t*)x; a.ldx = ldx; a.w1f = (const bf16_t*)w1f; a.w2f = (const bf16_t*)w2f;
   a.o = *out_desc;
   a.vtab = nullptr; a.vdiv = 1; a.vmod = 1; a.ldv = 0;
   if (a.o.vmode) {

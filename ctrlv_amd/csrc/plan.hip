@@ -351,9 +351,9 @@ struct Loader {
     TRY(linear(mod + ".net.0.proj", 8 * C, C, f.proj, true, 1));
     TRY(linear(mod + ".net.2", C_out, 4 * C, f.out));
     if (C == 320 && C_out == 320 && f.proj.n == 2560 && f.proj.k == 320 && f.out.n == 320 && f.out.k == 1280) {
-      TRY(alloc((size_t)2560 * 320 * 2, (void**)&f.w1f, false));
+      TRY(alloc((size_t)ctrlv_ff_fused_w1f_bytes(), (void**)&f.w1f, false));
       TRY(alloc((size_t)320 * 1280 * 2, (void**)&f.w2f, false));
-      TRY(ctrlv_ff_fused_pack(f.proj.w, f.out.w, f.w1f, f.w2f, st));
+      TRY(ctrlv_ff_fused_pack(f.proj.w, f.proj.b, f.out.w, f.w1f, f.w2f, st));
     }
     return CTRLV_OK;
   }
@@ -588,14 +588,14 @@ int ff_rows_per_chunk(long M, int C) {
   return (int)(((M + n - 1) / n + 255) / 256 * 256);
 }
 int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C) {
-  // C = 320, OPT-IN (CTRLV_FF_FUSED=1): one fused launch, the 4C-wide intermediate stays on chip (ff_fused.hip).  Measured
-  // equal to the two launches in the model (232.9 vs 233.3 ms per step, three alternations), so the default stays the pair.
-  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return e && atoi(e) != 0; }();
+  // C = 320: one fused launch, the 4C-wide intermediate stays on chip (ff_fused.hip): 234.5 -> 231.3 ms per step (three
+  // alternations on one device).  CTRLV_FF_FUSED=0: the two launches.
+  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
   if (fuse && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
                                              outd.R2 != nullptr)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
-    return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, proj.bias, f.w2f, &outd, c.st);
+    return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, f.w2f, &outd, c.st);
   }
   const int M = proj.M, rows = ff_rows_per_chunk(M, C);
   for (int m0 = 0; m0 < M; m0 += rows) {

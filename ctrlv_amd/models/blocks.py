@@ -136,7 +136,7 @@ def _ff_rows_per_chunk(M, C):
     return ((M + n - 1) // n + 255) // 256 * 256
 
 
-_FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ff_pair)
+_FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
 
 
 def _ff_pair(x, ffp, u, out, C, **epi):
@@ -146,7 +146,7 @@ def _ff_pair(x, ffp, u, out, C, **epi):
     wproj, bproj, wout, bout = ffp[:4]
     if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(C, 4 * C, epi.get("vmode", 0) if "V" in epi else 0,
                                                            epi.get("vdiv", 1), epi.get("s_acc", 1.0), "R1" in epi, "R2" in epi):
-        ops.ff_fused(x, ffp[4], bproj, ffp[5], out, bias=bout, **epi)
+        ops.ff_fused(x, ffp[4], ffp[5], out, bias=bout, **epi)
         return
     M = x.shape[0]
     rows = _ff_rows_per_chunk(M, C)
@@ -270,7 +270,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             w, b = packing.pack_geglu(f.net[0].proj.weight, f.net[0].proj.bias)
             w2 = packing.pack_linear(f.net[2].weight)
             if tuple(w.shape) == (2560, 320) and tuple(w2.shape) == (320, 1280) and w.is_cuda:
-                return (w, b, w2, _f32(f.net[2].bias)) + ops.ff_fused_pack(w.contiguous(), w2.contiguous())
+                return (w, b, w2, _f32(f.net[2].bias)) + ops.ff_fused_pack(w.contiguous(), b.float().contiguous(), w2.contiguous())
             return w, b, w2, _f32(f.net[2].bias)
 
         def ln(n):

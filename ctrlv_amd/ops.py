@@ -157,15 +157,18 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     return out
 
 
-def ff_fused_pack(w1_packed, w2_packed):
-    """Fragment-major copies (w1f, w2f) of a C = 320 feed-forward's packed weights for `ff_fused`:
-    w1_packed = the GEGLU projection in the interleaved packed form [2560, 320], w2_packed = the output projection [320, 1280]."""
+def ff_fused_pack(w1_packed, b1, w2_packed):
+    """Fragment-major copies (w1f, w2f) of a C = 320 feed-forward's packed weights for `ff_fused`: w1_packed = the GEGLU
+    projection in the interleaved packed form [2560, 320], b1 = its bias (fp32 [2560], same row order; carried inside w1f),
+    w2_packed = the output projection [320, 1280]."""
     _need_gpu(w1_packed, "w1_packed")
-    assert tuple(w1_packed.shape) == (2560, 320) and tuple(w2_packed.shape) == (320, 1280)
-    assert w1_packed.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16
-    assert w1_packed.is_contiguous() and w2_packed.is_contiguous()
-    w1f, w2f = torch.empty_like(w1_packed), torch.empty_like(w2_packed)
-    check(_lib.load().ctrlv_ff_fused_pack(_p(w1_packed), _p(w2_packed), _p(w1f), _p(w2f), _stream()), "ctrlv_ff_fused_pack")
+    assert tuple(w1_packed.shape) == (2560, 320) and tuple(w2_packed.shape) == (320, 1280) and b1.numel() == 2560
+    assert w1_packed.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16 and b1.dtype == torch.float32
+    assert w1_packed.is_contiguous() and w2_packed.is_contiguous() and b1.is_contiguous()
+    lib = _lib.load()
+    w1f = torch.empty(lib.ctrlv_ff_fused_w1f_bytes() // 2, dtype=torch.bfloat16, device=w1_packed.device)
+    w2f = torch.empty_like(w2_packed)
+    check(lib.ctrlv_ff_fused_pack(_p(w1_packed), _p(b1), _p(w2_packed), _p(w1f), _p(w2f), _stream()), "ctrlv_ff_fused_pack")
     return w1f, w2f
 
 
@@ -174,7 +177,7 @@ def ff_fused_serves(n, cin, vmode=0, vdiv=1, s_acc=1.0, has_r1=False, has_r2=Fal
     return bool(_lib.load().ctrlv_ff_fused_serves(n, cin, vmode, vdiv, float(s_acc), int(has_r1), int(has_r2)))
 
 
-def ff_fused(x, w1f, b1, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1,
+def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1,
              vmod=1 << 30, vS=1):
     """out = s_acc * (GEGLU(x W1^T + b1) W2^T + bias) + s1 R1 + s2 R2 + V[idx(m)] for a C = 320 feed-forward, the 4C-wide
     intermediate kept on chip (csrc/ff_fused.hip).  The epilogue operands are those of `gemm`."""
@@ -190,7 +193,7 @@ def ff_fused(x, w1f, b1, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.
     d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
     d.ldv = V.stride(0) if V is not None else 0
     ev = _prof.begin()
-    check(_lib.load().ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(b1), _p(w2f), ctypes.byref(d), _stream()),
+    check(_lib.load().ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
           "ctrlv_ff_fused")
     if ev is not None:
         M = out.shape[0]

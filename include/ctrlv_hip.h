@@ -123,13 +123,16 @@ int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float
 /* Fused feed-forward pair at C = 320:  out = epilogue( GEGLU(x . W1^T + b1) . W2^T )  with the second projection's
  * epilogue operands taken from `out_desc` (out, bias = b2, R1 / R2 / V, s_acc, s1, s2, M, N = 320, Cin = 1280, mode 0):
  * the two ctrlv_gemm launches of BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff [DIFF-0.27.2
- * attention.py FeedForward(GEGLU)] without the 4C-wide intermediate in HBM.  x: bf16 [M][ldx]; b1: fp32 [2560] in the
- * GEGLU-interleaved row order of the packed W1; w1f / w2f: the fragment-major forms written by ctrlv_ff_fused_pack from
- * the packed weights ([2560][320] interleaved, [320][1280]).  Results: same arithmetic as the two launches up to the
- * summation order of the second projection (csrc/ff_fused.hip). */
-int ctrlv_ff_fused_pack(const void* w1_packed, const void* w2_packed, void* w1f, void* w2f, ctrlv_stream_t stream);
-int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const float* b1, const void* w2f,
-                   const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream);
+ * attention.py FeedForward(GEGLU)] without the 4C-wide intermediate in HBM.  x: bf16 [M][ldx]; w1f / w2f: the
+ * fragment-major forms written by ctrlv_ff_fused_pack from the packed weights ([2560][320] in the GEGLU-interleaved row
+ * order, [320][1280]) and b1 (fp32 [2560], the same row order; it travels inside w1f as a 21st K step).  w1f holds
+ * ctrlv_ff_fused_w1f_bytes() bytes, w2f 320 * 1280 * 2.  Results: the arithmetic of the two launches up to the
+ * summation order of the second projection and 2^-17 |b1| (csrc/ff_fused.hip). */
+long ctrlv_ff_fused_w1f_bytes(void);
+int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const void* w2_packed, void* w1f, void* w2f,
+                        ctrlv_stream_t stream);
+int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f, const ctrlv_gemm_desc* out_desc,
+                   ctrlv_stream_t stream);
 /* 1 if ctrlv_ff_fused serves these settings of the second projection (N = 320, Cin = 1280; epilogue bias, +R1 or +R1+R2;
  * a row-vector operand only with vmode 1, vdiv a multiple of 256 and s_acc == 1), 0 = use the two ctrlv_gemm launches. */
 int ctrlv_ff_fused_serves(int n, int cin, int vmode, int vdiv, float s_acc, int has_r1, int has_r2);

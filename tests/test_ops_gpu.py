@@ -495,7 +495,7 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     V = torch.randn(5, C, generator=g(8))
     w1p, b1p = packing.pack_geglu(w1.to(DEV), b1.to(DEV))
     w2p = packing.pack_linear(w2.to(DEV))
-    w1f, w2f = ops.ff_fused_pack(w1p, w2p)
+    w1f, w2f = ops.ff_fused_pack(w1p, b1p.float().contiguous(), w2p)
     kw = {}
     if epi in ("r1", "r1r2", "r1v"):
         kw.update(R1=r1.to(DEV), s1=1.0)
@@ -508,7 +508,7 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
         assert not ops.ff_fused_serves(320, 1280, vmode=2, vdiv=512, has_r1=True)
     xd = x.to(DEV)
     out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ops.ff_fused(xd, w1f, b1p.float().contiguous(), w2f, out, bias=b2.to(DEV), **kw)
+    ops.ff_fused(xd, w1f, w2f, out, bias=b2.to(DEV), **kw)
     # the two launches
     u = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
     ops.gemm(xd, w1p, u, N=2 * I, cin=C, bias=b1p.float().contiguous(), geglu=1)
@@ -533,5 +533,5 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     # run-to-run: the kernel is deterministic, so any difference between repeats is a race
     for _ in range(10):
         again = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-        ops.ff_fused(xd, w1f, b1p.float().contiguous(), w2f, again, bias=b2.to(DEV), **kw)
+        ops.ff_fused(xd, w1f, w2f, again, bias=b2.to(DEV), **kw)
         assert torch.equal(again, out)

@@ -15,7 +15,7 @@ r = lambda *s: torch.randn(*s, generator=g, device=DEV)
 w1p, b1p = packing.pack_geglu(r(2 * I, C) / C ** 0.5, r(2 * I))
 w2p = packing.pack_linear(r(C, I) / I ** 0.5)
 b1, b2 = b1p.float().contiguous(), r(C)
-w1f, w2f = ops.ff_fused_pack(w1p, w2p)
+w1f, w2f = ops.ff_fused_pack(w1p, b1, w2p)
 NSET = int(os.environ.get("FF_SETS", 4))       # rotate through buffer sets far larger than the 256 MB Infinity Cache
 sets = [dict(x=r(M, C).bfloat16(), r1=r(M, C).bfloat16(), u=torch.empty(M, I, dtype=torch.bfloat16, device=DEV),
              out=torch.empty(M, C, dtype=torch.bfloat16, device=DEV)) for _ in range(NSET)]
@@ -27,7 +27,7 @@ def two(b):
 
 
 def fused(b):
-    ops.ff_fused(b["x"], w1f, b1, w2f, b["out"], bias=b2, R1=b["r1"])
+    ops.ff_fused(b["x"], w1f, w2f, b["out"], bias=b2, R1=b["r1"])
 
 
 for name, fn in (("two launches", two), ("fused", fused), ("two launches", two), ("fused", fused)):
