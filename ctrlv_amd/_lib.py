@@ -67,6 +67,8 @@ SIGNATURES = {
     "ctrlv_ff_fused_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctrlv_ff_fused_serves": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, c_int]),
     "ctrlv_ff_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),
+    "ctrlv_ff_fused_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_spatial_prescaled": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -40,6 +40,9 @@ struct FfArgs {
   const bf16_t* w1f; const bf16_t* w2f;
   ctrlv_gemm_desc o;            // the second projection's descriptor: out, bias (b2), R1, R2, scales, M, N = 320
   const float* vtab; int vdiv, vmod, ldv;   // row-vector operand V[(m / vdiv) % vmod] (vtab = nullptr: none), see below
+  // optional LayerNorm of the input rows (ln_g = nullptr: x is used as it is): x' = LN(x + lnv[(m / ln_vdiv) % ln_vmod])
+  const float* ln_g; const float* ln_b; float ln_eps;
+  const float* lnv; int ln_vdiv, ln_vmod, ln_ldv;
 };
 
 template <int EPI>
@@ -109,6 +112,59 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ok) v = *(const uint4*)(xp + ks * 16);
         *(uint4*)(xhi + (ks - 10) * 1024) = v;
+      }
+    }
+    if (a.ln_g) {
+      // LayerNorm of the rows in place (the norm3 / norm_in in front of every feed-forward: one kernel launch and one
+      // write + read of the activation less).  A row's 320 values sit in its two lanes (hsel = 0 / 1, 160 each: 80 in xr,
+      // 80 in the wave's x_hi strip); statistics about the row's first value as pilot (shifted sums: no cancellation), one
+      // lane exchange; the normalised values are rounded to bf16 like ctrlv_layernorm's output and overwrite the raw ones.
+      const float* lv = a.lnv ? a.lnv + (long)((m / a.ln_vdiv) % a.ln_vmod) * a.ln_ldv + 8 * hsel : nullptr;
+      auto raw8 = [&](int ks, float* f) {
+        const uint4 v = ks < 10 ? __builtin_bit_cast(uint4, xr[ks]) : *(const uint4*)(xhi + (ks - 10) * 1024);
+        unpack_bf16x8(v, f);
+        if (lv) {
+          const float4 p = *(const float4*)(lv + ks * 16), q = *(const float4*)(lv + ks * 16 + 4);
+          f[0] += p.x; f[1] += p.y; f[2] += p.z; f[3] += p.w; f[4] += q.x; f[5] += q.y; f[6] += q.z; f[7] += q.w;
+        }
+      };
+      float pilot;
+      {
+        float f0[8];
+        raw8(0, f0);
+        pilot = __shfl(f0[0], r32);                          // the row's column 0 (lane hsel = 0)
+      }
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 20; ++ks) {
+        float f[8];
+        raw8(ks, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dl = f[e] - pilot; sm += dl; sq += dl * dl; }
+        if (ks % 5 == 4) __builtin_amdgcn_sched_barrier(0);  // (five steps' loads in flight at a time, not all twenty)
+      }
+      sm += __shfl_xor(sm, 32);
+      sq += __shfl_xor(sq, 32);
+      const float dm = sm * (1.0f / kC);                     // mean - pilot
+      const float var = sq * (1.0f / kC) - dm * dm;
+      const float mean = pilot + dm, rstd = rsqrtf((var > 0.f ? var : 0.f) + a.ln_eps);
+      const float* gp = a.ln_g + 8 * hsel;
+      const float* bp = a.ln_b + 8 * hsel;
+#pragma unroll
+      for (int ks = 0; ks < 20; ++ks) {
+        float f[8];
+        raw8(ks, f);
+        const float4 g0 = *(const float4*)(gp + ks * 16), g1 = *(const float4*)(gp + ks * 16 + 4);
+        const float4 b0 = *(const float4*)(bp + ks * 16), b1v = *(const float4*)(bp + ks * 16 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
+        uint4 o = pack_bf16x8(f);
+        if (!(m < M)) o = make_uint4(0, 0, 0, 0);
+        if (ks < 10) xr[ks] = __builtin_bit_cast(bf16x8, o);
+        else *(uint4*)(xhi + (ks - 10) * 1024) = o;
+        if (ks % 5 == 4) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // output accumulators start from b2 -- plus the tile's row vector: V is constant over a tile (vdiv is a multiple of
@@ -244,10 +300,16 @@ extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const
   return CTRLV_OK;
 }
 
-extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f,
-                              const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
+extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                 const float* ln_V, int ln_vdiv, int ln_vmod, int ln_ldv, const void* w1f, const void* w2f,
+                                 const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && w1f && w2f && out_desc && out_desc->out, "ctrlv_ff_fused: null pointer");
+  CTRLV_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "ctrlv_ff_fused: LayerNorm needs gamma and beta");
+  CTRLV_CHECK_ARG(!ln_V || (ln_gamma && ln_vdiv > 0 && ln_vmod > 0 && ln_ldv >= 320 && ln_ldv % 4 == 0),
+                  "ctrlv_ff_fused: bad LayerNorm row-vector table");
   FfArgs a;
+  a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps;
+  a.lnv = ln_V; a.ln_vdiv = ln_V ? ln_vdiv : 1; a.ln_vmod = ln_V ? ln_vmod : 1; a.ln_ldv = ln_ldv;
   a.x = (const bf16_t*)x; a.ldx = ldx; a.w1f = (const bf16_t*)w1f; a.w2f = (const bf16_t*)w2f;
   a.o = *out_desc;
   a.vtab = nullptr; a.vdiv = 1; a.vmod = 1; a.ldv = 0;
@@ -280,6 +342,11 @@ extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const voi
   }
   ctrlv_set_error("ctrlv_ff_fused: epilogue operand combination not served (bias, +R1, +R1+R2, each with an optional V)");
   return CTRLV_E_BAD_ARG;
+}
+
+extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f,
+                              const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
+  return ctrlv_ff_fused_ln(x, ldx, nullptr, nullptr, 0.f, nullptr, 1, 1, 0, w1f, w2f, out_desc, stream);
 }
 
 // 1 if ctrlv_ff_fused serves a second-projection descriptor with these row-vector settings (the callers' switch between

@@ -614,6 +614,24 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
   return CTRLV_OK;
 }
 
+// LayerNorm -> feed-forward (blocks.py::_ln_ff).  OPT-IN (CTRLV_FF_LN=1): the norm folded into the fused kernel's tile
+// prologue (ctrlv_ff_fused_ln: one launch and one write + read of the activation less).  Measured equal in the model
+// (224.2 vs 224.2 and 230.3 vs 230.4 ms per step, three alternations each: the LayerNorm family drops 7.9 -> 5.3 ms, the
+// fused kernel's per-tile prologue takes it back), so the default keeps ctrlv_layernorm in front of the fused kernel.
+int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const bf16_t* xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
+          bf16_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C) {
+  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
+  static const bool fold = [] { const char* e = getenv("CTRLV_FF_LN"); return e && atoi(e) != 0; }();
+  if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
+                                                     outd.R2 != nullptr)) {
+    if (c.dry) return CTRLV_OK;
+    if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    return ctrlv_ff_fused_ln(xraw, C, nm.g, nm.b, 1e-5f, lnV, lnvdiv, lnvmod, lnldv, f.w1f, f.w2f, &outd, c.st);
+  }
+  TRY(layernorm(c, xraw, proj.M, C, nm, tt, lnV, lnvdiv, lnvmod, lnldv));
+  return ff_pair(c, f, proj, outd, C);
+}
+
 // ---- TransformerSpatioTemporalModel (blocks.py::TransformerSpatioTemporalModel.run)
 int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t** out_) {
   const int B = c.B, F = c.F, C = t.C, N = B * F, S = H * W;
@@ -647,7 +665,6 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     d.V = c.xattn + t.xattn_off[0]; d.ldv = c.ldx; d.vmode = 1; d.vdiv = F * S;
     TRY(gemm(c, d));
   }
-  TRY(layernorm(c, h1, (int)M, C, t.s_ln3, tt));
   bf16_t* u = c.rows(M, 4 * C);
   bf16_t* h2 = h0;      // h0 is dead from here on
   {
@@ -655,10 +672,9 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
     d.R1 = h1; d.ldr1 = C;
-    TRY(ff_pair(c, t.s_ff, dp, d, C));
+    TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
-  TRY(layernorm(c, h2, (int)M, C, t.t_lnin, tt, emb, S, F, C));
   bf16_t* g0 = h1;      // h1 is dead
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
@@ -666,7 +682,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0, C, (int)M, C, 4 * C, C);
     d.R1 = h2; d.ldr1 = C;
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
-    TRY(ff_pair(c, t.t_ffin, dp, d, C));
+    TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C));
   }
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
@@ -680,7 +696,6 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     else d.vmode = 1;
     TRY(gemm(c, d));
   }
-  TRY(layernorm(c, g1, (int)M, C, t.t_ln3, tt));
   bf16_t* h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
@@ -688,7 +703,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
     d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
     d.s2 = (float)t.alpha;
-    TRY(ff_pair(c, t.t_ff, dp, d, C));
+    TRY(ln_ff(c, t.t_ff, t.t_ln3, g1, nullptr, 1, 1 << 30, 0, tt, dp, d, C));
   }
   {
     ctrlv_gemm_desc d = gd(h3, C, t.pout, out, C, (int)M, C, C, C);

@@ -157,6 +157,25 @@ def _ff_pair(x, ffp, u, out, C, **epi):
         ops.gemm(u[m0:m1], wout, out[m0:m1], N=C, cin=4 * C, bias=bout, **kw)
 
 
+_FF_LN = os.environ.get("CTRLV_FF_LN", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ln_ff)
+
+
+def _ln_ff(xraw, ln, t, ffp, u, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, **epi):
+    """out = epilogue(FF(LayerNorm(xraw + ln_V))): with the fused kernel the norm is folded into its prologue, else
+    ops.layernorm into `t` followed by _ff_pair (csrc/plan.hip ln_ff)."""
+    if _FF_FUSED and _FF_LN and len(ffp) == 6 and ops.ff_fused_serves(C, 4 * C, epi.get("vmode", 0) if "V" in epi else 0,
+                                                                      epi.get("vdiv", 1), epi.get("s_acc", 1.0), "R1" in epi,
+                                                                      "R2" in epi):
+        ops.ff_fused(xraw, ffp[4], ffp[5], out, bias=ffp[3], ln=(ln[0], ln[1], 1e-5), ln_V=ln_V, ln_vdiv=ln_vdiv,
+                     ln_vmod=ln_vmod, **epi)
+        return
+    if ln_V is not None:
+        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, V=ln_V, vdiv=ln_vdiv, vmod=ln_vmod)
+    else:
+        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t)
+    _ff_pair(t, ffp, u, out, C, **epi)
+
+
 def _gn_scratch(ctx, n_img, S, C, ips):
     need = ops.groupnorm_scratch_floats(n_img, S, C, ips)
     if ctx.gn_part is None or ctx.gn_part.numel() < need:
@@ -338,14 +357,13 @@ class TransformerSpatioTemporalModel(nn.Module):
         h1 = ws.alloc((M, C))
         xs_vec = ctx.xattn[:, self.xattn_off[0]:]      # attn2 with one key == to_out(to_v(ehs[b])) for every query
         ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)
-        ops.layernorm(h1, pk["s_ln3"][0], pk["s_ln3"][1], 1e-5, t)
         u = ws.alloc((M, 4 * C))
         h2 = h0                                         # h0 is dead from here on
-        _ff_pair(t, pk["s_ff"], u, h2, C, R1=h1)
+        _ln_ff(h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, R1=h1)
         # ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
-        ops.layernorm(h2, pk["t_lnin"][0], pk["t_lnin"][1], 1e-5, t, V=emb, vdiv=S, vmod=F)
         g0 = h1                                         # h1 is dead
-        _ff_pair(t, pk["t_ffin"], u, g0, C, R1=h2, V=emb, vmode=1, vdiv=S, vmod=F)
+        _ln_ff(h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, R1=h2, V=emb, vmode=1, vdiv=S,
+               vmod=F)
         ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
         ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
         ops.attention_temporal(qkv, a, B, F, S, C)
@@ -356,11 +374,10 @@ class TransformerSpatioTemporalModel(nn.Module):
                      vmod=B)
         else:
             ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, vmode=1, vdiv=F * S)
-        ops.layernorm(g1, pk["t_ln3"][0], pk["t_ln3"][1], 1e-5, t)
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
-        _ff_pair(t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
+        _ln_ff(g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
         if ctx.trace is not None:

@@ -178,7 +178,7 @@ def ff_fused_serves(n, cin, vmode=0, vdiv=1, s_acc=1.0, has_r1=False, has_r2=Fal
 
 
 def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1,
-             vmod=1 << 30, vS=1):
+             vmod=1 << 30, vS=1, ln=None, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30):
     """out = s_acc * (GEGLU(x W1^T + b1) W2^T + bias) + s1 R1 + s2 R2 + V[idx(m)] for a C = 320 feed-forward, the 4C-wide
     intermediate kept on chip (csrc/ff_fused.hip).  The epilogue operands are those of `gemm`."""
     _need_gpu(x, "x")
@@ -193,8 +193,13 @@ def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s
     d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
     d.ldv = V.stride(0) if V is not None else 0
     ev = _prof.begin()
-    check(_lib.load().ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
-          "ctrlv_ff_fused")
+    if ln is None:        # ln = (gamma, beta, eps): the LayerNorm in front of the feed-forward, folded into the kernel
+        check(_lib.load().ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
+              "ctrlv_ff_fused")
+    else:
+        check(_lib.load().ctrlv_ff_fused_ln(_p(x), x.stride(0), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln_V), ln_vdiv,
+                                            ln_vmod, ln_V.stride(0) if ln_V is not None else 0, _p(w1f), _p(w2f),
+                                            ctypes.byref(d), _stream()), "ctrlv_ff_fused_ln")
     if ev is not None:
         M = out.shape[0]
         nbytes = M * 320 * 2 * (2 + (R1 is not None) + (R2 is not None))

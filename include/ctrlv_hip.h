@@ -133,6 +133,12 @@ int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const void* w2_p
                         ctrlv_stream_t stream);
 int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f, const ctrlv_gemm_desc* out_desc,
                    ctrlv_stream_t stream);
+/* The same with the LayerNorm in front of the feed-forward folded in (norm3 / norm_in of the transformer blocks):
+ * the kernel's input rows are x' = LayerNorm(x + ln_V[(m / ln_vdiv) % ln_vmod]) * gamma + beta, rounded to bf16 like
+ * ctrlv_layernorm's output (ln_V may be null; ln_gamma = null: no LayerNorm, = ctrlv_ff_fused). */
+int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                      const float* ln_V, int ln_vdiv, int ln_vmod, int ln_ldv, const void* w1f, const void* w2f,
+                      const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream);
 /* 1 if ctrlv_ff_fused serves these settings of the second projection (N = 320, Cin = 1280; epilogue bias, +R1 or +R1+R2;
  * a row-vector operand only with vmode 1, vdiv a multiple of 256 and s_acc == 1), 0 = use the two ctrlv_gemm launches. */
 int ctrlv_ff_fused_serves(int n, int cin, int vmode, int vdiv, float s_acc, int has_r1, int has_r2);

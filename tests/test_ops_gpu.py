@@ -535,3 +535,36 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
         again = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         ops.ff_fused(xd, w1f, w2f, again, bias=b2.to(DEV), **kw)
         assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("M,with_v", [(777, False), (256 * 9, True)])
+def test_ff_fused_with_the_layernorm_folded_in(ops, M, with_v):
+    """ctrlv_ff_fused_ln: LayerNorm(x + V) in the kernel's prologue == ctrlv_layernorm followed by ctrlv_ff_fused (the
+    normalised rows are rounded to bf16 in both; statistics differ in summation order only)."""
+    from ctrlv_amd import packing
+    C, I = 320, 1280
+    w1 = torch.randn(2 * I, C, generator=g(1)) / C ** 0.5
+    b1 = torch.randn(2 * I, generator=g(2)) * 0.5
+    w2 = torch.randn(C, I, generator=g(3)) / I ** 0.5
+    b2 = torch.randn(C, generator=g(4))
+    x = bf(torch.randn(M, C, generator=g(5)) * 2.0 + 0.7).to(DEV)          # rows with a mean
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g(6))).to(DEV), (0.3 * torch.randn(C, generator=g(7))).to(DEV)
+    V = torch.randn(3, C, generator=g(8)).to(DEV) if with_v else None
+    w1p, b1p = packing.pack_geglu(w1.to(DEV), b1.to(DEV))
+    w2p = packing.pack_linear(w2.to(DEV))
+    w1f, w2f = ops.ff_fused_pack(w1p, b1p.float().contiguous(), w2p)
+    lnkw = dict(V=V, vdiv=768, vmod=3) if with_v else {}
+    xn = torch.empty_like(x)
+    ops.layernorm(x, gamma, beta, 1e-5, xn, **lnkw)
+    ref = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.ff_fused(xn, w1f, w2f, ref, bias=b2.to(DEV), R1=x)
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    fkw = dict(ln_V=V, ln_vdiv=768, ln_vmod=3) if with_v else {}
+    ops.ff_fused(x, w1f, w2f, out, bias=b2.to(DEV), R1=x, ln=(gamma, beta, 1e-5), **fkw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert parity_err(out, ref.float().cpu()) < 3e-3
+    for _ in range(5):
+        again = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.ff_fused(x, w1f, w2f, again, bias=b2.to(DEV), R1=x, ln=(gamma, beta, 1e-5), **fkw)
+        assert torch.equal(again, out)
