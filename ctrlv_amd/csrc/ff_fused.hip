@@ -288,7 +288,7 @@ int launch_ff(const FfArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" long ctrlv_ff_fused_w1f_bytes(void) { return (long)kChunks * kW1Slot; }
+extern "C" int ctrlv_ff_fused_w1f_bytes(void) { return kChunks * kW1Slot; }
 
 extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const void* w2_packed, void* w1f, void* w2f,
                                    ctrlv_stream_t stream) {

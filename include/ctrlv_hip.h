@@ -128,7 +128,7 @@ int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float
  * order, [320][1280]) and b1 (fp32 [2560], the same row order; it travels inside w1f as a 21st K step).  w1f holds
  * ctrlv_ff_fused_w1f_bytes() bytes, w2f 320 * 1280 * 2.  Results: the arithmetic of the two launches up to the
  * summation order of the second projection and 2^-17 |b1| (csrc/ff_fused.hip). */
-long ctrlv_ff_fused_w1f_bytes(void);
+int ctrlv_ff_fused_w1f_bytes(void);
 int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const void* w2_packed, void* w1f, void* w2f,
                         ctrlv_stream_t stream);
 int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f, const ctrlv_gemm_desc* out_desc,
