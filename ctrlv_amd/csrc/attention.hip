@@ -298,6 +298,17 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 // slots) is gone.  m only changes on the slow path (see attn_spatial_kernel), which rewrites the 16 registers.
 // The other experiments of round 2 (skewed row blocks, anti-phase start delay, one wave per SIMD) are recorded in
 // DESIGN.md section 8 and tools/experiments/.
+// K / V ring of the 64-row kernel: kNS64 slots of (K 8 KiB | V 8 KiB), kNS64 - 1 tiles in flight.  Alone (K / V out of
+// the Infinity Cache) two slots were enough; inside the model they come from HBM beside the other stream's traffic and
+// one tile of 64 keys (~0.7 us of compute) no longer covers the latency.  A/B handle: -DCTRLV_ATTN_SLOTS=2.
+#ifndef CTRLV_ATTN_SLOTS
+#define CTRLV_ATTN_SLOTS 4
+#endif
+constexpr int kNS64 = CTRLV_ATTN_SLOTS;
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+static_assert(kNS64 >= 2 && kNS64 <= 4, "2 workgroups per CU: at most 4 x 16 KiB per workgroup");
+
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               float* __restrict__ lse, int S, int C) {
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
     return (r0 + r1) + (r2 + r3);
   };
   auto tile = [&](int t, auto masked_tag) {
-    const char* kst = smem + (t & 1) * 16384;
+    const char* kst = smem + (t % kNS64) * 16384;
     const char* vst = kst + 8192;
     bf16x8 pf[2][2][2];       // [row block][32-key half][16-key step]
     float rs[2];
@@ -503,18 +514,22 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
 
   const int nt = (S + 63) / 64;
   const int nt_full = S / 64;
-  issue(0, 0);
+  // kNS64 - 1 tiles in flight.  Every wave issues exactly four pieces per tile -- past the last tile too (all lanes out
+  // of range: zeros into a free slot, no memory traffic) -- so the counted wait is the same at every iteration.
+#pragma unroll
+  for (int p = 0; p < kNS64 - 1; ++p) issue(p, p);
   for (int t = 0; t < nt_full; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm<4 * (kNS64 - 2)>();
     asm volatile("s_barrier" ::: "memory");
-    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    issue(t + kNS64 - 1, (t + kNS64 - 1) % kNS64);
     tile(t, std::false_type{});
   }
   if (nt_full < nt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm<4 * (kNS64 - 2)>();
     asm volatile("s_barrier" ::: "memory");
     tile(nt_full, std::true_type{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead pieces: nothing in flight at exit
 
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
@@ -667,9 +682,9 @@ static int attention_spatial_launch(const void* qkv, void* out, float* lse, int 
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
     if (pre)
-      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kNS64 * 16384, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
     else
-      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kNS64 * 16384, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
