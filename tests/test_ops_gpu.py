@@ -568,3 +568,40 @@ def test_ff_fused_with_the_layernorm_folded_in(ops, M, with_v):
         again = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         ops.ff_fused(x, w1f, w2f, again, bias=b2.to(DEV), R1=x, ln=(gamma, beta, 1e-5), **fkw)
         assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("epi", ["r1", "r1r2", "r1v"])
+def test_ff_fused_full_size_is_stable_run_to_run(ops, epi):
+    """The fused feed-forward at the benchmark's own size (M = 50 x 9216 rows: 1800 tiles, 8 per workgroup) against the two
+    launches, and 12 repeats bit for bit (a race between the wave groups, the LDS rings or the epilogue's staging would
+    show as a difference between runs: the kernel has no atomics)."""
+    from ctrlv_amd import packing
+    C, I, M = 320, 1280, 50 * 9216
+    gd = torch.Generator(device=DEV).manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=gd, device=DEV)
+    w1p, b1p = packing.pack_geglu(r(2 * I, C) / C ** 0.5, r(2 * I) * 0.5)
+    w2p = packing.pack_linear(r(C, I) / I ** 0.5)
+    b1, b2 = b1p.float().contiguous(), r(C)
+    w1f, w2f = ops.ff_fused_pack(w1p, b1, w2p)
+    x, r1 = r(M, C).bfloat16(), r(M, C).bfloat16()
+    kw = dict(R1=r1)
+    if epi == "r1r2":
+        kw.update(R2=r(M, C).bfloat16(), s2=0.25, s_acc=0.75, s1=0.75)
+    if epi == "r1v":
+        kw.update(V=r(25, C), vmode=1, vdiv=9216, vmod=25)
+    u = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ref = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, w1p, u, N=2 * I, cin=C, bias=b1, geglu=1)
+    ops.gemm(u, w2p, ref, N=C, cin=I, bias=b2, **kw)
+    del u
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.ff_fused(x, w1f, w2f, out, bias=b2, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    d = (out.float() - ref.float()).abs()
+    assert float(d.max()) < 0.13 and float(d.mean()) < 4e-3          # bf16 outputs of magnitude ~2-4: a few ulps apart at most
+    again = torch.empty_like(out)
+    for _ in range(12):
+        again.fill_(float("nan"))
+        ops.ff_fused(x, w1f, w2f, again, bias=b2, **kw)
+        assert torch.equal(again, out)
