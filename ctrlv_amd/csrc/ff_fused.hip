@@ -60,14 +60,17 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
 
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1f, 0, kChunks * kW1Slot, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2f, 0, kChunks * kW2Slot, 0x00020000);
-  // this wave's pieces of a chunk: KiB number k * 8 + wid (k = 0..3) of the chunk's 31 (21 of W1, then 10 of W2);
-  // `cg` = the workgroup's running chunk count (ring phase), `chunk` = which of the 80 chunks of the weights
+  // The 31 KiB pieces of a chunk (21 of W1, then 10 of W2) are all issued by waves 0-3 (piece k * 4 + wid, k = 0..7): by
+  // the stamps (tools/ff_stamp.py) that group reached every window boundary ~900 cycles before waves 4-7 and waited at
+  // the barrier, while waves 4-7 -- the arbitration losers of their SIMDs -- spent 540 cycles issuing their four pieces
+  // right behind it (waves 0-3: 230).  `cg` = the workgroup's running chunk count (ring phase), `chunk` = which of the 80.
   auto dma = [&](int chunk, int cg) {
+    if (wid >= 4) return;                                    // (wave-uniform)
     char* s1 = smem + kW1Off + (cg & 1) * kW1Slot;
     char* s2 = smem + kW2Off + (cg % 3) * kW2Slot;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int pi = k * 8 + wid;                            // wave-uniform
+    for (int k = 0; k < 8; ++k) {
+      const int pi = k * 4 + wid;
       if (pi < kW1Pieces)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, LDS_PTR(s1 + pi * 1024), 16, lane * 16, chunk * kW1Slot + pi * 1024, 0, 0);
       else if (pi < kW1Pieces + 10)
@@ -189,12 +192,29 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
     // group 1 between GEGLU and GEMM 2.  Ring safety: after boundary k the W1 slot of chunk k + 2 was last read by GEMM 1
     // of chunk k (both groups: before their boundary k), its W2 slot by group 1's GEMM 2 of chunk k - 1 (between its
     // boundaries k - 1 and k).  x_hi, the staging and the accumulators are wave-private: a new tile needs no barrier.
+#ifdef CTRLV_FF_STAMP      // diagnostic build (tools/ff_stamp.py): cycles per phase, summed per wave, written to a.lnv
+#define FSTAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+    unsigned long long st_g1 = 0, st_ge = 0, st_b = 0, st_g2 = 0;
+#else
+#define FSTAMP(v)
+#endif
+#ifdef CTRLV_FF_STAMP
+    unsigned long long st_w = 0, st_bar = 0, st_dma = 0;
+#endif
     auto boundary = [&](int c) {
+      FSTAMP(b0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      FSTAMP(b1);
       __syncthreads();
+      FSTAMP(b2);
       dma((c + 2) % kChunks, cglob + 2);
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(b3);
+      st_w += b1 - b0; st_bar += b2 - b1; st_dma += b3 - b2;
+#endif
     };
     for (int c = 0; c < kChunks; ++c, ++cglob) {
+      FSTAMP(t0);
       const char* s1 = smem + kW1Off + (cglob & 1) * kW1Slot + lane * 16;
       f32x16 a1;
 #pragma unroll
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, a1, 0, 0, 0);
       }
       a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(s1 + 20 * 1024), xone, a1, 0, 0, 0);   // + bias
+      FSTAMP(t1);
       // GEGLU in the result layout: accumulators 0..7 are the 8 value columns of this lane, 8..15 their gates
       float h[8];
 #pragma unroll
@@ -213,15 +234,29 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       const uint4 hp = make_uint4(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]),
                                   pack_bf16x2(h[6], h[7]));
       const bf16x8 hf = __builtin_bit_cast(bf16x8, hp);
+      FSTAMP(t2);
       if (grp == 1) boundary(c);
+      FSTAMP(t3);
       const char* s2 = smem + kW2Off + (cglob % 3) * kW2Slot + lane * 16;
 #pragma unroll
       for (int n = 0; n < 10; ++n) {
         const bf16x8 wf = *(const bf16x8*)(s2 + n * 1024);
         acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc[0][n], 0, 0, 0);
       }
+      FSTAMP(t4);
       if (grp == 0) boundary(c);
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(t5);
+      st_g1 += t1 - t0; st_ge += t2 - t1; st_b += (t3 - t2) + (t5 - t4); st_g2 += t4 - t3;
+#endif
     }
+#ifdef CTRLV_FF_STAMP
+    if (lane == 0 && a.lnv) {
+      unsigned long long* o = (unsigned long long*)a.lnv + ((long)blockIdx.x * 8 + wid) * 4;
+      o[0] += st_g1; o[1] += st_w; o[2] += st_bar; o[3] += st_dma;      // (variant: the boundary split up)
+      (void)st_ge; (void)st_b; (void)st_g2;
+    }
+#endif
     // (x fragments are dead here: end their live ranges so that the epilogue's prefetch window gets their registers)
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) asm volatile("" : "=v"(xr[ks]));
@@ -305,8 +340,10 @@ extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, 
                                  const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && w1f && w2f && out_desc && out_desc->out, "ctrlv_ff_fused: null pointer");
   CTRLV_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "ctrlv_ff_fused: LayerNorm needs gamma and beta");
+#ifndef CTRLV_FF_STAMP        // (the stamped diagnostic build receives its output buffer through ln_V)
   CTRLV_CHECK_ARG(!ln_V || (ln_gamma && ln_vdiv > 0 && ln_vmod > 0 && ln_ldv >= 320 && ln_ldv % 4 == 0),
                   "ctrlv_ff_fused: bad LayerNorm row-vector table");
+#endif
   FfArgs a;
   a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps;
   a.lnv = ln_V; a.ln_vdiv = ln_V ? ln_vdiv : 1; a.ln_vmod = ln_V ? ln_vmod : 1; a.ln_ldv = ln_ldv;
