@@ -17,17 +17,18 @@ w2p = packing.pack_linear(r(C, I) / I ** 0.5)
 b1, b2 = b1p.float().contiguous(), r(C)
 w1f, w2f = ops.ff_fused_pack(w1p, b1, w2p)
 NSET = int(os.environ.get("FF_SETS", 4))       # rotate through buffer sets far larger than the 256 MB Infinity Cache
-sets = [dict(x=r(M, C).bfloat16(), r1=r(M, C).bfloat16(), u=torch.empty(M, I, dtype=torch.bfloat16, device=DEV),
+R2 = os.environ.get("FF_R2", "0") == "1"           # the AlphaBlender variant: + s2 * R2
+sets = [dict(x=r(M, C).bfloat16(), r1=r(M, C).bfloat16(), r2=r(M, C).bfloat16(), u=torch.empty(M, I, dtype=torch.bfloat16, device=DEV),
              out=torch.empty(M, C, dtype=torch.bfloat16, device=DEV)) for _ in range(NSET)]
 
 
 def two(b):
     ops.gemm(b["x"], w1p, b["u"], N=2 * I, cin=C, bias=b1, geglu=1)
-    ops.gemm(b["u"], w2p, b["out"], N=C, cin=I, bias=b2, R1=b["r1"])
+    ops.gemm(b["u"], w2p, b["out"], N=C, cin=I, bias=b2, R1=b["r1"], **(dict(R2=b["r2"], s2=0.5, s_acc=0.5, s1=0.5) if R2 else {}))
 
 
 def fused(b):
-    ops.ff_fused(b["x"], w1f, w2f, b["out"], bias=b2, R1=b["r1"])
+    ops.ff_fused(b["x"], w1f, w2f, b["out"], bias=b2, R1=b["r1"], **(dict(R2=b["r2"], s2=0.5, s_acc=0.5, s1=0.5) if R2 else {}))
 
 
 for name, fn in (("two launches", two), ("fused", fused), ("two launches", two), ("fused", fused)):
