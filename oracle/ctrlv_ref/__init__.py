@@ -5,7 +5,7 @@ CPU (plain PyTorch) restatement of the reference's denoising hot path.  Only `te
 (`ctrlv_amd`) never does.  See blocks.py for the provenance statement.
 """
 from .blocks import *            # noqa: F401,F403
-from .blocks import storage_rounding, store  # noqa: F401
+from .blocks import storage_rounding, store, store_absmax  # noqa: F401
 from .models import (SVD_CONFIG, TINY_CONFIG, ControlNetModel, UNetSpatioTemporalConditionModel,  # noqa: F401
                      seeded_init_, zero_module)
 from .scheduler import (SVD_SCHEDULER_CONFIG, EulerDiscreteScheduler, guidance_scale_tensor,  # noqa: F401

@@ -35,6 +35,7 @@ from torch import nn
 # the temb / frame-embedding / cross-attention row vectors) are therefore rounded once, after the fused sum.
 _STORE_DTYPE = [None]
 _TRUNK_DTYPE = ["same"]
+_STORE_ABSMAX = [None]      # [max |x| over every store() seen] while `store_absmax()` is active (fp16 overflow headroom)
 
 
 def store(x, trunk=False):
@@ -42,7 +43,21 @@ def store(x, trunk=False):
     branch is added back into); `storage_rounding(dtype, trunk_dtype=...)` can give it its own storage precision
     (tests/trunk_precision_study.py: what an fp32 residual trunk under bf16 branches would buy)."""
     dt = _TRUNK_DTYPE[0] if (trunk and _TRUNK_DTYPE[0] != "same") else _STORE_DTYPE[0]
+    if _STORE_ABSMAX[0] is not None:
+        _STORE_ABSMAX[0].append(float(x.detach().abs().max()))
     return x if dt is None else x.to(dt).to(x.dtype)
+
+
+@contextlib.contextmanager
+def store_absmax():
+    """Collects max |x| of every tensor that passes a store() mark (the values the HIP path writes to HBM): the headroom
+    of an fp16 activation-storage build against 65 504 (tests/trunk_precision_study.py)."""
+    prev = _STORE_ABSMAX[0]
+    _STORE_ABSMAX[0] = log = []
+    try:
+        yield log
+    finally:
+        _STORE_ABSMAX[0] = prev
 
 
 @contextlib.contextmanager

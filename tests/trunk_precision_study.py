@@ -9,7 +9,11 @@ tagged `trunk=True`.  This script runs the ControlNet -> UNet pair of the oracle
   bf16 everywhere         every store rounded to bf16 (what the HIP path does; this realisation's error ~ the HIP error),
   fp32 trunk              trunk stores kept in fp32, every branch store (norm outputs, conv1 / q / k / v / attention / GEGLU
                           intermediates, ControlNet residual outputs across the API) rounded to bf16,
-and prints the model-level relative L2 errors.  usage: python tests/trunk_precision_study.py [--full]
+  fp16 everywhere / fp32 trunk + fp16 branches   the same two with fp16 (the reference's own autocast dtype,
+                          config/a100l.yaml:9) -- what the fp16 activation-storage build of the
+                          inference kernels realises,
+and prints the model-level relative L2 errors and the largest |value| that passes any storage point (fp16 overflows at
+65 504).  usage: python tests/trunk_precision_study.py [--full]
 (--full: SVD widths at 2 frames x 32 x 32, ~1 minute; default: tiny config)"""
 import argparse
 import os
@@ -53,10 +57,18 @@ def main():
             all16 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
         with R.storage_rounding(torch.bfloat16, trunk_dtype=None):
             trunk32 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
+        with R.storage_rounding(torch.float16), R.store_absmax() as amax:
+            h16 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
+        with R.storage_rounding(torch.float16, trunk_dtype=None):
+            h16t = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
         print(f"{name}")
         for key in ("unet", "mid"):
             print(f"  {key:5s}  bf16 everywhere {rel_l2(all16[key], ref[key]):.3e}   fp32 trunk + bf16 branches "
-                  f"{rel_l2(trunk32[key], ref[key]):.3e}")
+                  f"{rel_l2(trunk32[key], ref[key]):.3e}   fp16 everywhere {rel_l2(h16[key], ref[key]):.3e}   "
+                  f"fp32 trunk + fp16 branches {rel_l2(h16t[key], ref[key]):.3e}")
+        srt = sorted(amax)
+        print(f"  max |value| over the {len(amax)} storage points of the fp16 run: {srt[-1]:.1f} (median {srt[len(srt) // 2]:.2f}, "
+              f"smallest per-tensor max {srt[0]:.3g}); fp16 max 65504")
 
 
 if __name__ == "__main__":
