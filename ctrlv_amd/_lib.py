@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libctrlv_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libctrlv_hip.so")            # element type bf16
+LIB_PATH_F16 = os.path.join(_HERE, "lib", "libctrlv_hip_f16.so")     # element type fp16 (same sources, -DCTRLV_ELEM_F16)
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 
@@ -52,6 +53,7 @@ class TensorDesc(ctypes.Structure):
 # name -> (restype, argtypes); lists every symbol include/ctrlv_hip.h declares (tests/test_abi.py checks this)
 SIGNATURES = {
     "ctrlv_abi_version": (c_int, []),
+    "ctrlv_elem_dtype": (c_int, []),
     "ctrlv_build_id": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
@@ -117,8 +119,8 @@ SIGNATURES = {
     "ctrlv_plan_destroy": (c_int, [c_void_p]),
 }
 
-_lib = None
-ABI_VERSION = 14
+_libs = {}                # element dtype code (2 bf16 / 1 fp16) -> CDLL
+ABI_VERSION = 15
 
 
 class CtrlvHipError(RuntimeError):
@@ -148,12 +150,30 @@ def build_id(lib=None):
     return buf.value.decode()
 
 
-def load():
-    """Load libctrlv_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("CTRLV_HIP_LIB", LIB_PATH)      # developer override: A/B builds of the same ABI (tools/)
+def elem_code(dtype=None):
+    """Element-type code of the library that serves activations of `dtype` (a torch dtype, a code, or None = bf16)."""
+    if dtype is None or dtype == 2:
+        return 2
+    if dtype == 1:
+        return 1
+    name = str(dtype)
+    if name == "torch.float16":
+        return 1
+    if name == "torch.bfloat16":
+        return 2
+    raise CtrlvHipError(f"ctrlv_amd: activations are stored as bf16 or fp16, not {dtype}")
+
+
+def load(dtype=None):
+    """Load the library whose ELEMENT type is `dtype` (torch.bfloat16 -- the default -- or torch.float16), once each.
+    Raises if it has not been built -- there is no fallback path."""
+    code = elem_code(dtype)
+    lib = _libs.get(code)
+    if lib is not None:
+        return lib
+    # developer override: A/B builds of the same ABI (tools/); CTRLV_HIP_LIB replaces the bf16 library, _F16 the fp16 one
+    env = "CTRLV_HIP_LIB" if code == 2 else "CTRLV_HIP_LIB_F16"
+    path = os.environ.get(env, LIB_PATH if code == 2 else LIB_PATH_F16)
     if not os.path.exists(path):
         raise CtrlvHipError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -164,20 +184,31 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.ctrlv_abi_version() != ABI_VERSION:
         raise CtrlvHipError(f"{path}: ABI version {lib.ctrlv_abi_version()}, this host layer needs {ABI_VERSION}")
+    if lib.ctrlv_elem_dtype() != code:
+        raise CtrlvHipError(f"{path}: element dtype code {lib.ctrlv_elem_dtype()}, expected {code}")
     # a shipped .so must come from the sources it sits next to (it is git-ignored and travels prebuilt); variant
     # libraries selected through CTRLV_HIP_LIB (tools/ab_build.py A/B builds) are exempt
     want = source_build_id()
-    if want is not None and "CTRLV_HIP_LIB" not in os.environ and build_id(lib) != want:
+    if want is not None and env not in os.environ and build_id(lib) != want:
         raise CtrlvHipError(f"{path} is stale: built from sources {build_id(lib)}, tree is {want}; rebuild with "
                             "`python -c 'import __graft_entry__ as g; g.build()'`")
-    _lib = lib
+    _libs[code] = lib
     return lib
 
 
-def last_error():
+def last_error(lib=None):
+    """Message of the last failing call of this thread (the libraries keep separate texts: the newest non-empty one of
+    the loaded libraries is returned when `lib` is not given -- a failing call always sets its own)."""
     buf = ctypes.create_string_buffer(512)
-    load().ctrlv_last_error(buf, 512)
-    return buf.value.decode("utf-8", "replace")
+    if lib is not None:
+        lib.ctrlv_last_error(buf, 512)
+        return buf.value.decode("utf-8", "replace")
+    msgs = []
+    for l in (_libs.values() or [load()]):
+        l.ctrlv_last_error(buf, 512)
+        if buf.value:
+            msgs.append(buf.value.decode("utf-8", "replace"))
+    return " | ".join(msgs)
 
 
 def check(rc, what):

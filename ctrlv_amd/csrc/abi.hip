@@ -1,4 +1,4 @@
-// ABI basics of libctrlv_hip.so: version, build id, thread-local error text, per-device property cache.
+// ABI basics of libctrlv_hip.so / libctrlv_hip_f16.so: version, build id, thread-local error text, per-device property cache.
 #include <stdarg.h>
 
 #include <mutex>
@@ -43,7 +43,8 @@ extern "C" int ctrlv_last_error(char* buf, size_t n) {
   return (int)strlen(g_err);
 }
 
-extern "C" int ctrlv_abi_version(void) { return 14; }
+extern "C" int ctrlv_abi_version(void) { return 15; }
+extern "C" int ctrlv_elem_dtype(void) { return CTRLV_ELEM_DTYPE; }
 
 // sha256 prefix of ctrlv_amd/csrc/* + include/*.h at build time (stamped by __graft_entry__.build()): the host layer
 // refuses a library whose id differs from the sources next to it.

@@ -35,12 +35,12 @@ __device__ __forceinline__ float half_sum(float v) {
 
 // V^T fragment (A operand of O^T += V^T.P) for 16 keys starting at `kbase` (+4 for the upper half-wave, folded
 // into voff by the caller) and 32 d-columns: two transposed 4x16 block reads.
-__device__ __forceinline__ bf16x8 vt_frag(const char* vt, int voff_lo, int voff_hi) {
+__device__ __forceinline__ elx8 vt_frag(const char* vt, int voff_lo, int voff_hi) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + voff_lo));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + voff_hi));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(elx8, v);
 }
 
 // byte offset inside a row-major [keys][64] bf16 V tile (128-B rows) of (key, d) with the tr-read swizzle:
@@ -54,16 +54,16 @@ __device__ __forceinline__ int v_off(int key, int d) {
 // MFMA and copies C into D first (16 v_mov_b64 per 64-key tile when C is the kept -m block of attn_spatial64_kernel),
 // so this one instruction is written out.  Hazards: A / B / C are not written inside the statement; the consumer of D is
 // the next MFMA of the same accumulation chain (C operand, same registers: no wait states needed).
-__device__ __forceinline__ f32x16 mfma_keep_c(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+__device__ __forceinline__ f32x16 mfma_keep_c(const elx8& a, const elx8& b, const f32x16& c) {
   f32x16 d;
-  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  asm(CTRLV_MFMA_32x32x16_ASM " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 
-__device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
-  bf16x8 r;
+__device__ __forceinline__ elx8 pack_p(const f32x16& p, int s) {
+  elx8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)p[8 * s + j];
+  for (int j = 0; j < 8; ++j) r[j] = (el_native_t)p[8 * s + j];
   return r;
 }
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x16& p, int s) {
 // default budget it parks them in AGPRs and spends 159 v_accvgpr_read/write per 64-key tile to feed the softmax VALU.
 // PRE: q arrives pre-scaled by (1/8) log2(e) (see attn_spatial64_kernel); here that only changes the constant.
 template <int NSLOT, bool PRE>
-__global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(const el_t* __restrict__ qkv, el_t* __restrict__ out,
                                                            float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 3 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
@@ -81,16 +81,16 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   const int head = blockIdx.y, img = blockIdx.z;
   const long row0 = (long)img * S;
   const int ld = 3 * C;
-  const bf16_t* qp = qkv + head * 64;
+  const el_t* qp = qkv + head * 64;
   constexpr float kScale = PRE ? 1.0f : kScaleLog2;
 
   const int qrow = blockIdx.x * 128 + wid * 32 + r32;
-  bf16x8 qf[4];
+  elx8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (qrow < S) v = *(const uint4*)(qp + (row0 + qrow) * ld + 16 * ks + 8 * hsel);
-    qf[ks] = __builtin_bit_cast(bf16x8, v);
+    qf[ks] = __builtin_bit_cast(elx8, v);
   }
 
   // K/V tiles are gathered by LDS-DMA through a buffer descriptor over THIS image's rows: the per-lane byte offsets
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 #if CTRLV_ATTN_DBG == 5          // diagnostic build (timing only): no K.Q^T (K fragment reads + MFMAs)
         sacc[kt][ks] = (float)lane;
 #else
-        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+        const elx8 kf = *(const elx8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
+        sacc[kt] = mfma_32x32x16(kf, qf[ks], sacc[kt]);
 #endif
       }
       // keep the four K fragments of the second 32-key half out of flight until the first half is consumed: the
@@ -221,15 +221,15 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = pack_p(sacc[kt], s);
+        const elx8 pf = pack_p(sacc[kt], s);
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
 #if CTRLV_ATTN_DBG == 4          // diagnostic build (timing only): no P.V (V fragment reads + MFMAs)
           asm volatile("" ::"v"(pf));
 #else
-          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          const elx8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+          oacc[dt] = mfma_32x32x16(vf, pf, oacc[dt]);
 #endif
         }
       }
@@ -269,14 +269,14 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   // kernels rebuild P = exp2(s * scale * log2e - L) from it
   if (lse && qrow < S && hsel == 0) lse[((long)img * gridDim.y + head) * S + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
   if (qrow < S) {
-    bf16_t* op = out + (row0 + qrow) * C + head * 64;
+    el_t* op = out + (row0 + qrow) * C + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int dcol = dt * 32 + 8 * q + 4 * hsel;
-        uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
-                              pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
+        uint2 pk = make_uint2(pack_elx2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
+                              pack_elx2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
         *(uint2*)(op + dcol) = pk;
       }
   }
@@ -310,7 +310,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 static_assert(kNS64 >= 2 && kNS64 <= 4, "2 workgroups per CU: at most 4 x 16 KiB per workgroup");
 
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __restrict__ qkv, el_t* __restrict__ out,
                                                               float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
   const int lane = threadIdx.x & 63;
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
 #endif
   const long row0 = (long)img * S;
   const int ld = 3 * C;
-  const bf16_t* qp = qkv + head * 64;
+  const el_t* qp = qkv + head * 64;
   constexpr float kScale = PRE ? 1.0f : kScaleLog2;      // what is left to apply to a raw score
 
   int qrow[2];
-  bf16x8 qf[2][4];
+  elx8 qf[2][4];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     qrow[rb] = qblk * 256 + wid * 64 + rb * 32 + r32;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
     for (int ks = 0; ks < 4; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (qrow[rb] < S) v = *(const uint4*)(qp + (row0 + qrow[rb]) * ld + 16 * ks + 8 * hsel);
-      qf[rb][ks] = __builtin_bit_cast(bf16x8, v);
+      qf[rb][ks] = __builtin_bit_cast(elx8, v);
     }
   }
 
@@ -405,11 +405,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
+        const elx8 kf = *(const elx8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
           if (SUB && ks == 0) sacc[rb][kt] = mfma_keep_c(kf, qf[rb][ks], negm[rb]);
-          else sacc[rb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rb][ks], sacc[rb][kt], 0, 0, 0);
+          else sacc[rb][kt] = mfma_32x32x16(kf, qf[rb][ks], sacc[rb][kt]);
       }
 #ifdef CTRLV_ATTN64_SERIAL
       if (kt == 0) asm volatile("" ::: "memory");   // keep the second half's K fragments out of flight (registers)
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
   // about four issue slots, two plain v_fma_f32 cost two (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
   // DIRECT: the accumulators already hold scale * s - m (PRE fast path).  The exponentials are packed to bf16 at once
   // (the B operands of O^T += V^T.P), so the 64 score registers of a tile die here and not at the end of the P.V phase.
-  auto exp_pack = [&](const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float m, auto direct_tag) -> float {
+  auto exp_pack = [&](const f32x16 (&sacc)[2], elx8 (&pf)[2][2], float m, auto direct_tag) -> float {
     constexpr bool DIRECT = decltype(direct_tag)::value;
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
     const float nm = -m;
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
           p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 2], kScale, nm));
           p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][e + 3], kScale, nm));
         }
-        bf16x8& d = pf[kt][e >> 3];
+        elx8& d = pf[kt][e >> 3];
         const int o = e & 7;
-        d[o] = (__bf16)p0; d[o + 1] = (__bf16)p1; d[o + 2] = (__bf16)p2; d[o + 3] = (__bf16)p3;
+        d[o] = (el_native_t)p0; d[o + 1] = (el_native_t)p1; d[o + 2] = (el_native_t)p2; d[o + 3] = (el_native_t)p3;
         r0 += p0; r1 += p1; r2 += p2; r3 += p3;
       }
     return (r0 + r1) + (r2 + r3);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
   auto tile = [&](int t, auto masked_tag) {
     const char* kst = smem + (t % kNS64) * 16384;
     const char* vst = kst + 8192;
-    bf16x8 pf[2][2][2];       // [row block][32-key half][16-key step]
+    elx8 pf[2][2][2];       // [row block][32-key half][16-key step]
     float rs[2];
     {
       f32x16 sacc[2][2];
@@ -504,9 +504,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
-          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kt][s], oacc[0][dt], 0, 0, 0);
-          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kt][s], oacc[1][dt], 0, 0, 0);
+          const elx8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+          oacc[0][dt] = mfma_32x32x16(vf, pf[0][kt][s], oacc[0][dt]);
+          oacc[1][dt] = mfma_32x32x16(vf, pf[1][kt][s], oacc[1][dt]);
         }
       }
     }
@@ -538,14 +538,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
     if (lse && qrow[rb] < S && hsel == 0)
       lse[((long)img * gridDim.y + head) * S + qrow[rb]] = m_run[rb] + __builtin_amdgcn_logf(l_tot);
     if (qrow[rb] < S) {
-      bf16_t* op = out + (row0 + qrow[rb]) * C + head * 64;
+      el_t* op = out + (row0 + qrow[rb]) * C + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int dcol = dt * 32 + 8 * q + 4 * hsel;
-          uint2 pk = make_uint2(pack_bf16x2(oacc[rb][dt][4 * q] * inv, oacc[rb][dt][4 * q + 1] * inv),
-                                pack_bf16x2(oacc[rb][dt][4 * q + 2] * inv, oacc[rb][dt][4 * q + 3] * inv));
+          uint2 pk = make_uint2(pack_elx2(oacc[rb][dt][4 * q] * inv, oacc[rb][dt][4 * q + 1] * inv),
+                                pack_elx2(oacc[rb][dt][4 * q + 2] * inv, oacc[rb][dt][4 * q + 3] * inv));
           *(uint2*)(op + dcol) = pk;
         }
     }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const bf16_t* __
 // and the 25 x 64 output goes back through the (dead) Q tile so that the stores are 16 B per lane, row-contiguous.
 // The first version gathered Q / K fragments straight from global memory (32 B per cache line per instruction) and
 // stored 8 B per lane at a 17 MB row stride: 3.07 TB/s on a kernel that moves 4 x M x C x 2 bytes and nothing else.
-__global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const el_t* __restrict__ qkv, el_t* __restrict__ out,
                                                             int B, int F, int S, int C) {
   __shared__ __attribute__((aligned(1024))) char smem[4 * 12288];  // per wave: Q | K | V tiles of 32 x 64 bf16
   const int lane = threadIdx.x & 63;
@@ -605,9 +605,9 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int fo = r32 * 128 + (((ks * 2 + hsel) ^ sw) * 16);
-    const bf16x8 kf = *(const bf16x8*)(kst + fo);
-    const bf16x8 qf = *(const bf16x8*)(qst + fo);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);
+    const elx8 kf = *(const elx8*)(kst + fo);
+    const elx8 qf = *(const elx8*)(qst + fo);
+    sacc = mfma_32x32x16(kf, qf, sacc);
   }
   float mx = -INFINITY;
 #pragma unroll
@@ -638,12 +638,12 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const bf16x8 pf = pack_p(sacc, st);
+    const elx8 pf = pack_p(sacc, st);
     const int kb = 16 * st + vkey;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      const bf16x8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
-      oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+      const elx8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
+      oacc[dt] = mfma_32x32x16(vf, pf, oacc[dt]);
     }
   }
   // O^T (lane = query frame r32, 32 d-values) -> row-major [frame][64] bf16 in the Q tile (its fragments are consumed;
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_kernel(const bf16_t* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int dcol = dt * 32 + 8 * q + 4 * hsel;
-      const uint2 pk = make_uint2(pack_bf16x2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
-                                  pack_bf16x2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
+      const uint2 pk = make_uint2(pack_elx2(oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv),
+                                  pack_elx2(oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv));
       *(uint2*)(qst + r32 * 128 + (((dcol >> 3) ^ (r32 & 7)) * 16) + (dcol & 4) * 2) = pk;
     }
   __builtin_amdgcn_wave_barrier();
@@ -682,9 +682,9 @@ static int attention_spatial_launch(const void* qkv, void* out, float* lse, int 
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
     if (pre)
-      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kNS64 * 16384, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid64, dim3(256), kNS64 * 16384, stream, (const el_t*)qkv, (el_t*)out, lse, S, C);
     else
-      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kNS64 * 16384, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid64, dim3(256), kNS64 * 16384, stream, (const el_t*)qkv, (el_t*)out, lse, S, C);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
@@ -692,9 +692,9 @@ static int attention_spatial_launch(const void* qkv, void* out, float* lse, int 
   // tiles of LDS-DMA in flight but 3 waves/SIMD) -- occupancy beats prefetch depth for this VALU-heavy d = 64 kernel.
   dim3 grid((S + 127) / 128, C / 64, n_img);
   if (pre)
-    hipLaunchKernelGGL((attn_spatial_kernel<2, true>), grid, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+    hipLaunchKernelGGL((attn_spatial_kernel<2, true>), grid, dim3(256), 32768, stream, (const el_t*)qkv, (el_t*)out, lse, S, C);
   else
-    hipLaunchKernelGGL((attn_spatial_kernel<2, false>), grid, dim3(256), 32768, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, C);
+    hipLaunchKernelGGL((attn_spatial_kernel<2, false>), grid, dim3(256), 32768, stream, (const el_t*)qkv, (el_t*)out, lse, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -716,7 +716,7 @@ extern "C" int ctrlv_attention_temporal(const void* qkv, void* out, int B, int F
   CTRLV_CHECK_SHAPE(F > 0 && F <= 32, "attention_temporal: F=%d frames must be in [1, 32]", F);
   const long nprob = (long)B * S * (C / 64);
   hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((nprob + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)qkv, (bf16_t*)out, B, F, S, C);
+                     (const el_t*)qkv, (el_t*)out, B, F, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -34,50 +34,50 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 // transposed fragment (A operand, 32 columns x 16 rows of a row-major [rows][64] bf16 tile), see attention.hip
-__device__ __forceinline__ bf16x8 t_frag(const char* tile, int off_lo, int off_hi) {
+__device__ __forceinline__ elx8 t_frag(const char* tile, int off_lo, int off_hi) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off_lo));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off_hi));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(elx8, v);
 }
 // byte offset of (row, d) in a tile staged for transposed reads: 16-B chunk index ^= ((row >> 1) & 1) << 2
 __device__ __forceinline__ int t_off(int row, int d) {
   const int chunk = (d >> 3) ^ (((row >> 1) & 1) << 2);
   return row * 128 + chunk * 16 + (d & 7) * 2;
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
-  bf16x8 r;
+__device__ __forceinline__ elx8 pack8(const f32x16& p, int s) {
+  elx8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)p[8 * s + j];
+  for (int j = 0; j < 8; ++j) r[j] = (el_native_t)p[8 * s + j];
   return r;
 }
 __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
   float fa[8], fb[8];
-  unpack_bf16x8(a, fa);
-  unpack_bf16x8(b, fb);
+  unpack_elx8(a, fa);
+  unpack_elx8(b, fb);
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s = __builtin_fmaf(fa[j], fb[j], s);
   return s;
 }
 // store a transposed accumulator pair (lane = row r, 2 x 16 registers = 64 columns) as one bf16 row
-__device__ __forceinline__ void store_row64(bf16_t* dst, const f32x16 (&acc)[2], int hsel, float scale) {
+__device__ __forceinline__ void store_row64(el_t* dst, const f32x16 (&acc)[2], int hsel, float scale) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int dcol = dt * 32 + 8 * q + 4 * hsel;
-      uint2 pk = make_uint2(pack_bf16x2(acc[dt][4 * q] * scale, acc[dt][4 * q + 1] * scale),
-                            pack_bf16x2(acc[dt][4 * q + 2] * scale, acc[dt][4 * q + 3] * scale));
+      uint2 pk = make_uint2(pack_elx2(acc[dt][4 * q] * scale, acc[dt][4 * q + 1] * scale),
+                            pack_elx2(acc[dt][4 * q + 2] * scale, acc[dt][4 * q + 3] * scale));
       *(uint2*)(dst + dcol) = pk;
     }
 }
 
 // ------------------------------------------------------------------------------------------ spatial: dQ (+ D)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16_t* __restrict__ dqkv, float* __restrict__ delta, int S,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const el_t* __restrict__ qkv, const el_t* __restrict__ out,
+                                                             const el_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             el_t* __restrict__ dqkv, float* __restrict__ delta, int S,
                                                              int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K rows 8 KiB | K for tr reads 8 KiB | V rows 8 KiB)
   constexpr int SLOT = 24576;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bool qok = qrow < S;
 
   // Q and dO fragments of this lane's query (B operands), D = dO . O, L
-  bf16x8 qf[4], dof[4];
+  elx8 qf[4], dof[4];
   float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       g = *(const uint4*)(dout + (row0 + qrow) * C + head * 64 + 16 * ks + 8 * hsel);
       o = *(const uint4*)(out + (row0 + qrow) * C + head * 64 + 16 * ks + 8 * hsel);
     }
-    qf[ks] = __builtin_bit_cast(bf16x8, q);
-    dof[ks] = __builtin_bit_cast(bf16x8, g);
+    qf[ks] = __builtin_bit_cast(elx8, q);
+    dof[ks] = __builtin_bit_cast(elx8, g);
     dpart += dot8(g, o);
   }
   const float D = half_sum(dpart);
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int fo = (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16);
-        const bf16x8 kf = *(const bf16x8*)(krm + fo);
-        const bf16x8 vf = *(const bf16x8*)(vrm + fo);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
-        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kt], 0, 0, 0);
+        const elx8 kf = *(const elx8*)(krm + fo);
+        const elx8 vf = *(const elx8*)(vrm + fo);
+        sacc[kt] = mfma_32x32x16(kf, qf[ks], sacc[kt]);
+        dp[kt] = mfma_32x32x16(vf, dof[ks], dp[kt]);
       }
     }
     // dS^T in place of the scores (lane = query: L and D are per-lane scalars)
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = pack8(sacc[kt], s);
+        const elx8 pf = pack8(sacc[kt], s);
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 kf = t_frag(ktr, t_off(kb, dt * 32 + vcol), t_off(kb + 8, dt * 32 + vcol));
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, pf, dq[dt], 0, 0, 0);
+          const elx8 kf = t_frag(ktr, t_off(kb, dt * 32 + vcol), t_off(kb + 8, dt * 32 + vcol));
+          dq[dt] = mfma_32x32x16(kf, pf, dq[dt]);
         }
       }
   };
@@ -205,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------ spatial: dK, dV
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const el_t* __restrict__ qkv, const el_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, int S, int C) {
+                                                               el_t* __restrict__ dqkv, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (Q rows | Q tr | dO rows | dO tr | L | D)
   constexpr int SLOT = 4 * 8192 + 512;
   const int lane = threadIdx.x & 63;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
   const int krow = blockIdx.x * 128 + wid * 32 + r32;
   const bool kok = krow < S;
 
-  bf16x8 kf[4], vf[4];       // this lane's key: B operands of S = Q.K^T and dP = dO.V^T
+  elx8 kf[4], vf[4];       // this lane's key: B operands of S = Q.K^T and dP = dO.V^T
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     uint4 k = make_uint4(0, 0, 0, 0), v = k;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
       k = *(const uint4*)(qkv + (row0 + krow) * ld + C + head * 64 + 16 * ks + 8 * hsel);
       v = *(const uint4*)(qkv + (row0 + krow) * ld + 2 * C + head * 64 + 16 * ks + 8 * hsel);
     }
-    kf[ks] = __builtin_bit_cast(bf16x8, k);
-    vf[ks] = __builtin_bit_cast(bf16x8, v);
+    kf[ks] = __builtin_bit_cast(elx8, k);
+    vf[ks] = __builtin_bit_cast(elx8, v);
   }
 
   const int prow = lane >> 3, pslot = lane & 7;
@@ -282,10 +282,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int fo = (qt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16);
-        const bf16x8 qa = *(const bf16x8*)(qrm + fo);
-        const bf16x8 ga = *(const bf16x8*)(grm + fo);
-        sacc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc[qt], 0, 0, 0);
-        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp[qt], 0, 0, 0);
+        const elx8 qa = *(const elx8*)(qrm + fo);
+        const elx8 ga = *(const elx8*)(grm + fo);
+        sacc[qt] = mfma_32x32x16(qa, kf[ks], sacc[qt]);
+        dp[qt] = mfma_32x32x16(ga, vf[ks], dp[qt]);
       }
     }
     // lane = key; register e of block qt is query qt*32 + 8*(e>>2) + 4*hsel + (e&3): L, D come as 4-vectors
@@ -308,14 +308,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = pack8(sacc[qt], s);
-        const bf16x8 dsf = pack8(dp[qt], s);
+        const elx8 pf = pack8(sacc[qt], s);
+        const elx8 dsf = pack8(dp[qt], s);
         const int qb = qt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int o_lo = t_off(qb, dt * 32 + vcol), o_hi = t_off(qb + 8, dt * 32 + vcol);
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t_frag(gtr, o_lo, o_hi), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t_frag(qtr, o_lo, o_hi), dsf, dk[dt], 0, 0, 0);
+          dv[dt] = mfma_32x32x16(t_frag(gtr, o_lo, o_hi), pf, dv[dt]);
+          dk[dt] = mfma_32x32x16(t_frag(qtr, o_lo, o_hi), dsf, dk[dt]);
         }
       }
   };
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 // ------------------------------------------------------------------------------------------ temporal
 // One wave per (clip, pixel, head).  LDS per wave: Q, K, dO each as a row tile (fragment reads) and as a tile for
 // transposed reads, V as a row tile: 7 x 4 KiB, plus 256 B for L and D.  Rows >= F are zeros (out of range).
-__global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                                   const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+__global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const el_t* __restrict__ qkv, const el_t* __restrict__ out,
+                                                                   const el_t* __restrict__ dout, el_t* __restrict__ dqkv,
                                                                    int B, int F, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int WAVE_LDS = 7 * 4096 + 256;
@@ -404,12 +404,12 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const bf16_t*
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int fo = r32 * 128 + (((ks * 2 + hsel) ^ sw) * 16);
-    const bf16x8 kf = *(const bf16x8*)(k_rm + fo);
-    const bf16x8 qf = *(const bf16x8*)(q_rm + fo);
-    const bf16x8 vf = *(const bf16x8*)(v_rm + fo);
-    const bf16x8 gf = *(const bf16x8*)(g_rm + fo);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);
-    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf, dp, 0, 0, 0);
+    const elx8 kf = *(const elx8*)(k_rm + fo);
+    const elx8 qf = *(const elx8*)(q_rm + fo);
+    const elx8 vf = *(const elx8*)(v_rm + fo);
+    const elx8 gf = *(const elx8*)(g_rm + fo);
+    sacc = mfma_32x32x16(kf, qf, sacc);
+    dp = mfma_32x32x16(vf, gf, dp);
   }
   float mx = -INFINITY;
 #pragma unroll
@@ -441,12 +441,11 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const bf16_t*
     for (int e = 0; e < 16; ++e) acc[dt][e] = 0.f;
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const bf16x8 pf = pack8(sacc, st);
+    const elx8 pf = pack8(sacc, st);
     const int kb = 16 * st + vkey;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
-      acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t_frag(k_tr, t_off(kb, dt * 32 + vcol), t_off(kb + 8, dt * 32 + vcol)),
-                                                        pf, acc[dt], 0, 0, 0);
+      acc[dt] = mfma_32x32x16(t_frag(k_tr, t_off(kb, dt * 32 + vcol), t_off(kb + 8, dt * 32 + vcol)), pf, acc[dt]);
   }
   if (r32 < F) store_row64(dqkv + ((long)(b * F + r32) * S + s) * ld + head * 64, acc, hsel, kScale);
 
@@ -457,12 +456,12 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const bf16_t*
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int fo = r32 * 128 + (((ks * 2 + hsel) ^ sw) * 16);
-    const bf16x8 qa = *(const bf16x8*)(q_rm + fo);
-    const bf16x8 kb_ = *(const bf16x8*)(k_rm + fo);
-    const bf16x8 ga = *(const bf16x8*)(g_rm + fo);
-    const bf16x8 vb = *(const bf16x8*)(v_rm + fo);
-    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb_, sacc, 0, 0, 0);
-    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vb, dp, 0, 0, 0);
+    const elx8 qa = *(const elx8*)(q_rm + fo);
+    const elx8 kb_ = *(const elx8*)(k_rm + fo);
+    const elx8 ga = *(const elx8*)(g_rm + fo);
+    const elx8 vb = *(const elx8*)(v_rm + fo);
+    sacc = mfma_32x32x16(qa, kb_, sacc);
+    dp = mfma_32x32x16(ga, vb, dp);
   }
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
@@ -485,18 +484,18 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_bwd_kernel(const bf16_t*
     for (int e = 0; e < 16; ++e) { acc[dt][e] = 0.f; dk[dt][e] = 0.f; }
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const bf16x8 pf = pack8(sacc, st);
-    const bf16x8 dsf = pack8(dp, st);
+    const elx8 pf = pack8(sacc, st);
+    const elx8 dsf = pack8(dp, st);
     const int qb = 16 * st + vkey;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int o_lo = t_off(qb, dt * 32 + vcol), o_hi = t_off(qb + 8, dt * 32 + vcol);
-      acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t_frag(g_tr, o_lo, o_hi), pf, acc[dt], 0, 0, 0);
-      dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t_frag(q_tr, o_lo, o_hi), dsf, dk[dt], 0, 0, 0);
+      acc[dt] = mfma_32x32x16(t_frag(g_tr, o_lo, o_hi), pf, acc[dt]);
+      dk[dt] = mfma_32x32x16(t_frag(q_tr, o_lo, o_hi), dsf, dk[dt]);
     }
   }
   if (r32 < F) {
-    bf16_t* drow = dqkv + ((long)(b * F + r32) * S + s) * ld + head * 64;
+    el_t* drow = dqkv + ((long)(b * F + r32) * S + s) * ld + head * 64;
     store_row64(drow + C, dk, hsel, kScale);
     store_row64(drow + 2 * C, acc, hsel, 1.0f);
   }
@@ -520,11 +519,11 @@ extern "C" int ctrlv_attention_spatial_bwd(const void* qkv, const void* out, con
     attr_set[dev] = true;
   }
   dim3 grid((S + 127) / 128, C / 64, n_img);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), kSmemDq, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, delta, S, C);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), kSmemDq, (hipStream_t)stream, (const el_t*)qkv, (const el_t*)out,
+                     (const el_t*)dout, lse, (el_t*)dqkv, delta, S, C);
   CTRLV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), kSmemKv, (hipStream_t)stream, (const bf16_t*)qkv,
-                     (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, S, C);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), kSmemKv, (hipStream_t)stream, (const el_t*)qkv,
+                     (const el_t*)dout, lse, (const float*)delta, (el_t*)dqkv, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -544,7 +543,7 @@ extern "C" int ctrlv_attention_temporal_bwd(const void* qkv, const void* out, co
   }
   const long nprob = (long)B * S * (C / 64);
   hipLaunchKernelGGL(attn_temporal_bwd_kernel, dim3((unsigned)((nprob + 3) / 4)), dim3(256), kSmem, (hipStream_t)stream,
-                     (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, (bf16_t*)dqkv, B, F, S, C);
+                     (const el_t*)qkv, (const el_t*)out, (const el_t*)dout, (el_t*)dqkv, B, F, S, C);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

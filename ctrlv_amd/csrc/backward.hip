@@ -23,7 +23,7 @@ __device__ __forceinline__ int tr_off(int row, int col) {      // [rows][64] bf1
   return row * 128 + chunk * 16 + (col & 7) * 2;
 }
 // 32 (columns cb .. cb+31) x 16 (rows kb .. kb+15) MFMA operand from a row-major tile: two transposed 4x16 block reads
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int lane) {
+__device__ __forceinline__ elx8 tr_frag(const char* tile, int kb, int cb, int lane) {
   const int hsel = lane >> 5, i16 = lane & 15;
   const int row = kb + 4 * hsel + (i16 >> 2);
   const int col = cb + 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
@@ -31,11 +31,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int 
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + tr_off(row + 8, col)));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(elx8, v);
 }
 
 struct WgradArgs {
-  const bf16_t* A; const bf16_t* A2; const bf16_t* dY; float* dW; float* dbias; float scale; int torch_layout;
+  const el_t* A; const el_t* A2; const el_t* dY; float* dW; float* dbias; float scale; int torch_layout;
   int M, N, Cin, taps, lda, lda2, c_split, ldy, mode, H, Wd, Ho, Wo, stride, up, F, S, rows_per_slab;
 };
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const bool a_ok = kcol < ktot;
   const int tap = a_ok ? kcol / a.Cin : 0, c = kcol - tap * a.Cin;
   const bool second = a.A2 != nullptr && c >= a.c_split;
-  const bf16_t* abase = second ? a.A2 + (c - a.c_split) : a.A + c;
+  const el_t* abase = second ? a.A2 + (c - a.c_split) : a.A + c;
   const long ald = second ? a.lda2 : a.lda;
   auto sw = [](int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) * 16); };
   // bias gradient (column sums of dY) rides along in the workgroups of the first K tile: they stream dY anyway
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float f[8];
-        unpack_bf16x8(vy[i], f);
+        unpack_elx8(vy[i], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bsum[e] += f[e];
       }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     if (m0 + 64 < m_hi) load(m0 + 64);                       // in flight while this chunk is consumed
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 fy[2], fa[4];
+      elx8 fy[2], fa[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fy[i] = tr_frag(ty + nh * 8192, 16 * s, 32 * i, lane);          // A operand: i = n
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16(fy[i], fa[j], acc[i][j]);
     }
   }
   // D[i][j]: lane holds column j = lane % 32, rows i = (e & 3) + 8 * (e >> 2) + 4 * (lane / 32)
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // 64 column groups of 8 (16-B loads) x 4 row lanes per workgroup; the row lanes are folded through LDS so that a
 // workgroup issues ONE atomic per column (same-address float atomics execute serially at the memory side: the first
 // version -- one column per thread, 2-B loads, an atomic per 256 rows -- cost 124 us per call on average).
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int M, int N, int ldx, int rows_per_block,
+__global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x, int M, int N, int ldx, int rows_per_block,
                                                      int vmode, int vdiv, int vmod, float scale, float* __restrict__ out,
                                                      int ldo) {
   __shared__ float red[4][64][8];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     }
     if (col_ok) {
       float f[8];
-      unpack_bf16x8(*(const uint4*)(x + (long)m * ldx + n0), f);
+      unpack_elx8(*(const uint4*)(x + (long)m * ldx + n0), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += f[e];
     }
@@ -234,23 +234,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // out[0] += scale * sum_i dy[i] * (p[i] - q[i])      (gradient of a folded AlphaBlender's mixing weight)
-__global__ __launch_bounds__(256) void dot_diff_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ p,
-                                                       const bf16_t* __restrict__ q, size_t n, float scale,
+__global__ __launch_bounds__(256) void dot_diff_kernel(const el_t* __restrict__ dy, const el_t* __restrict__ p,
+                                                       const el_t* __restrict__ q, size_t n, float scale,
                                                        float* __restrict__ out) {
   __shared__ float red[4];
   float acc = 0.f;
   const size_t nv = n >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     float a[8], b[8], c[8];
-    unpack_bf16x8(((const uint4*)dy)[i], a);
-    unpack_bf16x8(((const uint4*)p)[i], b);
-    unpack_bf16x8(((const uint4*)q)[i], c);
+    unpack_elx8(((const uint4*)dy)[i], a);
+    unpack_elx8(((const uint4*)p)[i], b);
+    unpack_elx8(((const uint4*)q)[i], c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc += a[e] * (b[e] - c[e]);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     const size_t i = (nv << 3) + threadIdx.x;
-    acc += bf16_to_f32(dy[i]) * (bf16_to_f32(p[i]) - bf16_to_f32(q[i]));
+    acc += el_to_f32(dy[i]) * (el_to_f32(p[i]) - el_to_f32(q[i]));
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -267,7 +267,7 @@ __device__ __forceinline__ float dsilu(float z) {            // d/dz [z * sigmoi
 }
 
 // pass 1: per (image, chunk, channel): s1 = sum dz * xhat, s2 = sum dz      grid (n_chunks, n_img), C/8 * RPP threads
-__global__ void gn_bwd_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, GnB s,
+__global__ void gn_bwd_partial_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, GnB s,
                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, int silu, float* __restrict__ part) {
   extern __shared__ float red[];      // [RPP][C][2]
@@ -288,8 +288,8 @@ __global__ void gn_bwd_partial_kernel(const bf16_t* __restrict__ x, const bf16_t
   for (int r = r0 + rsub; r < r1; r += RPP) {
     const long row = (long)n * s.S + r;
     float fx[8], fd[8];
-    unpack_bf16x8(*(const uint4*)(x + row * s.C + c0), fx);
-    unpack_bf16x8(*(const uint4*)(dy + row * s.C + c0), fd);
+    unpack_elx8(*(const uint4*)(x + row * s.C + c0), fx);
+    unpack_elx8(*(const uint4*)(dy + row * s.C + c0), fd);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = (fx[e] - mean[e]) * rstd[e];
@@ -365,10 +365,10 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnB s, const float* 
   }
 }
 // pass 3: dx = rstd * (dz * gamma - m1 - xhat * m2)
-__global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, GnB s,
+__global__ void gn_bwd_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, GnB s,
                                     const float* __restrict__ stats, const float* __restrict__ gmean,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                    bf16_t* __restrict__ dx) {
+                                    el_t* __restrict__ dx) {
   const int CV = s.C / 8, RPP = blockDim.x / CV;
   const int tid = threadIdx.x, col = tid % CV, rsub = tid / CV;
   const int n = blockIdx.y, chunk = blockIdx.x, stat = n / s.ips, cpg = s.C / 32, c0 = col * 8;
@@ -387,15 +387,15 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
   for (int r = r0 + rsub; r < r1; r += RPP) {
     const long row = (long)n * s.S + r;
     float fx[8], fd[8];
-    unpack_bf16x8(*(const uint4*)(x + row * s.C + c0), fx);
-    unpack_bf16x8(*(const uint4*)(dy + row * s.C + c0), fd);
+    unpack_elx8(*(const uint4*)(x + row * s.C + c0), fx);
+    unpack_elx8(*(const uint4*)(dy + row * s.C + c0), fd);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = (fx[e] - mean[e]) * rstd[e];
       const float dz = silu ? fd[e] * dsilu(xh * g[e] + b[e]) : fd[e];
       fx[e] = rstd[e] * (dz * g[e] - m1[e] - xh * m2[e]);
     }
-    *(uint4*)(dx + row * s.C + c0) = pack_bf16x8(fx);
+    *(uint4*)(dx + row * s.C + c0) = pack_elx8(fx);
   }
 }
 
@@ -406,9 +406,9 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
 // ln_bwd_reduce_kernel folds the rows with 16 atomics per column.  (One atomic per column PER WAVE -- 4096 same-address
 // memory-side atomics per column -- made this kernel 10x slower than its HBM traffic: 0.93 ms at C = 320, M = 230 k.)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int M, int C,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, int M, int C,
                                                      const float* __restrict__ gamma, float eps, const float* __restrict__ V,
-                                                     int vdiv, int vmod, int ldv, bf16_t* __restrict__ dx,
+                                                     int vdiv, int vmod, int ldv, el_t* __restrict__ dx,
                                                      float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int CV = C >> 3;
@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int k = 0; k < NV; ++k) {
       const int cv = lane + k * 64;
       if (cv < CV) {
-        unpack_bf16x8(*(const uint4*)(x + m * C + cv * 8), fx[k]);
-        unpack_bf16x8(*(const uint4*)(dy + m * C + cv * 8), fd[k]);
+        unpack_elx8(*(const uint4*)(x + m * C + cv * 8), fx[k]);
+        unpack_elx8(*(const uint4*)(dy + m * C + cv * 8), fd[k]);
         if (vrow) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) fx[k][e] += vrow[cv * 8 + e];
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (fd[k][e] * g[k][e] - m1 - fx[k][e] * m2);
-        *(uint4*)(dx + m * C + cv * 8) = pack_bf16x8(o);
+        *(uint4*)(dx + m * C + cv * 8) = pack_elx8(o);
       }
     }
   }
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 // raw: the projection output [M][2I] in the packed (16-value, 16-gate) column-block order (the forward GEMM without its
 // GEGLU epilogue); du: gradient of u = a * gelu(g), [M][I].  draw (same layout as raw): da = du * gelu(g),
 // dg = du * a * (Phi(g) + g * phi(g)).
-__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ raw, const bf16_t* __restrict__ du, long M,
-                                                        int I, bf16_t* __restrict__ draw) {
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const el_t* __restrict__ raw, const el_t* __restrict__ du, long M,
+                                                        int I, el_t* __restrict__ draw) {
   const long total = M * (I >> 3);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / (I >> 3);
@@ -521,9 +521,9 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     const int blk = j0 >> 4, r0 = j0 & 15;
     const long base = m * (2L * I) + blk * 32 + r0;
     float a[8], g[8], d[8], oa[8], og[8];
-    unpack_bf16x8(*(const uint4*)(raw + base), a);
-    unpack_bf16x8(*(const uint4*)(raw + base + 16), g);
-    unpack_bf16x8(*(const uint4*)(du + m * I + j0), d);
+    unpack_elx8(*(const uint4*)(raw + base), a);
+    unpack_elx8(*(const uint4*)(raw + base + 16), g);
+    unpack_elx8(*(const uint4*)(du + m * I + j0), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const f32x4_t gv = {g[e], g[e], g[e], g[e]};
@@ -532,8 +532,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
       oa[e] = d[e] * (g[e] * Phi);
       og[e] = d[e] * a[e] * (Phi + g[e] * phi);
     }
-    *(uint4*)(draw + base) = pack_bf16x8(oa);
-    *(uint4*)(draw + base + 16) = pack_bf16x8(og);
+    *(uint4*)(draw + base) = pack_elx8(oa);
+    *(uint4*)(draw + base + 16) = pack_elx8(og);
   }
 }
 
@@ -555,8 +555,8 @@ extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, 
   const long blocks = ln_bwd_blocks(M);
   hipStream_t st = (hipStream_t)stream;
 #define LNB_LAUNCH(NV)                                                                                                  \
-  hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, M, C, \
-                     gamma, eps, V, vdiv, vmod, ldv, (bf16_t*)dx, scratch)
+  hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, (const el_t*)dy, M, C, \
+                     gamma, eps, V, vdiv, vmod, ldv, (el_t*)dx, scratch)
   switch (nv) {
     case 1: LNB_LAUNCH(1); break;
     case 2: LNB_LAUNCH(2); break;
@@ -577,8 +577,8 @@ extern "C" int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I,
   CTRLV_CHECK_SHAPE(M > 0 && I > 0 && I % 16 == 0, "geglu_bwd: inner dim %d must be a multiple of 16", I);
   size_t blocks = (M * (I / 8) + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)raw,
-                     (const bf16_t*)du, (long)M, I, (bf16_t*)draw);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const el_t*)raw,
+                     (const el_t*)du, (long)M, I, (el_t*)draw);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -594,7 +594,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
                     "gemm_wgrad: mode / taps mismatch");
   if (d.A2) CTRLV_CHECK_SHAPE(d.c_split % 64 == 0 && d.lda2 % 8 == 0, "gemm_wgrad: bad concat split");
   WgradArgs a;
-  a.A = (const bf16_t*)d.A; a.A2 = (const bf16_t*)d.A2; a.dY = (const bf16_t*)dY; a.dW = dW; a.dbias = dbias; a.scale = scale; a.torch_layout = torch_layout;
+  a.A = (const el_t*)d.A; a.A2 = (const el_t*)d.A2; a.dY = (const el_t*)dY; a.dW = dW; a.dbias = dbias; a.scale = scale; a.torch_layout = torch_layout;
   a.M = d.M; a.N = d.N; a.Cin = d.Cin; a.taps = d.taps; a.lda = d.lda; a.lda2 = d.lda2; a.c_split = d.c_split; a.ldy = ldy;
   a.mode = d.mode; a.H = d.H; a.Wd = d.Wd; a.Ho = d.Ho; a.Wo = d.Wo; a.stride = d.stride ? d.stride : 1; a.up = d.up;
   a.F = d.F; a.S = d.S;
@@ -619,7 +619,7 @@ extern "C" int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int
   CTRLV_CHECK_ARG(vmode == 0 || (vmode == 1 && vdiv > 0 && vmod > 0), "colsum: vmode must be 0 or 1 with vdiv, vmod > 0");
   const int rpb = M >= (1 << 18) ? 1024 : (M >= (1 << 14) ? 256 : 64);      // >= ~225 workgroups per 512 columns at L0
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, M, N, ldx, rpb, vmode, vdiv, vmod, scale, out, ldo);
+                     (const el_t*)x, M, N, ldx, rpb, vmode, vdiv, vmod, scale, out, ldo);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -630,8 +630,8 @@ extern "C" int ctrlv_dot_diff(const void* dy, const void* p, const void* q, size
   size_t blocks = (n / 8 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(dot_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (const bf16_t*)p, (const bf16_t*)q, n, scale, out);
+  hipLaunchKernelGGL(dot_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const el_t*)dy,
+                     (const el_t*)p, (const el_t*)q, n, scale, out);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -660,7 +660,7 @@ extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int
   const int CV = C / 8, RPP = CV >= 256 ? 1 : 256 / CV, nt = CV * RPP;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks, n_img), dim3(nt), (size_t)RPP * C * 2 * sizeof(float), st,
-                     (const bf16_t*)x, (const bf16_t*)dy, s, stats, gamma, beta, silu, part);
+                     (const el_t*)x, (const el_t*)dy, s, stats, gamma, beta, silu, part);
   CTRLV_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(32, n_img / imgs_per_stat), dim3(256), 0, st, s, part, gamma, gmean);
   CTRLV_LAUNCH_CHECK();
@@ -669,8 +669,8 @@ extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int
     hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 63) / 64, tot >= 64 ? 16 : 1), dim3(256), 0, st, s, part, dgamma, dbeta);
   }
   CTRLV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, n_img), dim3(nt), 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, stats,
-                     gmean, gamma, beta, silu, (bf16_t*)dx);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, n_img), dim3(nt), 0, st, (const el_t*)x, (const el_t*)dy, s, stats,
+                     gmean, gamma, beta, silu, (el_t*)dx);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -1,4 +1,4 @@
-// Shared device/host helpers for libctrlv_hip.so (gfx950 only: wave64, MFMA 32x32x16 bf16, LDS-DMA).
+// Shared device/host helpers for libctrlv_hip.so / libctrlv_hip_f16.so (gfx950 only: wave64, MFMA 32x32x16, LDS-DMA).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,13 +7,30 @@
 
 #include "../../include/ctrlv_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// ---- the activation / weight ELEMENT type.  The library is built twice from these sources:
+//   libctrlv_hip.so      el = bf16 (default)             -- BASELINE.json's dtype; inference and the training step
+//   libctrlv_hip_f16.so  el = IEEE fp16 (-DCTRLV_ELEM_F16) -- the reference's own autocast dtype (config/a100l.yaml:9,
+//                        tools/eval_video_controlnet.py:110-118): same bytes, same MFMA rate, 3 more mantissa bits, which
+//                        is what north_star's 1e-3 model-level tolerance needs.
+// Everything that touches an element goes through the helpers below; kernels are otherwise type-agnostic (16-bit moves,
+// LDS-DMA, ds_read_b64_tr_b16).  fp32 accumulation / statistics in both builds.
+#ifdef CTRLV_ELEM_F16
+typedef _Float16 el_native_t;
+#define CTRLV_ELEM_DTYPE 1                                    /* the ABI's dtype code of the element type */
+#define CTRLV_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_f16"
+#else
+typedef __bf16 el_native_t;
+#define CTRLV_ELEM_DTYPE 2
+#define CTRLV_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_bf16"
+#endif
+typedef __attribute__((ext_vector_type(8))) el_native_t elx8;
+typedef __attribute__((ext_vector_type(4))) el_native_t elx4;
+typedef __attribute__((ext_vector_type(2))) el_native_t elx2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef uint16_t bf16_t;  // raw storage
+typedef uint16_t el_t;    // raw storage of one element
+typedef uint16_t bf16_t;  // raw storage of a genuine bf16 value (dtype code 2 at the model boundary, whatever el is)
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -22,25 +39,59 @@ typedef uint16_t bf16_t;  // raw storage
 // (one copy per translation unit: the library is built without relocatable device code)
 static __device__ __attribute__((aligned(256), used)) unsigned char g_ctrlv_zeros[256];
 
+// D = A . B + C on the matrix pipe, 32 x 32 x 16, element-type operands, fp32 accumulate
+__device__ __forceinline__ f32x16 mfma_32x32x16(const elx8& a, const elx8& b, const f32x16& c) {
+#ifdef CTRLV_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// genuine bf16 <-> fp32 (boundary dtype code 2): round-to-nearest-even through the hardware convert (keeps NaN a NaN,
+// see MI355X_MICROARCH correctness table)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even through the hardware convert (keeps NaN a NaN, see MI355X_MICROARCH correctness table)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#ifdef CTRLV_ELEM_F16
+// IEEE fp16, round-to-nearest-even (v_cvt_f16_f32; overflow -> inf like the reference's autocast: the largest stored
+// |value| of the path is < 10, profiles/r04_storage_precision_study.txt)
+__device__ __forceinline__ float el_to_f32(el_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ el_t f32_to_el(float f) { return __builtin_bit_cast(el_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack_elx2(float lo, float hi) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
+__device__ __forceinline__ void unpack_elx8(const uint4& v, float* f) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y), c = __builtin_bit_cast(h2, v.z),
+           d = __builtin_bit_cast(h2, v.w);
+  f[0] = (float)a.x; f[1] = (float)a.y; f[2] = (float)b.x; f[3] = (float)b.y;
+  f[4] = (float)c.x; f[5] = (float)c.y; f[6] = (float)d.x; f[7] = (float)d.y;
+}
+#else
+__device__ __forceinline__ float el_to_f32(el_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ el_t f32_to_el(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ uint32_t pack_elx2(float lo, float hi) {
+  return (uint32_t)f32_to_el(lo) | ((uint32_t)f32_to_el(hi) << 16);
+}
+__device__ __forceinline__ void unpack_elx8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
   f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
-__device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
+#endif
+// the two 16-bit halves of a packed dword as fp32 (the 2-stage epilogue's residual reads)
+__device__ __forceinline__ float el_lo_f32(uint32_t v) { return el_to_f32((el_t)(v & 0xffffu)); }
+__device__ __forceinline__ float el_hi_f32(uint32_t v) { return el_to_f32((el_t)(v >> 16)); }
+__device__ __forceinline__ uint4 pack_elx8(const float* f) {
   uint4 v;
-  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+  v.x = pack_elx2(f[0], f[1]); v.y = pack_elx2(f[2], f[3]);
+  v.z = pack_elx2(f[4], f[5]); v.w = pack_elx2(f[6], f[7]);
   return v;
 }
 // silu(x) = x * sigmoid(x) with the raw v_exp_f32 / v_rcp_f32 (1 ulp each); x -> -inf gives x * 0.

@@ -36,8 +36,8 @@ constexpr int kSmem = kTabOff + kGeluTabBytes;
 static_assert(kSmem <= 160 * 1024, "fused feed-forward tile does not fit the LDS");
 
 struct FfArgs {
-  const bf16_t* x; int ldx;
-  const bf16_t* w1f; const bf16_t* w2f;
+  const el_t* x; int ldx;
+  const el_t* w1f; const el_t* w2f;
   ctrlv_gemm_desc o;            // the second projection's descriptor: out, bias (b2), R1, R2, scales, M, N = 320
   const float* vtab; int vdiv, vmod, ldv;   // row-vector operand V[(m / vdiv) % vmod] (vtab = nullptr: none), see below
   // optional LayerNorm of the input rows (ln_g = nullptr: x is used as it is): x' = LN(x + lnv[(m / ln_vdiv) % ln_vmod])
@@ -92,23 +92,23 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
   // but a 21st K step -- the packed W1 chunk carries (bf16(b), bf16(b - bf16(b))) in two K slots against a constant-one x
   // fragment, which adds b to within 2^-17 |b| in the fp32 accumulator -- and from b2, read from global once per tile.
   const int grp = wid >> 2;
-  const uint4 xone_u = hsel == 0 ? make_uint4(0x3F803F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
-  const bf16x8 xone = __builtin_bit_cast(bf16x8, xone_u);
+  const uint4 xone_u = hsel == 0 ? make_uint4(CTRLV_ELEM_DTYPE == 1 ? 0x3C003C00u : 0x3F803F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+  const elx8 xone = __builtin_bit_cast(elx8, xone_u);
 
   int cglob = 0;                                             // chunks processed so far by this workgroup (ring phase)
   for (int tile = blockIdx.x; tile < tiles; tile += G) {
     const int bm = tile * 256;
     const int m = bm + wid * 32 + r32;
     // ---- x rows of this wave as B fragments: k-step ks = columns ks*16 + 8*hsel .. +8 of row m
-    bf16x8 xr[10];
+    elx8 xr[10];
     {
-      const bf16_t* xp = a.x + (long)m * a.ldx + 8 * hsel;
+      const el_t* xp = a.x + (long)m * a.ldx + 8 * hsel;
       const bool ok = m < M;
 #pragma unroll
       for (int ks = 0; ks < 10; ++ks) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ok) v = *(const uint4*)(xp + ks * 16);
-        xr[ks] = __builtin_bit_cast(bf16x8, v);
+        xr[ks] = __builtin_bit_cast(elx8, v);
       }
 #pragma unroll
       for (int ks = 10; ks < 20; ++ks) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       const float* lv = a.lnv ? a.lnv + (long)((m / a.ln_vdiv) % a.ln_vmod) * a.ln_ldv + 8 * hsel : nullptr;
       auto raw8 = [&](int ks, float* f) {
         const uint4 v = ks < 10 ? __builtin_bit_cast(uint4, xr[ks]) : *(const uint4*)(xhi + (ks - 10) * 1024);
-        unpack_bf16x8(v, f);
+        unpack_elx8(v, f);
         if (lv) {
           const float4 p = *(const float4*)(lv + ks * 16), q = *(const float4*)(lv + ks * 16 + 4);
           f[0] += p.x; f[1] += p.y; f[2] += p.z; f[3] += p.w; f[4] += q.x; f[5] += q.y; f[6] += q.z; f[7] += q.w;
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
-        uint4 o = pack_bf16x8(f);
+        uint4 o = pack_elx8(f);
         if (!(m < M)) o = make_uint4(0, 0, 0, 0);
-        if (ks < 10) xr[ks] = __builtin_bit_cast(bf16x8, o);
+        if (ks < 10) xr[ks] = __builtin_bit_cast(elx8, o);
         else *(uint4*)(xhi + (ks - 10) * 1024) = o;
         if (ks % 5 == 4) __builtin_amdgcn_sched_barrier(0);
       }
@@ -221,27 +221,27 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       for (int e = 0; e < 16; ++e) a1[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 20; ++ks) {
-        const bf16x8 wf = *(const bf16x8*)(s1 + ks * 1024);
-        const bf16x8 xf = ks < 10 ? xr[ks] : *(const bf16x8*)(xhi + (ks - 10) * 1024);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, a1, 0, 0, 0);
+        const elx8 wf = *(const elx8*)(s1 + ks * 1024);
+        const elx8 xf = ks < 10 ? xr[ks] : *(const elx8*)(xhi + (ks - 10) * 1024);
+        a1 = mfma_32x32x16(wf, xf, a1);
       }
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(s1 + 20 * 1024), xone, a1, 0, 0, 0);   // + bias
+      a1 = mfma_32x32x16(*(const elx8*)(s1 + 20 * 1024), xone, a1);   // + bias
       FSTAMP(t1);
       // GEGLU in the result layout: accumulators 0..7 are the 8 value columns of this lane, 8..15 their gates
       float h[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[e] = geglu_tab(a1[e], a1[8 + e], tab);
-      const uint4 hp = make_uint4(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]),
-                                  pack_bf16x2(h[6], h[7]));
-      const bf16x8 hf = __builtin_bit_cast(bf16x8, hp);
+      const uint4 hp = make_uint4(pack_elx2(h[0], h[1]), pack_elx2(h[2], h[3]), pack_elx2(h[4], h[5]),
+                                  pack_elx2(h[6], h[7]));
+      const elx8 hf = __builtin_bit_cast(elx8, hp);
       FSTAMP(t2);
       if (grp == 1) boundary(c);
       FSTAMP(t3);
       const char* s2 = smem + kW2Off + (cglob % 3) * kW2Slot + lane * 16;
 #pragma unroll
       for (int n = 0; n < 10; ++n) {
-        const bf16x8 wf = *(const bf16x8*)(s2 + n * 1024);
-        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc[0][n], 0, 0, 0);
+        const elx8 wf = *(const elx8*)(s2 + n * 1024);
+        acc[0][n] = mfma_32x32x16(wf, hf, acc[0][n]);
       }
       FSTAMP(t4);
       if (grp == 0) boundary(c);
@@ -274,21 +274,21 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
 
 // fragment-major copies of the two packed weights (device-side permutation of bf16 values, once per weight); the 21st
 // K step of every W1 chunk carries the GEMM-1 bias as (bf16(b), bf16(b - bf16(b))) in K slots 0 and 1
-__global__ void ff_pack_kernel(const bf16_t* __restrict__ w1p, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
-                               bf16_t* __restrict__ w1f, bf16_t* __restrict__ w2f) {
+__global__ void ff_pack_kernel(const el_t* __restrict__ w1p, const float* __restrict__ b1, const el_t* __restrict__ w2p,
+                               el_t* __restrict__ w1f, el_t* __restrict__ w2f) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n1 = (long)kChunks * kW1Pieces * 64 * 8, n2 = (long)kChunks * 10 * 64 * 8;
   if (i < n1) {
     // w1f[chunk][ks][lane][j] = w1p[chunk*32 + lane%32][ks*16 + 8*(lane/32) + j]
     const int j = i & 7, lane = (i >> 3) & 63;
     const int ks = (int)((i >> 9) % kW1Pieces), chunk = (int)(i / (kW1Pieces * 512));
-    bf16_t v = 0;
+    el_t v = 0;
     if (ks < 20) {
       v = w1p[(long)(chunk * 32 + (lane & 31)) * kC + ks * 16 + 8 * (lane >> 5) + j];
     } else if (lane < 32 && j < 2) {
       const float b = b1[chunk * 32 + lane];
-      const bf16_t hi = f32_to_bf16(b);
-      v = j == 0 ? hi : f32_to_bf16(b - __uint_as_float((unsigned)hi << 16));
+      const el_t hi = f32_to_el(b);
+      v = j == 0 ? hi : f32_to_el(b - el_to_f32(hi));
     }
     w1f[i] = v;
   } else if (i < n1 + n2) {
@@ -330,7 +330,7 @@ extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const
   CTRLV_CHECK_ARG(w1_packed && b1 && w2_packed && w1f && w2f, "ctrlv_ff_fused_pack: null pointer");
   const long n = (long)kChunks * (kW1Pieces + 10) * 64 * 8;
   hipLaunchKernelGGL(ff_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)w1_packed, b1, (const bf16_t*)w2_packed, (bf16_t*)w1f, (bf16_t*)w2f);
+                     (const el_t*)w1_packed, b1, (const el_t*)w2_packed, (el_t*)w1f, (el_t*)w2f);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -347,7 +347,7 @@ extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, 
   FfArgs a;
   a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps;
   a.lnv = ln_V; a.ln_vdiv = ln_V ? ln_vdiv : 1; a.ln_vmod = ln_V ? ln_vmod : 1; a.ln_ldv = ln_ldv;
-  a.x = (const bf16_t*)x; a.ldx = ldx; a.w1f = (const bf16_t*)w1f; a.w2f = (const bf16_t*)w2f;
+  a.x = (const el_t*)x; a.ldx = ldx; a.w1f = (const el_t*)w1f; a.w2f = (const el_t*)w2f;
   a.o = *out_desc;
   a.vtab = nullptr; a.vdiv = 1; a.vmod = 1; a.ldv = 0;
   if (a.o.vmode) {

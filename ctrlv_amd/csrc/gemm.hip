@@ -103,10 +103,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
     int cc = (kt - tap * kpt) << 6;
 #endif
     const int wcol = tap * d.Cin + cc;
-    const bf16_t* src = (const bf16_t*)d.A;
+    const el_t* src = (const el_t*)d.A;
     int ld = d.lda;
     if (d.A2 != nullptr && cc >= d.c_split) {
-      src = (const bf16_t*)d.A2; ld = d.lda2; cc -= d.c_split;
+      src = (const el_t*)d.A2; ld = d.lda2; cc -= d.c_split;
     }
     const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
       const char* p = ok ? (const char*)(src + row * ld + cc + a_coff[q]) : zsrc;
       __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
     }
-    const bf16_t* wsrc = (const bf16_t*)d.W + wcol;
+    const el_t* wsrc = (const el_t*)d.W + wcol;
 #pragma unroll
     for (int q = 0; q < B_INSTR; ++q) {
       const char* p = b_ok[q] ? (const char*)(wsrc + b_row[q] + b_coff[q]) : zsrc;
@@ -161,16 +161,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + hsel) ^ sw) * 16;
-      bf16x8 af[TM], wf[TN];
+      elx8 af[TM], wf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_frag_base + i * 32 * 128 + coff);
+      for (int i = 0; i < TM; ++i) af[i] = *(const elx8*)(st + a_frag_base + i * 32 * 128 + coff);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + b_frag_base + j * 32 * 128 + coff);
+      for (int j = 0; j < TN; ++j) wf[j] = *(const elx8*)(st + b_frag_base + j * 32 * 128 + coff);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16(wf[j], af[i], acc[i][j]);
     }
   }
 

@@ -35,8 +35,8 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             o[e] = geglu_tab(a, g, gelu_tab);
           }
           if (ocol < d.n_store) {
-            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-            *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ocol) = pk;
+            uint2 pk = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
+            *(uint2*)((el_t*)d.out + (long)m * d.ldo + ocol) = pk;
           }
         }
       }
@@ -60,18 +60,18 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             for (int e = 0; e < 4; ++e) o[e] = o[e] * (ncol < d.n_scale2 ? d.s_acc2 : d.s_acc);
           }
           if (d.R1) {
-            const uint2 rv = *(const uint2*)((const bf16_t*)d.R1 + (long)m * d.ldr1 + ncol);
-            o[0] = __builtin_fmaf(d.s1, __uint_as_float(rv.x << 16), o[0]);
-            o[1] = __builtin_fmaf(d.s1, __uint_as_float(rv.x & 0xffff0000u), o[1]);
-            o[2] = __builtin_fmaf(d.s1, __uint_as_float(rv.y << 16), o[2]);
-            o[3] = __builtin_fmaf(d.s1, __uint_as_float(rv.y & 0xffff0000u), o[3]);
+            const uint2 rv = *(const uint2*)((const el_t*)d.R1 + (long)m * d.ldr1 + ncol);
+            o[0] = __builtin_fmaf(d.s1, el_lo_f32(rv.x), o[0]);
+            o[1] = __builtin_fmaf(d.s1, el_hi_f32(rv.x), o[1]);
+            o[2] = __builtin_fmaf(d.s1, el_lo_f32(rv.y), o[2]);
+            o[3] = __builtin_fmaf(d.s1, el_hi_f32(rv.y), o[3]);
           }
           if (d.R2) {
-            const uint2 rv = *(const uint2*)((const bf16_t*)d.R2 + (long)m * d.ldr2 + ncol);
-            o[0] = __builtin_fmaf(d.s2, __uint_as_float(rv.x << 16), o[0]);
-            o[1] = __builtin_fmaf(d.s2, __uint_as_float(rv.x & 0xffff0000u), o[1]);
-            o[2] = __builtin_fmaf(d.s2, __uint_as_float(rv.y << 16), o[2]);
-            o[3] = __builtin_fmaf(d.s2, __uint_as_float(rv.y & 0xffff0000u), o[3]);
+            const uint2 rv = *(const uint2*)((const el_t*)d.R2 + (long)m * d.ldr2 + ncol);
+            o[0] = __builtin_fmaf(d.s2, el_lo_f32(rv.x), o[0]);
+            o[1] = __builtin_fmaf(d.s2, el_hi_f32(rv.x), o[1]);
+            o[2] = __builtin_fmaf(d.s2, el_lo_f32(rv.y), o[2]);
+            o[3] = __builtin_fmaf(d.s2, el_hi_f32(rv.y), o[3]);
           }
           if (vrow) {
             const float4 vv = *(const float4*)(vrow + ncol);
@@ -84,9 +84,9 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
           if (d.out_f32 == 1) {
             *(float4*)((float*)d.out + (long)m * d.ldo + ncol) = make_float4(o[0], o[1], o[2], o[3]);
           } else {
-            uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            uint2 pk = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
             if (d.out_f32 & 2) asm volatile("" ::"v"(pk.x), "v"(pk.y));   // profiling aid: compute, do not store
-            else *(uint2*)((bf16_t*)d.out + (long)m * d.ldo + ncol) = pk;
+            else *(uint2*)((el_t*)d.out + (long)m * d.ldo + ncol) = pk;
           }
         }
       }

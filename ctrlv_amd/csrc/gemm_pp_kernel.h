@@ -98,6 +98,21 @@ __device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wb
 #ifndef CTRLV_PP_STORE_AUX
 #define CTRLV_PP_STORE_AUX 0
 #endif
+// STORE-DATA HAZARD (root cause of two "intermittent wrong dword" defects).  A buffer_store_dwordx4
+// reads its four data VGPRs over several cycles AFTER it has issued; a VALU instruction that overwrites one of them within
+// the next two issue slots replaces the bytes that leave the CU, for some lanes (the ones whose quad the store has not
+// read yet) -- seen as ZERO dwords (a zero-initialisation scheduled right behind the store: the EPI = 3 / TN = 10
+// instantiation of round 3) and as raw fp32 bit patterns in an fp16 output (a v_pk_mul_f32 of the next row pass right
+// behind it: <256,2,4,0,false,0> of the fp16 build).  LLVM's hazard recognizer knows the hazard (2 wait states on gfx940+)
+// but EXEMPTS stores whose soffset is an SGPR -- which is exactly the form this epilogue uses since its addressing moved the
+// sub-tile displacement into the scalar offset (round 3); gfx950 has the hazard for that form too.  So the two wait states
+// are written out: an `s_nop 1` that takes the stored registers as operands -- the register allocator cannot hand them to
+// another value before it, the scheduler cannot move a redefinition above it.
+__device__ __forceinline__ void store_data_hazard_guard(const u32x4_t& pv) {
+#ifndef CTRLV_PP_NO_STORE_GUARD     // A/B handle: reproduces the defect (tools/ab_build.py)
+  asm volatile("s_nop 1" ::"v"(pv));
+#endif
+}
 __device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
 #ifdef CTRLV_PP_NOSTORE
   asm volatile("" ::"v"(pv), "v"(voff), "s"(soff));
@@ -105,6 +120,7 @@ __device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_
   __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff == 0xFFFFFFFFu ? voff : ((voff + (unsigned)soff) & (unsigned)(CTRLV_PP_STORE_L2 - 16)), 0, 0);
 #else
   __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff, soff, CTRLV_PP_STORE_AUX);
+  store_data_hazard_guard(pv);
 #endif
 }
 
@@ -242,14 +258,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         if (EPI & 2) {
           float f[8];
           const u32x4_t r = q[HAS_RES ? s : 0].r1[pass];
-          unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
+          unpack_elx8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
         }
         if (EPI & 4) {
           float f[8];
           const u32x4_t r = q[HAS_RES ? s : 0].r2[pass];
-          unpack_bf16x8(make_uint4(r.x, r.y, r.z, r.w), f);
+          unpack_elx8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
         }
@@ -260,7 +276,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
             o[4 + e] += __uint_as_float(vv[pass][1][e]);
           }
         }
-        const uint4 pk = pack_bf16x8(o);
+        const uint4 pk = pack_elx8(o);
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
         pp_store_out(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
       }
@@ -299,10 +315,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           const float4 v0 = img[pass][0], v1 = img[pass][1];
           const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           const int m = m0 + i * 32 + pass * 16;
-          const uint4 pk = pack_bf16x8(o);
+          const uint4 pk = pack_elx8(o);
           const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
           __builtin_amdgcn_raw_buffer_store_b128(
               pv, rsRaw, (m < d.M && ocol < d.N) ? (unsigned)m * (unsigned)(d.ld_raw * 2) + (unsigned)(ocol * 2) : kOOB, 0, 0);
+          store_data_hazard_guard(pv);
         }
       }
     }
@@ -375,7 +392,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         const float4 v0 = img[pass][0], v1 = img[pass][1];
         const float ov[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const int m = m0 + i * 32 + pass * 16;
-        const uint4 pk = pack_bf16x8(ov);
+        const uint4 pk = pack_elx8(ov);
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
         pp_store_out(pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(ocol * 2) : kOOB, 0);
       }
@@ -667,15 +684,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
     // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
     const char* st = smem + (g & (NH - 1)) * SLOT;
-    bf16x8 af[TM][2], wf[TN][2];
+    elx8 af[TM][2], wf[TN][2];
     STAMP(t0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
 #pragma unroll
-      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const bf16x8*)(st + b_frag + n * 32 * 64 + coff_);
+      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const elx8*)(st + b_frag + n * 32 * 64 + coff_);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i][ks] = *(const bf16x8*)(st + a_frag + i * 32 * 64 + coff_);
+      for (int i = 0; i < TM; ++i) af[i][ks] = *(const elx8*)(st + a_frag + i * 32 * 64 + coff_);
     }
     STAMP(t1);
     // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
@@ -721,14 +738,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
           const f32x16 bc = bias_c(n);
 #pragma unroll
           for (int i = i0; i < i0 + HM; ++i)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], af[i][0], bc, 0, 0, 0);
+            acc[i][n] = mfma_32x32x16(wf[n][0], af[i][0], bc);
         }
       } else {
 #pragma unroll
         for (int i = i0; i < i0 + HM; ++i)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], af[i][ks], acc[i][n], 0, 0, 0);
+            acc[i][n] = mfma_32x32x16(wf[n][ks], af[i][ks], acc[i][n]);
       }
       PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);

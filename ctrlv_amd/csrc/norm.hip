@@ -19,7 +19,7 @@ struct GnShape {
   int rev_stats, rev_apply;       // walk the images / chunks from the END (which workgroup reads what first; results unchanged)
 };
 
-__device__ __forceinline__ uint4 gn_load(const bf16_t* x, const bf16_t* x2, int c_split, int C, long row, int c0) {
+__device__ __forceinline__ uint4 gn_load(const el_t* x, const el_t* x2, int c_split, int C, long row, int c0) {
   if (x2 != nullptr && c0 >= c_split) return *(const uint4*)(x2 + row * (C - c_split) + (c0 - c_split));
   const int ld = x2 != nullptr ? c_split : C;
   return *(const uint4*)(x + row * ld + c0);
@@ -30,7 +30,7 @@ __device__ __forceinline__ uint4 gn_load(const bf16_t* x, const bf16_t* x2, int 
 // a column, so all partial sums of a channel share their pilot): with |mean| >> std, E[x^2] - mean^2 would cancel in
 // fp32, the shifted sums do not.  32 threads then turn the channel sums of their group into the chunk's
 // (mean_c, M2_c) with Chan's pairwise update (equal counts per channel).
-__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
+__global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnShape s,
                                 float* __restrict__ partials) {
   extern __shared__ float red[];  // [RPP][C][2] sums, then [C] pilots
   const int tid = threadIdx.x;
@@ -45,7 +45,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   {
     const uint4 pv = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r0, c0);
     float pf[8];
-    unpack_bf16x8(pv, pf);
+    unpack_elx8(pv, pf);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       piv2[e] = f32x2_t{pf[2 * e], pf[2 * e + 1]};
@@ -55,7 +55,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   }
   auto accum = [&](const uint4& v) {
     float f[8];
-    unpack_bf16x8(v, f);
+    unpack_elx8(v, f);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const f32x2_t dl = f32x2_t{f[2 * e], f[2 * e + 1]} - piv2[e];
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(GnShape s, const floa
   }
 }
 
-__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ x2, GnShape s,
+__global__ void gn_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnShape s,
                                 const float* __restrict__ stats, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, int silu, bf16_t* __restrict__ y) {
+                                const float* __restrict__ beta, int silu, el_t* __restrict__ y) {
   const int tid = threadIdx.x;
   const int n = s.rev_apply ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int chunk = s.rev_apply ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
@@ -171,13 +171,13 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __re
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   auto apply_row = [&](const uint4& v, long row) {
     float f[8];
-    unpack_bf16x8(v, f);
+    unpack_elx8(v, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = f[e] * a[e] + b[e];
       f[e] = silu ? silu_f(t) : t;
     }
-    *(uint4*)(y + row * s.C + c0) = pack_bf16x8(f);
+    *(uint4*)(y + row * s.C + c0) = pack_elx8(f);
   };
   int r = r0 + rsub;
   for (; r + 3 * s.RPP < r1; r += 4 * s.RPP) {      // four loads in flight per lane, as in the statistics pass
@@ -231,10 +231,10 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 template <int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, int M, int C,
+__global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, int M, int C,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
-                                                 bf16_t* __restrict__ y) {
+                                                 el_t* __restrict__ y) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int CV = C >> 3;
   float g[NV][8], b[NV][8];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, i
       const int cv = lane + k * 64;
       if (cv < CV) {
         const uint4 v = cur[k];
-        unpack_bf16x8(v, f[k]);
+        unpack_elx8(v, f[k]);
         if (vrow) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[k][e] += vrow[cv * 8 + e];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, i
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f[k][e] - mean) * rstd * g[k][e] + b[k][e];
-        *(uint4*)(y + m * C + cv * 8) = pack_bf16x8(o);
+        *(uint4*)(y + m * C + cv * 8) = pack_elx8(o);
       }
     }
   }
@@ -311,11 +311,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, i
 // mid block: scores come from a GEMM, P feeds the P.V GEMM).  One workgroup per row, the row held in registers between the
 // max / sum passes (cols <= 256 x 64); base-2 exponentials of (s - max) * log2(e).
 constexpr int kSmxPer = 64;
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int cols, long lds, bf16_t* __restrict__ p,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int cols, long lds, el_t* __restrict__ p,
                                                            long ldp) {
   __shared__ float red[8];
   const float* row = s + (long)blockIdx.x * lds;
-  bf16_t* out = p + (long)blockIdx.x * ldp;
+  el_t* out = p + (long)blockIdx.x * ldp;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float v[kSmxPer];
   float mx = -INFINITY;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int k = 0; k < kSmxPer; k += 4) {
     const int c = (k / 4 * 256 + tid) * 4;
     if (c < cols)
-      *(uint2*)(out + c) = make_uint2(pack_bf16x2(v[k] * inv, v[k + 1] * inv), pack_bf16x2(v[k + 2] * inv, v[k + 3] * inv));
+      *(uint2*)(out + c) = make_uint2(pack_elx2(v[k] * inv, v[k + 1] * inv), pack_elx2(v[k + 2] * inv, v[k + 3] * inv));
   }
 }
 
@@ -358,7 +358,7 @@ extern "C" int ctrlv_softmax_rows(const float* scores, int rows, int cols, long 
   CTRLV_CHECK_SHAPE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= kSmxPer * 256 && ld_scores % 4 == 0 && ld_probs % 4 == 0,
                     "softmax_rows: cols=%d must be a multiple of 4, <= %d", cols, kSmxPer * 256);
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, cols, ld_scores,
-                     (bf16_t*)probs, ld_probs);
+                     (el_t*)probs, ld_probs);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -378,7 +378,7 @@ extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split,
   const int nt = s.CV * s.RPP;
   const size_t smem = ((size_t)s.RPP * C * 2 + C) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)x2, s, partials);
+                     (const el_t*)x, (const el_t*)x2, s, partials);
   CTRLV_LAUNCH_CHECK();
   // (mean, rstd) per (statistics row, group), behind the chunk partials
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat), dim3(1024), 0, (hipStream_t)stream, s, partials,
@@ -395,8 +395,8 @@ extern "C" int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split,
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
   const int nt = s.CV * s.RPP;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (const bf16_t*)x2, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (bf16_t*)y);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                     (const el_t*)x2, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (el_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -411,8 +411,8 @@ extern "C" int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, 
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipStream_t st = (hipStream_t)stream;
 #define LN_LAUNCH(NV)                                                                                             \
-  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, M, C, gamma, beta, \
-                     eps, V, vdiv, vmod, ldv, (bf16_t*)y)
+  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, M, C, gamma, beta, \
+                     eps, V, vdiv, vmod, ldv, (el_t*)y)
   switch (nv) {
     case 1: LN_LAUNCH(1); break;
     case 2: LN_LAUNCH(2); break;

@@ -40,14 +40,14 @@ __device__ __forceinline__ int row_map(int n, int N, int geglu) {
 // dst[(n_off + rowmap(n)) * ld + tap * cp + c_off + c] = src[(n * C + c) * taps + tap]   (dst pre-zeroed)
 // covers nn.Linear / 1x1 conv (taps 1), Conv2d 3x3 (taps 9, tap = ky*3+kx), Conv3d (3,1,1) (taps 3), the shared
 // conv_in | control_conv_in im2col slots (cp = slot width, c_off = slot offset) and row concatenation (n_off).
-__global__ void pack_weight_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps, bf16_t* __restrict__ dst,
+__global__ void pack_weight_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps, el_t* __restrict__ dst,
                                    int ld, int cp, int c_off, int n_off, int geglu) {
   const long total = (long)N * C * taps;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
     const long nc = i / taps;
     const int c = (int)(nc % C), n = (int)(nc / C);
-    dst[(long)(n_off + row_map(n, N, geglu)) * ld + tap * cp + c_off + c] = f32_to_bf16(ld_any(src, dtype, i));
+    dst[(long)(n_off + row_map(n, N, geglu)) * ld + tap * cp + c_off + c] = f32_to_el(ld_any(src, dtype, i));
   }
 }
 // Role-swapped (dgrad) form of a weight: dst[c][(taps - 1 - tap) * Np + n] = src[(n * C + c) * taps + tap]  -- taps
@@ -55,7 +55,7 @@ __global__ void pack_weight_kernel(const void* __restrict__ src, int dtype, int 
 // A transpose: 32 output rows n x 64 consecutive (c, tap) source elements per workgroup go through LDS, so that reads are
 // contiguous along a source row and writes are 32 consecutive n (64 B) per (c, tap).   grid (ceil(C*taps/64), ceil(Np/32))
 __global__ __launch_bounds__(256) void pack_weight_swapped_kernel(const void* __restrict__ src, int dtype, int N, int C,
-                                                                  int taps, int Np, bf16_t* __restrict__ dst, int ld) {
+                                                                  int taps, int Np, el_t* __restrict__ dst, int ld) {
   __shared__ float tile[32][65];
   const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 32, ktot = C * taps;
   for (int i = threadIdx.x; i < 32 * 64; i += 256) {
@@ -67,17 +67,17 @@ __global__ __launch_bounds__(256) void pack_weight_swapped_kernel(const void* __
     const int kk = i >> 5, r = i & 31, k = k0 + kk, n = n0 + r;
     if (k >= ktot || n >= Np) continue;
     const int c = k / taps, tap = k - c * taps;
-    dst[(long)c * ld + (long)(taps - 1 - tap) * Np + n] = f32_to_bf16(tile[r][kk]);
+    dst[(long)c * ld + (long)(taps - 1 - tap) * Np + n] = f32_to_el(tile[r][kk]);
   }
 }
 // Forward form with coalesced writes: dst[rowmap(n)][tap * C + c] = src[(n * C + c) * taps + tap]   grid (ceil(taps*C/256), N)
 __global__ void pack_weight_rows_kernel(const void* __restrict__ src, int dtype, int N, int C, int taps,
-                                        bf16_t* __restrict__ dst, int ld, int geglu) {
+                                        el_t* __restrict__ dst, int ld, int geglu) {
   const int n = blockIdx.y;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= taps * C) return;
   const int tap = k / C, c = k - tap * C;
-  dst[(long)row_map(n, N, geglu) * ld + k] = f32_to_bf16(ld_any(src, dtype, ((long)n * C + c) * taps + tap));
+  dst[(long)row_map(n, N, geglu) * ld + k] = f32_to_el(ld_any(src, dtype, ((long)n * C + c) * taps + tap));
 }
 __global__ void pack_vector_kernel(const void* __restrict__ src, int dtype, int N, float* __restrict__ dst, int n_off,
                                    int geglu, int accumulate) {
@@ -100,7 +100,7 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ plan data
 struct Linear {      // packed GEMM weight: bf16 [n][k] (n % 32 == 0, k % 64 == 0 for taps == 1) + fp32 bias [n] (or null)
-  bf16_t* w = nullptr;
+  el_t* w = nullptr;
   float* b = nullptr;
   int n = 0, k = 0;  // padded rows, total K (taps * cin)
 };
@@ -118,8 +118,8 @@ struct ResBlock {
 };
 struct FeedFwd {
   Linear proj, out;
-  bf16_t* w1f = nullptr;      // C = 320 only: the fragment-major forms of ctrlv_ff_fused (ff_fused.hip), else null
-  bf16_t* w2f = nullptr;
+  el_t* w1f = nullptr;      // C = 320 only: the fragment-major forms of ctrlv_ff_fused (ff_fused.hip), else null
+  el_t* w2f = nullptr;
 };
 struct Transformer {
   int C = 0;
@@ -443,7 +443,7 @@ struct Ctx {
     if (!dry && off > cap) overflow = true;
     return base + o;
   }
-  bf16_t* rows(long m, int c) { return (bf16_t*)alloc((size_t)m * c * 2); }
+  el_t* rows(long m, int c) { return (el_t*)alloc((size_t)m * c * 2); }
   size_t mark() const { return off; }
   void release(size_t m) { off = m; }
 };
@@ -463,8 +463,8 @@ int gemm(Ctx& c, const ctrlv_gemm_desc& d) {
   if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
   return ctrlv_gemm(&d, c.st);
 }
-int groupnorm(Ctx& c, const bf16_t* x, const bf16_t* x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
-              float eps, int silu, bf16_t* y) {
+int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
+              float eps, int silu, el_t* y) {
   const int chunks = ctrlv_groupnorm_chunks(n_img, S, C, ips);
   if (chunks < 0) return chunks;
   const size_t m = c.mark();
@@ -478,42 +478,42 @@ int groupnorm(Ctx& c, const bf16_t* x, const bf16_t* x2, int c_split, int n_img,
   c.release(m);          // stream order keeps the scratch alive until the apply pass has read it
   return rc;
 }
-int layernorm(Ctx& c, const bf16_t* x, int M, int C, const Norm& nm, bf16_t* y, const float* V = nullptr, int vdiv = 1,
+int layernorm(Ctx& c, const el_t* x, int M, int C, const Norm& nm, el_t* y, const float* V = nullptr, int vdiv = 1,
               int vmod = 1 << 30, int ldv = 0) {
   if (c.dry) return CTRLV_OK;
   return ctrlv_layernorm(x, M, C, nm.g, nm.b, 1e-5f, V, vdiv, vmod, ldv, y, c.st);
 }
 
 // ---- SpatioTemporalResBlock (blocks.py::SpatioTemporalResBlock.run)
-int run_res(Ctx& c, const ResBlock& r, const bf16_t* x, const bf16_t* x2, int c1, int H, int W, bf16_t** out_) {
+int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, int H, int W, el_t** out_) {
   const int N = c.B * c.F, S = H * W, F = c.F;
   const long M = (long)N * S;
   const int cin = r.cin, cout = r.cout;
-  bf16_t* out = c.rows(M, cout);
+  el_t* out = c.rows(M, cout);
   const size_t mk = c.mark();
   const int lda_x = x2 ? c1 : cin;
-  bf16_t* xn = c.rows(M, cin);
+  el_t* xn = c.rows(M, cin);
   TRY(groupnorm(c, x, x2, x2 ? c1 : 0, N, S, cin, 1, r.n1, r.eps, 1, xn));
-  bf16_t* h = c.rows(M, cout);
+  el_t* h = c.rows(M, cout);
   {
     ctrlv_gemm_desc d = gd(xn, cin, r.c1, h, cout, (int)M, cout, cin, cout);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1; d.up = 0;
     d.V = c.temb + r.temb_off[0]; d.ldv = c.ldtemb; d.vmode = 1; d.vdiv = F * S;
     TRY(gemm(c, d));
   }
-  bf16_t* hn = c.rows(M, cout);
+  el_t* hn = c.rows(M, cout);
   TRY(groupnorm(c, h, nullptr, 0, N, S, cout, 1, r.n2, r.eps, 1, hn));
-  const bf16_t* res = x;
+  const el_t* res = x;
   int ldres = cin;
   if (r.has_sc) {
-    bf16_t* rs = c.rows(M, cout);
+    el_t* rs = c.rows(M, cout);
     ctrlv_gemm_desc d = gd(x, lda_x, r.sc, rs, cout, (int)M, cout, cin, cout);
     if (x2) { d.A2 = x2; d.lda2 = cin - c1; d.c_split = c1; }
     TRY(gemm(c, d));
     res = rs;
     ldres = cout;
   }
-  bf16_t* xs = c.rows(M, cout);
+  el_t* xs = c.rows(M, cout);
   {
     ctrlv_gemm_desc d = gd(hn, cout, r.c2, xs, cout, (int)M, cout, cout, cout);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1;
@@ -544,9 +544,9 @@ int frame_embedding(Ctx& c, const Transformer& t, int F, float* e) {
   const int C = t.C, kp = t.tpe1.k;
   const size_t mk = c.mark();
   float* ar = (float*)c.alloc((size_t)F * 4);
-  bf16_t* te = c.rows(F, kp);
-  bf16_t* hh = c.rows(F, 4 * C);
-  bf16_t* tmp = kp != C ? c.rows(F, C) : nullptr;
+  el_t* te = c.rows(F, kp);
+  el_t* hh = c.rows(F, 4 * C);
+  el_t* tmp = kp != C ? c.rows(F, C) : nullptr;
   if (!c.dry) {
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small"); return CTRLV_E_BAD_ARG; }
     hipLaunchKernelGGL(arange_kernel, dim3((F + 63) / 64), dim3(64), 0, c.st, ar, F);
@@ -602,12 +602,12 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
     const int mc = M - m0 < rows ? M - m0 : rows;
     ctrlv_gemm_desc p = proj, o = outd;
     p.M = o.M = mc;
-    p.A = (const bf16_t*)proj.A + (long)m0 * proj.lda;
-    p.out = (bf16_t*)proj.out + (long)m0 * proj.ldo;
-    o.A = (const bf16_t*)outd.A + (long)m0 * outd.lda;
-    o.out = (bf16_t*)outd.out + (long)m0 * outd.ldo;
-    if (outd.R1) o.R1 = (const bf16_t*)outd.R1 + (long)m0 * outd.ldr1;
-    if (outd.R2) o.R2 = (const bf16_t*)outd.R2 + (long)m0 * outd.ldr2;
+    p.A = (const el_t*)proj.A + (long)m0 * proj.lda;
+    p.out = (el_t*)proj.out + (long)m0 * proj.ldo;
+    o.A = (const el_t*)outd.A + (long)m0 * outd.lda;
+    o.out = (el_t*)outd.out + (long)m0 * outd.ldo;
+    if (outd.R1) o.R1 = (const el_t*)outd.R1 + (long)m0 * outd.ldr1;
+    if (outd.R2) o.R2 = (const el_t*)outd.R2 + (long)m0 * outd.ldr2;
     TRY(gemm(c, p));
     TRY(gemm(c, o));
   }
@@ -618,8 +618,8 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
 // prologue (ctrlv_ff_fused_ln: one launch and one write + read of the activation less).  Measured equal in the model
 // (224.2 vs 224.2 and 230.3 vs 230.4 ms per step, three alternations each: the LayerNorm family drops 7.9 -> 5.3 ms, the
 // fused kernel's per-tile prologue takes it back), so the default keeps ctrlv_layernorm in front of the fused kernel.
-int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const bf16_t* xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
-          bf16_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C) {
+int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const el_t* xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
+          el_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C) {
   static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
   static const bool fold = [] { const char* e = getenv("CTRLV_FF_LN"); return e && atoi(e) != 0; }();
   if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
@@ -633,10 +633,10 @@ int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const bf16_t* xraw, const fl
 }
 
 // ---- TransformerSpatioTemporalModel (blocks.py::TransformerSpatioTemporalModel.run)
-int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t** out_) {
+int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out_) {
   const int B = c.B, F = c.F, C = t.C, N = B * F, S = H * W;
   const long M = (long)N * S;
-  bf16_t* out = c.rows(M, C);
+  el_t* out = c.rows(M, C);
   const size_t mk = c.mark();
   const float* emb = t.frame_emb;
   if (F != c.p->cfg.num_frames || emb == nullptr) {
@@ -644,29 +644,29 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     TRY(frame_embedding(c, t, F, e));
     emb = e;
   }
-  bf16_t* tt = c.rows(M, C);
+  el_t* tt = c.rows(M, C);
   TRY(groupnorm(c, x, nullptr, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
-  bf16_t* h0 = c.rows(M, C);
+  el_t* h0 = c.rows(M, C);
   TRY(gemm(c, gd(tt, C, t.pin, h0, C, (int)M, C, C, C)));
   // ---- spatial BasicTransformerBlock
   TRY(layernorm(c, h0, (int)M, C, t.s_ln1, tt));
-  bf16_t* qkv = c.rows(M, 3 * C);
+  el_t* qkv = c.rows(M, 3 * C);
   {
     ctrlv_gemm_desc d = gd(tt, C, t.s_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C);
     d.n_scale2 = C; d.s_acc2 = 0.125f * 1.44269504088896340736f;      // q block pre-scaled: (1/sqrt(64)) log2(e)
     TRY(gemm(c, d));
   }
-  bf16_t* a = c.rows(M, C);
+  el_t* a = c.rows(M, C);
   if (!c.dry) TRY(ctrlv_attention_spatial_prescaled(qkv, a, N, S, C, c.st));
-  bf16_t* h1 = c.rows(M, C);
+  el_t* h1 = c.rows(M, C);
   {   // attn2 with one key == to_out(to_v(ehs[b])) for every query: a per-clip row vector
     ctrlv_gemm_desc d = gd(a, C, t.s_o, h1, C, (int)M, C, C, C);
     d.R1 = h0; d.ldr1 = C;
     d.V = c.xattn + t.xattn_off[0]; d.ldv = c.ldx; d.vmode = 1; d.vdiv = F * S;
     TRY(gemm(c, d));
   }
-  bf16_t* u = c.rows(M, 4 * C);
-  bf16_t* h2 = h0;      // h0 is dead from here on
+  el_t* u = c.rows(M, 4 * C);
+  el_t* h2 = h0;      // h0 is dead from here on
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
@@ -675,7 +675,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
-  bf16_t* g0 = h1;      // h1 is dead
+  el_t* g0 = h1;      // h1 is dead
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
@@ -687,7 +687,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
   if (!c.dry) TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
-  bf16_t* g1 = c.rows(M, C);
+  el_t* g1 = c.rows(M, C);
   {
     ctrlv_gemm_desc d = gd(a, C, t.t_o, g1, C, (int)M, C, C, C);
     d.R1 = g0; d.ldr1 = C;
@@ -696,7 +696,7 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
     else d.vmode = 1;
     TRY(gemm(c, d));
   }
-  bf16_t* h3 = g0;
+  el_t* h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
@@ -715,11 +715,11 @@ int run_tr(Ctx& c, const Transformer& t, const bf16_t* x, int H, int W, bf16_t**
   return CTRLV_OK;
 }
 
-int run_resample(Ctx& c, const Resample& r, const bf16_t* x, int H, int W, bool up, bf16_t** out_, int* Ho_, int* Wo_) {
+int run_resample(Ctx& c, const Resample& r, const el_t* x, int H, int W, bool up, el_t** out_, int* Ho_, int* Wo_) {
   const int N = c.B * c.F;
   const int Ho = up ? 2 * H : (H + 2 - 3) / 2 + 1, Wo = up ? 2 * W : (W + 2 - 3) / 2 + 1;
   const long M = (long)N * Ho * Wo;
-  bf16_t* out = c.rows(M, r.C);
+  el_t* out = c.rows(M, r.C);
   ctrlv_gemm_desc d = gd(x, r.C, r.conv, out, r.C, (int)M, r.C, r.C, r.C);
   d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = Ho; d.Wo = Wo; d.stride = up ? 1 : 2; d.up = up ? 1 : 0;
   TRY(gemm(c, d));
@@ -727,7 +727,7 @@ int run_resample(Ctx& c, const Resample& r, const bf16_t* x, int H, int W, bool 
   return CTRLV_OK;
 }
 
-struct Tap { bf16_t* x; int H, W, C; };
+struct Tap { el_t* x; int H, W, C; };
 
 // ---- embeddings + per-clip row-vector tables (encoder.py::_context)
 int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* ehs, const float* ids32, int n_ids) {
@@ -741,13 +741,13 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
                     cfg.projection_class_embeddings_input_dim, add_dim * n_ids);
   float* t32 = (float*)c.alloc((size_t)B * 4);
   const int kt = p->te1.k, ka = p->ae1.k, kx = p->xv.k;
-  bf16_t* te = c.rows(B, kt);
-  bf16_t* ae = c.rows(B, ka);
-  bf16_t* te_tmp = kt != boc0 ? c.rows(B, boc0) : nullptr;
-  bf16_t* ae_tmp = ka != n_ids * add_dim ? c.rows((long)B * n_ids, add_dim) : nullptr;
-  bf16_t* h = c.rows(B, ted);
-  bf16_t* emb_t = c.rows(B, ted);
-  bf16_t* emb_s = c.rows(B, ted);
+  el_t* te = c.rows(B, kt);
+  el_t* ae = c.rows(B, ka);
+  el_t* te_tmp = kt != boc0 ? c.rows(B, boc0) : nullptr;
+  el_t* ae_tmp = ka != n_ids * add_dim ? c.rows((long)B * n_ids, add_dim) : nullptr;
+  el_t* h = c.rows(B, ted);
+  el_t* emb_t = c.rows(B, ted);
+  el_t* emb_s = c.rows(B, ted);
   c.ldtemb = p->temb.n;
   c.temb = (float*)c.alloc((size_t)B * c.ldtemb * 4);
   if (!c.dry) {
@@ -782,8 +782,8 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
   { ctrlv_gemm_desc d = gd(emb_s, ted, p->temb, c.temb, c.ldtemb, B, p->temb.n, ted, c.ldtemb); d.out_f32 = 1; TRY(gemm(c, d)); }
   if (p->xattn_n) {
     const int dc = cfg.cross_attention_dim, nx = p->xv.n;
-    bf16_t* e = c.rows(B, kx);
-    bf16_t* v_all = c.rows(B, nx);
+    el_t* e = c.rows(B, kx);
+    el_t* v_all = c.rows(B, nx);
     c.ldx = nx;
     c.xattn = (float*)c.alloc((size_t)B * nx * 4);
     if (!c.dry) {
@@ -803,13 +803,13 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
 }
 
 // conv_in (+ control_conv_in) as ONE im2col GEMM over the [conv_in channels | control channels | pad] slots
-int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h, int w, bf16_t** out_) {
+int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h, int w, el_t** out_) {
   ctrlv_plan* p = c.p;
   const int N = c.B * c.F, cin = p->cfg.in_channels, c0 = p->cfg.block_out_channels[0];
   const long M = (long)N * h * w;
-  bf16_t* x16 = c.rows(M, p->cin_cp);
-  bf16_t* col = c.rows(M, p->cin_kp);
-  bf16_t* x = c.rows(M, c0);
+  el_t* x16 = c.rows(M, p->cin_cp);
+  el_t* col = c.rows(M, p->cin_kp);
+  el_t* x = c.rows(M, c0);
   if (!c.dry) {
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     CTRLV_HIP_TRY(hipMemsetAsync(x16, 0, (size_t)M * p->cin_cp * 2, c.st));
@@ -822,26 +822,26 @@ int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h,
   return CTRLV_OK;
 }
 
-int run_down_mid(Ctx& c, bf16_t* x, int h, int w, std::vector<Tap>& taps, bf16_t** mid_, int* H_, int* W_) {
+int run_down_mid(Ctx& c, el_t* x, int h, int w, std::vector<Tap>& taps, el_t** mid_, int* H_, int* W_) {
   ctrlv_plan* p = c.p;
   int H = h, W = w;
   taps.push_back({x, H, W, p->cfg.block_out_channels[0]});
   for (auto& b : p->down) {
     for (size_t j = 0; j < b.res.size(); ++j) {
-      bf16_t* y;
+      el_t* y;
       TRY(run_res(c, b.res[j], x, nullptr, 0, H, W, &y));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
       taps.push_back({x, H, W, b.res[j].cout});
     }
     if (b.down.present) {
-      bf16_t* y; int Ho, Wo;
+      el_t* y; int Ho, Wo;
       TRY(run_resample(c, b.down, x, H, W, false, &y, &Ho, &Wo));
       x = y; H = Ho; W = Wo;
       taps.push_back({x, H, W, b.down.C});
     }
   }
-  bf16_t* y;
+  el_t* y;
   TRY(run_res(c, p->mid_r0, x, nullptr, 0, H, W, &y)); x = y;
   TRY(run_tr(c, p->mid_attn, x, H, W, &y)); x = y;
   TRY(run_res(c, p->mid_r1, x, nullptr, 0, H, W, &y)); x = y;
@@ -863,7 +863,7 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
                  int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  bf16_t* x;
+  el_t* x;
   TRY(run_input(c, dtype, sample, nullptr, h, w, &x));
   std::vector<Tap> taps;
   int H, W;
@@ -883,22 +883,22 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
     for (size_t j = 0; j < b.res.size(); ++j) {
       const Tap skip = taps.back();
       taps.pop_back();
-      bf16_t* y;
+      el_t* y;
       TRY(run_res(c, b.res[j], x, skip.x, b.res[j].cin - skip.C, H, W, &y));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
     }
     if (b.up.present) {
-      bf16_t* y; int Ho, Wo;
+      el_t* y; int Ho, Wo;
       TRY(run_resample(c, b.up, x, H, W, true, &y, &Ho, &Wo));
       x = y; H = Ho; W = Wo;
     }
   }
   const int c0 = p->cfg.block_out_channels[0], co = p->cfg.out_channels, co_p = pad_to(co, 4);
   const long M = (long)N * H * W;
-  bf16_t* xn = c.rows(M, c0);
+  el_t* xn = c.rows(M, c0);
   TRY(groupnorm(c, x, nullptr, 0, N, H * W, c0, 1, p->gno, 1e-5f, 1, xn));       // :161-163
-  bf16_t* y = c.rows(M, co_p);
+  el_t* y = c.rows(M, co_p);
   {
     ctrlv_gemm_desc d = gd(xn, c0, p->cout, y, co_p, (int)M, p->cout.n, c0, co_p);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1;
@@ -913,7 +913,7 @@ int controlnet_forward(ctrlv_plan* p, Ctx& c, const void* sample, const void* co
                        void* out_mid, int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  bf16_t* x;
+  el_t* x;
   TRY(run_input(c, dtype, sample, control, h, w, &x));
   std::vector<Tap> taps;
   int H, W;
@@ -955,12 +955,12 @@ extern "C" int ctrlv_pack_weight(const void* src, int src_dtype, int N, int C, i
   if (form == 0) {
     CTRLV_CHECK_SHAPE(ld_dst >= taps * C && (!geglu || N % 32 == 0), "pack_weight: ld_dst < taps * C (or odd GEGLU rows)");
     hipLaunchKernelGGL(pack_weight_rows_kernel, dim3((taps * C + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, src,
-                       src_dtype, N, C, taps, (bf16_t*)dst, ld_dst, geglu);
+                       src_dtype, N, C, taps, (el_t*)dst, ld_dst, geglu);
   } else {
     CTRLV_CHECK_SHAPE(ld_dst % taps == 0 && ld_dst / taps >= N && !geglu, "pack_weight: ld_dst must be taps * Np, Np >= N");
     const int Np = ld_dst / taps;
     hipLaunchKernelGGL(pack_weight_swapped_kernel, dim3((taps * C + 63) / 64, (Np + 31) / 32), dim3(256), 0,
-                       (hipStream_t)stream, src, src_dtype, N, C, taps, Np, (bf16_t*)dst, ld_dst);
+                       (hipStream_t)stream, src, src_dtype, N, C, taps, Np, (el_t*)dst, ld_dst);
   }
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
@@ -1177,7 +1177,7 @@ static int unet_encoder(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, co
                         const float* ids, int n_ids, void* const* out_taps, void* out_mid, int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  bf16_t* x;
+  el_t* x;
   TRY(run_input(c, dtype, sample, nullptr, h, w, &x));
   std::vector<Tap> taps;
   int H, W;

@@ -319,16 +319,17 @@ class TransformerSpatioTemporalModel(nn.Module):
         """time_pos_embed(time_proj(arange(F))) -> fp32 [F, C]; depends on the weights and F only."""
         if F not in self._frame_emb:
             C, pk = self.C, self._pk
+            el = pk["tpe"][0].dtype
             t = torch.arange(F, dtype=torch.float32, device=device)
             kp = pk["tpe"][0].shape[1]
-            te = torch.zeros(F, kp, dtype=torch.bfloat16, device=device)
+            te = torch.zeros(F, kp, dtype=el, device=device)
             if kp == C:
                 ops.timestep_embedding(t, C, te)
             else:
-                tmp = torch.empty(F, C, dtype=torch.bfloat16, device=device)
+                tmp = torch.empty(F, C, dtype=el, device=device)
                 ops.timestep_embedding(t, C, tmp)
                 te[:, :C] = tmp
-            h = torch.empty(F, 4 * C, dtype=torch.bfloat16, device=device)
+            h = torch.empty(F, 4 * C, dtype=el, device=device)
             ops.gemm(te, pk["tpe"][0], h, N=4 * C, cin=kp, bias=pk["tpe"][1], act=1)
             e = torch.empty(F, C, dtype=torch.float32, device=device)
             ops.gemm(h, pk["tpe"][2], e, N=C, cin=4 * C, bias=pk["tpe"][3], out_f32=True)

@@ -124,7 +124,8 @@ class ControlNetModel(SpatioTemporalEncoderBase):
         t32, ehs, ids32 = self._plan_inputs(sample, timestep, encoder_hidden_states, added_time_ids)
         control = control_cond.to(device=sample.device, dtype=sample.dtype).contiguous()
         shapes = [plan.residual_shape(i, B, F, h, w) for i in range(plan.n_down + 1)]
-        rows = [torch.empty(M, C, dtype=torch.bfloat16, device=sample.device) for M, C in shapes]
+        el = self.el_dtype
+        rows = [torch.empty(M, C, dtype=el, device=sample.device) for M, C in shapes]
         plan.controlnet_forward(sample.contiguous(), control, t32, ehs, ids32, float(conditioning_scale), rows[:-1],
                                 rows[-1], lane=getattr(self, "_lane", 0))
 
@@ -135,7 +136,7 @@ class ControlNetModel(SpatioTemporalEncoderBase):
             while hh * (w * hh // h) != s:     # recover (H, W) of the level from its pixel count
                 hh //= 2
             o = o.view(N, hh, s // hh, C).permute(0, 3, 1, 2)
-            return o if sample.dtype == torch.bfloat16 else o.to(sample.dtype)
+            return o if sample.dtype == el else o.to(sample.dtype)
 
         outs = [view(o, M) for o, (M, _) in zip(rows, shapes)]
         down, mid = outs[:-1], outs[-1]
@@ -177,10 +178,10 @@ class ControlNetModel(SpatioTemporalEncoderBase):
 
         def zero_conv(rows, hh, ww, wb):                                                       # :331-344
             C = rows.shape[1]
-            o = torch.empty(rows.shape[0], C, dtype=torch.bfloat16, device=rows.device)
+            o = torch.empty(rows.shape[0], C, dtype=rows.dtype, device=rows.device)
             ops.gemm(rows, wb[0], o, N=wb[0].shape[0], cin=C, bias=wb[1], s_acc=scale)
             o = o.view(N, hh, ww, C).permute(0, 3, 1, 2)       # (N, C, H, W) shape, channels-last strides
-            return o if sample.dtype == torch.bfloat16 else o.to(sample.dtype)
+            return o if sample.dtype == o.dtype else o.to(sample.dtype)
 
         down = [zero_conv(r, hh, ww, wb) for (r, hh, ww), wb in zip(taps, pk["zc"])]
         mid = zero_conv(x, H, W, pk["zc_mid"])

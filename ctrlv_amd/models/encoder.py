@@ -104,6 +104,13 @@ class SpatioTemporalEncoderBase(HipModelMixin):
                 self._packed = False                     # (also drops the plan)
             object.__setattr__(self, "_packed_fp", fp)
 
+    @property
+    def el_dtype(self):
+        """Element type of this model's activations / packed weights: fp16 parameters run on libctrlv_hip_f16.so (the
+        reference's autocast dtype), everything else (bf16 parameters, the fp32 masters of a training step) on the bf16
+        library."""
+        return torch.float16 if self.dtype == torch.float16 else torch.bfloat16
+
     # ------------------------------------------------------------------------------------------- C++ plan
     def _use_plan(self):
         return (self.executor == "plan" and getattr(self, "_trace", None) is None and _prof._active is None)
@@ -111,15 +118,18 @@ class SpatioTemporalEncoderBase(HipModelMixin):
     def _ensure_plan(self, sample):
         """The C++ execution plan of this model (csrc/plan.hip): created and loaded with the current parameters on first
         use, rebuilt after .to() / load_state_dict()."""
-        _lib.load()                               # raises if the HIP library is missing: no fallback
+        el = self.el_dtype
+        _lib.load(el)                             # raises if the HIP library is missing: no fallback
         if not sample.is_cuda:
             raise _lib.CtrlvHipError("ctrlv_amd models run on a HIP device only; there is no CPU forward "
                                      f"(got a {sample.device} input)")
         if self.device != sample.device:
             raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
         self._check_params_unchanged()
+        if self._plan is not None and self._plan.dtype != el:
+            object.__setattr__(self, "_plan", None)
         if self._plan is None:
-            plan = Plan(self._plan_kind, self.config, sample.device, self.time_context_order)
+            plan = Plan(self._plan_kind, self.config, sample.device, self.time_context_order, dtype=el)
             plan.load_state_dict(self.state_dict())
             object.__setattr__(self, "_plan", plan)
             self._plan_order = self.time_context_order
@@ -156,7 +166,12 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         return []
 
     def pack(self):
-        """(Re)build every packed bf16 weight buffer from the current parameters."""
+        """(Re)build every packed weight buffer (element type `el_dtype`) from the current parameters."""
+        with packing.element_dtype(self.el_dtype):
+            self._pack()
+        self._pk_el = self.el_dtype
+
+    def _pack(self):
         res_blocks, transformers = [], []
         for m in self.modules():
             if isinstance(m, SpatioTemporalResBlock):
@@ -208,14 +223,15 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         pass
 
     def _ensure_ready(self, sample):
-        _lib.load()                               # raises if the HIP library is missing: no fallback
+        el = self.el_dtype
+        _lib.load(el)                             # raises if the HIP library is missing: no fallback
         if not sample.is_cuda:
             raise _lib.CtrlvHipError("ctrlv_amd models run on a HIP device only; there is no CPU forward "
                                      f"(got a {sample.device} input)")
         if self.device != sample.device:
             raise ValueError(f"model is on {self.device} but the input is on {sample.device}")
         self._check_params_unchanged()
-        if not self._packed:
+        if not self._packed or getattr(self, "_pk_el", None) != el:
             self.pack()
         # one activation arena per execution lane: DenoiseStepper runs the two CFG halves of a step as concurrent
         # forwards of this one model (shared packed weights) on different streams
@@ -225,25 +241,26 @@ class SpatioTemporalEncoderBase(HipModelMixin):
             ws = self._wss[lane] = Workspace(sample.device)
         if lane == 0:
             self._ws = ws
+        ws.el = el
         ws.reset()
         return ws
 
     # ------------------------------------------------------------------------------------------- embeddings
     @staticmethod
-    def _sinusoid(t32, dim, kpad, device):
+    def _sinusoid(t32, dim, kpad, device, el=torch.bfloat16):
         n = t32.numel()
         if kpad == dim:
-            out = torch.empty(n, dim, dtype=torch.bfloat16, device=device)
+            out = torch.empty(n, dim, dtype=el, device=device)
             return ops.timestep_embedding(t32, dim, out)
-        tmp = torch.empty(n, dim, dtype=torch.bfloat16, device=device)
+        tmp = torch.empty(n, dim, dtype=el, device=device)
         ops.timestep_embedding(t32, dim, tmp)
-        out = torch.zeros(n, kpad, dtype=torch.bfloat16, device=device)
+        out = torch.zeros(n, kpad, dtype=el, device=device)
         out[:, :dim] = tmp
         return out
 
     def _context(self, ws, sample, timestep, encoder_hidden_states, added_time_ids):
         """unet_spatio_temporal_condition.py:64-94 / controlnet.py:262-294 -> FwdCtx with the per-clip tables."""
-        pk, dev = self._pk, sample.device
+        pk, dev, el = self._pk, sample.device, ws.el
         B, F = sample.shape[:2]
         boc0 = self.conv_in.weight.shape[0]
         ted = boc0 * 4
@@ -258,10 +275,10 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         if t32.numel() == 1:
             t32 = t32.expand(B)
         t32 = t32.contiguous()
-        te = self._sinusoid(t32, boc0, pk["te1_w"].shape[1], dev)
-        h = torch.empty(B, ted, dtype=torch.bfloat16, device=dev)
+        te = self._sinusoid(t32, boc0, pk["te1_w"].shape[1], dev, el)
+        h = torch.empty(B, ted, dtype=el, device=dev)
         ops.gemm(te, pk["te1_w"], h, N=ted, cin=te.shape[1], bias=pk["te1_b"], act=1)
-        emb_t = torch.empty(B, ted, dtype=torch.bfloat16, device=dev)
+        emb_t = torch.empty(B, ted, dtype=el, device=dev)
         ops.gemm(h, pk["te2_w"], emb_t, N=ted, cin=ted, bias=pk["te2_b"])
         ids = added_time_ids.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         n_ids = added_time_ids.shape[1]
@@ -270,27 +287,27 @@ class SpatioTemporalEncoderBase(HipModelMixin):
             raise ValueError(f"Model expects an added time embedding vector of length "
                              f"{self.add_embedding.linear_1.in_features}, but a vector of {add_dim * n_ids} was created.")
         kp = pk["ae1_w"].shape[1]
-        ae = self._sinusoid(ids, add_dim, add_dim, dev).reshape(B, n_ids * add_dim)
+        ae = self._sinusoid(ids, add_dim, add_dim, dev, el).reshape(B, n_ids * add_dim)
         if kp != ae.shape[1]:
-            ae_p = torch.zeros(B, kp, dtype=torch.bfloat16, device=dev)
+            ae_p = torch.zeros(B, kp, dtype=el, device=dev)
             ae_p[:, :ae.shape[1]] = ae
             ae = ae_p
         ops.gemm(ae, pk["ae1_w"], h, N=ted, cin=kp, bias=pk["ae1_b"], act=1)
-        emb_s = torch.empty(B, ted, dtype=torch.bfloat16, device=dev)       # silu(emb + aug_emb)
+        emb_s = torch.empty(B, ted, dtype=el, device=dev)       # silu(emb + aug_emb)
         ops.gemm(h, pk["ae2_w"], emb_s, N=ted, cin=ted, bias=pk["ae2_b"], R1=emb_t, act=1)
         temb = torch.empty(B, pk["temb_w"].shape[0], dtype=torch.float32, device=dev)
         ops.gemm(emb_s, pk["temb_w"], temb, N=pk["temb_w"].shape[0], cin=ted, bias=pk["temb_b"], out_f32=True)
         xattn = None
         if pk["xattn_n"]:
             dc = encoder_hidden_states.shape[2]
-            ehs = encoder_hidden_states.reshape(B, dc).to(torch.bfloat16).contiguous()
+            ehs = encoder_hidden_states.reshape(B, dc).to(el).contiguous()
             kx = pk["xv_w"].shape[1]
             if kx != dc:
-                ehs_p = torch.zeros(B, kx, dtype=torch.bfloat16, device=dev)
+                ehs_p = torch.zeros(B, kx, dtype=el, device=dev)
                 ehs_p[:, :dc] = ehs
                 ehs = ehs_p
             nx = pk["xv_w"].shape[0]
-            v_all = torch.empty(B, nx, dtype=torch.bfloat16, device=dev)
+            v_all = torch.empty(B, nx, dtype=el, device=dev)
             ops.gemm(ehs, pk["xv_w"], v_all, N=nx, cin=kx)
             xattn = torch.empty(B, nx, dtype=torch.float32, device=dev)
             for off, c, wo, bo in pk["xattn_out"]:

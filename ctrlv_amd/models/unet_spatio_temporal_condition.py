@@ -119,16 +119,16 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
         pk["cout_w"] = packing.pack_conv3x3(self.conv_out.weight)       # rows padded to 32
         pk["cout_b"] = packing.pad_bias(self.conv_out.bias)
 
-    @staticmethod
-    def _residual_rows(ws, r, M, C):
-        """A ControlNet residual given as an (N, C, H, W) tensor -> channels-last bf16 rows [M, C] (view if it already
-        is channels-last bf16, which is what ctrlv_amd's ControlNetModel returns)."""
+    def _residual_rows(self, ws, r, M, C):
+        """A ControlNet residual given as an (N, C, H, W) tensor -> channels-last rows [M, C] of this model's element
+        type (a view if it already is that, which is what ctrlv_amd's ControlNetModel of the same dtype returns)."""
+        el = self.el_dtype
         if tuple(r.shape[:2]) != (r.shape[0], C) or r.numel() != M * C:
             raise ValueError(f"additional residual has shape {tuple(r.shape)}, expected {M * C} elements with {C} channels")
         rp = r.permute(0, 2, 3, 1)
-        if r.dtype == torch.bfloat16 and rp.is_contiguous():
+        if r.dtype == el and rp.is_contiguous():
             return rp.reshape(M, C)
-        rows = ws.alloc((M, C)) if ws is not None else torch.empty(M, C, dtype=torch.bfloat16, device=r.device)
+        rows = ws.alloc((M, C)) if ws is not None else torch.empty(M, C, dtype=el, device=r.device)
         return ops.nchw_to_rows(r.contiguous(), rows, 0)
 
     def _forward_plan(self, sample, timestep, encoder_hidden_states, added_time_ids, down, mid, return_dict):

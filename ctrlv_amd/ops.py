@@ -19,6 +19,14 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _L(*tensors):
+    """The library that serves these element tensors: libctrlv_hip_f16.so when they are fp16, else the bf16 library."""
+    for t in tensors:
+        if t is not None and t.dtype == torch.float16:
+            return _lib.load(torch.float16)
+    return _lib.load()
+
+
 def _need_gpu(t, name="tensor"):
     if not t.is_cuda:
         raise _lib.CtrlvHipError(f"ctrlv_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
@@ -40,13 +48,13 @@ def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=No
         d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
     if temporal is not None:
         d.F, d.S = temporal
-    check(_lib.load().ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
+    check(_L(A, dY).ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
                                        1 if torch_layout else 0, _stream()), "ctrlv_gemm_wgrad")
     return dW
 
 
-def pack_weight(weight, form=0, geglu=False):
-    """bf16 GEMM layout of a PyTorch-layout parameter in ONE kernel (ctrlv_pack_weight): form 0 = forward
+def pack_weight(weight, form=0, geglu=False, dtype=torch.bfloat16):
+    """Element-type (`dtype`: bf16 / fp16) GEMM layout of a PyTorch-layout parameter in ONE kernel (ctrlv_pack_weight): form 0 = forward
     [N32, taps*C], form 1 = role-swapped dgrad [C32, taps*N64].  Returns None when the shape needs the torch packer
     (K not a multiple of 64 for Linear, odd channel counts)."""
     w = weight.detach()
@@ -62,8 +70,8 @@ def pack_weight(weight, form=0, geglu=False):
         if C % 32:
             return None
         rows, ld = C, taps * ((N + 63) // 64 * 64)
-    dst = (torch.zeros if rows != (N if form == 0 else C) else torch.empty)(rows, ld, dtype=torch.bfloat16, device=w.device)
-    check(_lib.load().ctrlv_pack_weight(_p(w), _DT[w.dtype], N, C, taps, form, 1 if geglu else 0, _p(dst), ld, _stream()),
+    dst = (torch.zeros if rows != (N if form == 0 else C) else torch.empty)(rows, ld, dtype=dtype, device=w.device)
+    check(_L(dst).ctrlv_pack_weight(_p(w), _DT[w.dtype], N, C, taps, form, 1 if geglu else 0, _p(dst), ld, _stream()),
           "ctrlv_pack_weight")
     return dst
 
@@ -71,20 +79,20 @@ def pack_weight(weight, form=0, geglu=False):
 def colsum(x, out, vmode=0, vdiv=1, vmod=1, scale=1.0):
     """out[idx(m), :N] += scale * sum_m x[m, :]  (fp32, atomics): bias gradients (vmode 0) / per-clip row-vector gradients."""
     _need_gpu(x, "x")
-    check(_lib.load().ctrlv_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), vmode, vdiv, vmod, float(scale), _p(out),
+    check(_L(x).ctrlv_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), vmode, vdiv, vmod, float(scale), _p(out),
                                    out.stride(0) if out.dim() > 1 else x.shape[1], _stream()), "ctrlv_colsum")
     return out
 
 
 def dot_diff(dy, p, q, out, scale=1.0):
     _need_gpu(dy, "dy")
-    check(_lib.load().ctrlv_dot_diff(_p(dy), _p(p), _p(q), dy.numel(), float(scale), _p(out), _stream()), "ctrlv_dot_diff")
+    check(_L(dy).ctrlv_dot_diff(_p(dy), _p(p), _p(q), dy.numel(), float(scale), _p(out), _stream()), "ctrlv_dot_diff")
     return out
 
 
 def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, silu, dx, dgamma, dbeta):
     _need_gpu(x, "x")
-    lib = _lib.load()
+    lib = _L(x)
     n = lib.ctrlv_groupnorm_bwd_scratch_floats(n_img, S, C, imgs_per_stat)
     if n < 0:
         check(n, "ctrlv_groupnorm_bwd_scratch_floats")
@@ -98,7 +106,7 @@ def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, 
 def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 << 30):
     _need_gpu(x, "x")
     M, C = x.shape
-    lib = _lib.load()
+    lib = _L(x)
     scratch = torch.empty(lib.ctrlv_layernorm_bwd_scratch_floats(M, C), dtype=torch.float32, device=x.device)
     check(lib.ctrlv_layernorm_bwd(_p(x), _p(dy), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
                                   V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch),
@@ -108,7 +116,7 @@ def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 <
 
 def geglu_bwd(raw, du, draw):
     _need_gpu(raw, "raw")
-    check(_lib.load().ctrlv_geglu_bwd(_p(raw), _p(du), du.shape[0], du.shape[1], _p(draw), _stream()), "ctrlv_geglu_bwd")
+    check(_L(raw).ctrlv_geglu_bwd(_p(raw), _p(du), du.shape[0], du.shape[1], _p(draw), _stream()), "ctrlv_geglu_bwd")
     return draw
 
 
@@ -143,7 +151,7 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
         d.raw_out, d.ld_raw = _p(raw_out), raw_out.stride(0)
     d.n_scale2, d.s_acc2 = n_scale2, s_acc2
     ev = _prof.begin()
-    check(_lib.load().ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
+    check(_L(A, W).ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
     if ev is not None:
         n_alg = d.N if geglu else min(d.N, d.n_store)
         fam = "gemm_conv3x3" if mode == 1 else ("gemm_conv_temporal" if mode == 2 else "gemm_linear")
@@ -163,10 +171,10 @@ def ff_fused_pack(w1_packed, b1, w2_packed):
     w2_packed = the output projection [320, 1280]."""
     _need_gpu(w1_packed, "w1_packed")
     assert tuple(w1_packed.shape) == (2560, 320) and tuple(w2_packed.shape) == (320, 1280) and b1.numel() == 2560
-    assert w1_packed.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16 and b1.dtype == torch.float32
+    assert w1_packed.dtype in (torch.bfloat16, torch.float16) and w2_packed.dtype == w1_packed.dtype and b1.dtype == torch.float32
     assert w1_packed.is_contiguous() and w2_packed.is_contiguous() and b1.is_contiguous()
-    lib = _lib.load()
-    w1f = torch.empty(lib.ctrlv_ff_fused_w1f_bytes() // 2, dtype=torch.bfloat16, device=w1_packed.device)
+    lib = _L(w1_packed)
+    w1f = torch.empty(lib.ctrlv_ff_fused_w1f_bytes() // 2, dtype=w1_packed.dtype, device=w1_packed.device)
     w2f = torch.empty_like(w2_packed)
     check(lib.ctrlv_ff_fused_pack(_p(w1_packed), _p(b1), _p(w2_packed), _p(w1f), _p(w2f), _stream()), "ctrlv_ff_fused_pack")
     return w1f, w2f
@@ -194,10 +202,10 @@ def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s
     d.ldv = V.stride(0) if V is not None else 0
     ev = _prof.begin()
     if ln is None:        # ln = (gamma, beta, eps): the LayerNorm in front of the feed-forward, folded into the kernel
-        check(_lib.load().ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
+        check(_L(x).ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
               "ctrlv_ff_fused")
     else:
-        check(_lib.load().ctrlv_ff_fused_ln(_p(x), x.stride(0), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln_V), ln_vdiv,
+        check(_L(x).ctrlv_ff_fused_ln(_p(x), x.stride(0), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln_V), ln_vdiv,
                                             ln_vmod, ln_V.stride(0) if ln_V is not None else 0, _p(w1f), _p(w2f),
                                             ctypes.byref(d), _stream()), "ctrlv_ff_fused_ln")
     if ev is not None:
@@ -223,7 +231,7 @@ def groupnorm_scratch_floats(n_img, S, C, imgs_per_stat):
 def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
     """Two-pass GroupNorm(32)(+SiLU) over channels-last rows; (x | x2) is a channel concat when x2 is given."""
     _need_gpu(x, "x")
-    lib = _lib.load()
+    lib = _L(x)
     c_split = x.shape[1] if x2 is not None else 0
     st = _stream()
     ev = _prof.begin()
@@ -239,7 +247,7 @@ def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30):
     _need_gpu(x, "x")
     M, C = x.shape
     ev = _prof.begin()
-    check(_lib.load().ctrlv_layernorm(_p(x), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
+    check(_L(x).ctrlv_layernorm(_p(x), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
                                       V.stride(0) if V is not None else 0, _p(y), _stream()), "ctrlv_layernorm")
     _prof.end(ev, "layernorm", 0.0, 2.0 * 2 * M * C)
     return y
@@ -252,7 +260,7 @@ def attention_spatial(qkv, out, n_img, S, C, prescaled=False):
     """prescaled: the q columns already carry Q_PRESCALE (gemm(..., n_scale2=C, s_acc2=Q_PRESCALE))."""
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()
-    fn = _lib.load().ctrlv_attention_spatial_prescaled if prescaled else _lib.load().ctrlv_attention_spatial
+    fn = _L(qkv).ctrlv_attention_spatial_prescaled if prescaled else _L(qkv).ctrlv_attention_spatial
     check(fn(_p(qkv), _p(out), n_img, S, C, _stream()), "ctrlv_attention_spatial")
     _prof.end(ev, "attention_spatial", 4.0 * n_img * (C // 64) * S * S * 64, 2.0 * 4 * n_img * S * C)
     return out
@@ -262,7 +270,7 @@ def attention_spatial_lse(qkv, out, lse, n_img, S, C):
     """Training forward: also writes lse [n_img, C/64, S] fp32 (log2-domain log-sum-exp of the scaled scores)."""
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()
-    check(_lib.load().ctrlv_attention_spatial_lse(_p(qkv), _p(out), _p(lse), n_img, S, C, _stream()),
+    check(_L(qkv).ctrlv_attention_spatial_lse(_p(qkv), _p(out), _p(lse), n_img, S, C, _stream()),
           "ctrlv_attention_spatial_lse")
     _prof.end(ev, "attention_spatial", 4.0 * n_img * (C // 64) * S * S * 64, 2.0 * 4 * n_img * S * C)
     return out
@@ -270,9 +278,9 @@ def attention_spatial_lse(qkv, out, lse, n_img, S, C):
 
 def attention_spatial_bwd(qkv, out, dout, lse, dqkv, n_img, S, C):
     _need_gpu(qkv, "qkv")
-    delta = torch.empty(_lib.load().ctrlv_attention_bwd_scratch_floats(n_img, S, C), dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(_L(qkv).ctrlv_attention_bwd_scratch_floats(n_img, S, C), dtype=torch.float32, device=qkv.device)
     ev = _prof.begin()
-    check(_lib.load().ctrlv_attention_spatial_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), n_img, S, C,
+    check(_L(qkv).ctrlv_attention_spatial_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), n_img, S, C,
                                                   _stream()), "ctrlv_attention_spatial_bwd")
     _prof.end(ev, "attention_spatial_bwd", 14.0 * n_img * (C // 64) * S * S * 64, 2.0 * 8 * n_img * S * C)
     return dqkv
@@ -281,7 +289,7 @@ def attention_spatial_bwd(qkv, out, dout, lse, dqkv, n_img, S, C):
 def attention_temporal_bwd(qkv, out, dout, dqkv, B, F, S, C):
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()
-    check(_lib.load().ctrlv_attention_temporal_bwd(_p(qkv), _p(out), _p(dout), _p(dqkv), B, F, S, C, _stream()),
+    check(_L(qkv).ctrlv_attention_temporal_bwd(_p(qkv), _p(out), _p(dout), _p(dqkv), B, F, S, C, _stream()),
           "ctrlv_attention_temporal_bwd")
     _prof.end(ev, "attention_temporal_bwd", 14.0 * B * S * (C // 64) * F * F * 64, 2.0 * 8 * B * F * S * C)
     return dqkv
@@ -290,7 +298,7 @@ def attention_temporal_bwd(qkv, out, dout, dqkv, B, F, S, C):
 def attention_temporal(qkv, out, B, F, S, C):
     _need_gpu(qkv, "qkv")
     ev = _prof.begin()
-    check(_lib.load().ctrlv_attention_temporal(_p(qkv), _p(out), B, F, S, C, _stream()), "ctrlv_attention_temporal")
+    check(_L(qkv).ctrlv_attention_temporal(_p(qkv), _p(out), B, F, S, C, _stream()), "ctrlv_attention_temporal")
     _prof.end(ev, "attention_temporal", 4.0 * B * S * (C // 64) * F * F * 64, 2.0 * 4 * B * F * S * C)
     return out
 
@@ -300,7 +308,7 @@ def nchw_to_rows(src, dst, c_off=0):
     _need_gpu(src, "src")
     n_img, C = src.shape[0], src.shape[1]
     HW = src.shape[2] * src.shape[3]
-    check(_lib.load().ctrlv_nchw_to_rows(_p(src), _DT[src.dtype], n_img, C, HW, _p(dst), dst.stride(0), c_off,
+    check(_L(dst).ctrlv_nchw_to_rows(_p(src), _DT[src.dtype], n_img, C, HW, _p(dst), dst.stride(0), c_off,
                                          _stream()), "ctrlv_nchw_to_rows")
     return dst
 
@@ -310,14 +318,14 @@ def rows_to_nchw(src, dst, C=None):
     _need_gpu(src, "src")
     n_img, Cd = dst.shape[0], dst.shape[1]
     HW = dst.shape[2] * dst.shape[3]
-    check(_lib.load().ctrlv_rows_to_nchw(_p(src), src.stride(0), n_img, Cd if C is None else C, HW, _p(dst),
+    check(_L(src).ctrlv_rows_to_nchw(_p(src), src.stride(0), n_img, Cd if C is None else C, HW, _p(dst),
                                          _DT[dst.dtype], _stream()), "ctrlv_rows_to_nchw")
     return dst
 
 
 def im2col3x3(x, n_img, H, W, col):
     _need_gpu(x, "x")
-    check(_lib.load().ctrlv_im2col3x3(_p(x), n_img, H, W, x.shape[1], _p(col), col.shape[1], _stream()),
+    check(_L(x).ctrlv_im2col3x3(_p(x), n_img, H, W, x.shape[1], _p(col), col.shape[1], _stream()),
           "ctrlv_im2col3x3")
     return col
 
@@ -325,21 +333,21 @@ def im2col3x3(x, n_img, H, W, col):
 def axpby(x, r, a, b, y):
     _need_gpu(x, "x")
     ev = _prof.begin()
-    check(_lib.load().ctrlv_axpby(_p(x), _p(r), a, b, _p(y), x.numel(), _stream()), "ctrlv_axpby")
+    check(_L(x).ctrlv_axpby(_p(x), _p(r), a, b, _p(y), x.numel(), _stream()), "ctrlv_axpby")
     _prof.end(ev, "residual_add", 0.0, 2.0 * 3 * x.numel())
     return y
 
 
 def silu(x, y):
     _need_gpu(x, "x")
-    check(_lib.load().ctrlv_silu(_p(x), _p(y), x.numel(), _stream()), "ctrlv_silu")
+    check(_L(x).ctrlv_silu(_p(x), _p(y), x.numel(), _stream()), "ctrlv_silu")
     return y
 
 
 def timestep_embedding(t, dim, out):
     """t: fp32 [n] -> out [n, dim] bf16 = [cos | sin] (Timesteps(dim, flip_sin_to_cos=True, shift 0))."""
     _need_gpu(t, "t")
-    check(_lib.load().ctrlv_timestep_embedding(_p(t), t.numel(), dim, _p(out), _stream()),
+    check(_L(out).ctrlv_timestep_embedding(_p(t), t.numel(), dim, _p(out), _stream()),
           "ctrlv_timestep_embedding")
     return out
 
@@ -350,7 +358,7 @@ def cfg_euler_step(latents, noise_pred, guidance, sigma, sigma_next, scaled_next
     B, F = latents.shape[0], latents.shape[1]
     chw = latents[0, 0].numel()
     cfg = 1 if noise_pred.shape[0] == 2 * B else 0
-    check(_lib.load().ctrlv_cfg_euler_step(_p(latents), _p(noise_pred), _DT[noise_pred.dtype], cfg, _p(guidance), B,
+    check(_L(scaled_next).ctrlv_cfg_euler_step(_p(latents), _p(noise_pred), _DT[noise_pred.dtype], cfg, _p(guidance), B,
                                            F, chw, float(sigma), float(sigma_next), _p(scaled_next), _stream()),
           "ctrlv_cfg_euler_step")
     return latents
@@ -360,7 +368,7 @@ def time_conv_rows_to_nchw(rows, n_frames, C, HW, weight, bias, out):
     """Conv3d(C, C, (3,1,1)) over the frames of one clip on channels-last rows, written as NCHW `out` (the VAE decoder's
     time_conv_out)."""
     _need_gpu(rows, "rows")
-    check(_lib.load().ctrlv_time_conv_rows_to_nchw(_p(rows), rows.stride(0), n_frames, C, HW, _p(weight), _p(bias), _p(out),
+    check(_L(rows).ctrlv_time_conv_rows_to_nchw(_p(rows), rows.stride(0), n_frames, C, HW, _p(weight), _p(bias), _p(out),
                                                    _DT[out.dtype], _stream()), "ctrlv_time_conv_rows_to_nchw")
     return out
 
@@ -368,6 +376,6 @@ def time_conv_rows_to_nchw(rows, n_frames, C, HW, weight, bias, out):
 def softmax_rows(scores, probs):
     """probs (bf16) = row softmax of fp32 `scores` (both 2-D, unit inner stride)."""
     _need_gpu(scores, "scores")
-    check(_lib.load().ctrlv_softmax_rows(_p(scores), scores.shape[0], scores.shape[1], scores.stride(0), _p(probs),
+    check(_L(probs).ctrlv_softmax_rows(_p(scores), scores.shape[0], scores.shape[1], scores.stride(0), _p(probs),
                                          probs.stride(0), _stream()), "ctrlv_softmax_rows")
     return probs

@@ -1,9 +1,25 @@
-"""Weight packing: diffusers state-dict layouts -> the K-contiguous bf16 layouts the gather-GEMM consumes.
+"""Weight packing: diffusers state-dict layouts -> the K-contiguous 16-bit layouts the gather-GEMM consumes (element type
+bf16 by default; `with element_dtype(torch.float16):` packs for libctrlv_hip_f16.so).
 
 Pure host-side tensor shuffling (runs on any device, unit-tested on CPU).  Layouts (include/ctrlv_hip.h):
   W[n, tap*Cin + c]; N padded to a multiple of 32 rows, K padded to a multiple of 64 columns (zeros).
 """
+import contextlib
+
 import torch
+
+_EL = [torch.bfloat16]          # element type the packers round to (see element_dtype)
+
+
+@contextlib.contextmanager
+def element_dtype(dtype):
+    """Packers called inside round to `dtype` (torch.bfloat16 / torch.float16): the model's element type."""
+    prev = _EL[0]
+    _EL[0] = dtype
+    try:
+        yield
+    finally:
+        _EL[0] = prev
 
 
 def _pad_rows(w, mult=32):
@@ -25,21 +41,21 @@ def _pad_cols(w, mult=64):
 def pack_linear(weight):
     """nn.Linear / 1x1 Conv2d weight [N, K(,1,1)] -> bf16 [N32, K64]."""
     w = weight.detach().reshape(weight.shape[0], -1)
-    return _pad_cols(_pad_rows(w)).to(torch.bfloat16).contiguous()
+    return _pad_cols(_pad_rows(w)).to(_EL[0]).contiguous()
 
 
 def pack_conv3x3(weight):
     """Conv2d weight [N, C, 3, 3] -> bf16 [N32, 9*C] with k = (ky*3+kx)*C + c."""
     n, c = weight.shape[:2]
     w = weight.detach().permute(0, 2, 3, 1).reshape(n, 9 * c)
-    return _pad_rows(w).to(torch.bfloat16).contiguous()
+    return _pad_rows(w).to(_EL[0]).contiguous()
 
 
 def pack_conv_temporal(weight):
     """Conv3d weight [N, C, 3, 1, 1] -> bf16 [N32, 3*C] with k = t*C + c."""
     n, c = weight.shape[:2]
     w = weight.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(n, 3 * c)
-    return _pad_rows(w).to(torch.bfloat16).contiguous()
+    return _pad_rows(w).to(_EL[0]).contiguous()
 
 
 def pack_conv_in(weights, cp=16, kp=192):
@@ -54,7 +70,7 @@ def pack_conv_in(weights, cp=16, kp=192):
         off += c
     assert off <= cp
     w = w.reshape(n, 9 * cp)
-    return _pad_cols(_pad_rows(w), kp).to(torch.bfloat16).contiguous()
+    return _pad_cols(_pad_rows(w), kp).to(_EL[0]).contiguous()
 
 
 GEGLU_BLOCK = 16
@@ -74,7 +90,7 @@ def geglu_interleave(t):
 
 
 def pack_geglu(weight, bias):
-    w = _pad_cols(geglu_interleave(weight.detach())).to(torch.bfloat16).contiguous()
+    w = _pad_cols(geglu_interleave(weight.detach())).to(_EL[0]).contiguous()
     b = geglu_interleave(bias.detach()).float().contiguous()
     return w, b
 

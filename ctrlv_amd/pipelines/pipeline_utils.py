@@ -536,7 +536,9 @@ class DenoiseStepper:
         self.lmi[:, :, self.c_lat:] = image_latents.to(self.model_dtype)
         self.image_embeddings, self.added_time_ids, self.cond_em = image_embeddings, added_time_ids, cond_em
         self.control_scale = control_condition_scale
-        self.scaled = torch.empty(B, F, *self.latents.shape[2:], dtype=torch.bfloat16, device=device)
+        # next scaled model input, written by the fused Euler kernel in the models' element type
+        self.scaled = torch.empty(B, F, *self.latents.shape[2:], device=device,
+                                  dtype=torch.float16 if self.model_dtype == torch.float16 else torch.bfloat16)
         self.set_latents(self.latents, 0)
         self.t_dev = torch.zeros((), dtype=torch.float32, device=device)
         self.use_hip_graph = use_hip_graph

@@ -54,10 +54,13 @@ def config_struct(kind, cfg, time_context_order="sb"):
 class Plan:
     """Owns one `ctrlv_plan` (module graph + packed weights in library-owned device memory)."""
 
-    def __init__(self, kind, config, device, time_context_order="sb"):
+    def __init__(self, kind, config, device, time_context_order="sb", dtype=torch.bfloat16):
+        """dtype: the ELEMENT type of the plan's activations and packed weights -- torch.bfloat16 (libctrlv_hip.so) or
+        torch.float16 (libctrlv_hip_f16.so)."""
         self.kind = kind
         self.device = torch.device(device)
-        self._lib = _lib.load()
+        self.dtype = dtype
+        self._lib = _lib.load(dtype)
         self._h = ctypes.c_void_p()
         self._cfg = config_struct(kind, config, time_context_order)
         check(self._lib.ctrlv_plan_create(ctypes.byref(self._cfg), self.device.index or 0, ctypes.byref(self._h)),

@@ -17,6 +17,7 @@ class Workspace:
         self.cur = 0              # index of the active block
         self.off = 0              # bump offset inside the active block
         self.peak = 0
+        self.el = torch.bfloat16  # element type of the forward using this arena (default dtype of alloc)
 
     def _block_for(self, nbytes):
         while True:
@@ -30,7 +31,8 @@ class Workspace:
             size = max(self.chunk_bytes, nbytes)
             self.blocks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
 
-    def alloc(self, shape, dtype=torch.bfloat16):
+    def alloc(self, shape, dtype=None):
+        dtype = self.el if dtype is None else dtype
         n = 1
         for s in shape:
             n *= int(s)

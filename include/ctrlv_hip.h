@@ -10,7 +10,15 @@
  *   - read inputs only; outputs are caller-owned buffers.
  *
  * Activations are CHANNELS-LAST rows: a tensor the reference holds as (N, C, H, W) is the row-major matrix
- * [N*H*W, C] of bf16 here (row = (n, y, x), n = b*F + f).  fp32 is used for all accumulation and statistics.
+ * [N*H*W, C] of 16-bit ELEMENTS here (row = (n, y, x), n = b*F + f).  fp32 is used for all accumulation and statistics.
+ *
+ * ELEMENT TYPE.  The same sources and the same ABI are built twice:
+ *   libctrlv_hip.so      elements are bf16  (ctrlv_elem_dtype() == 2) -- BASELINE.json's dtype; inference + training step
+ *   libctrlv_hip_f16.so  elements are fp16  (ctrlv_elem_dtype() == 1) -- the dtype the reference itself evaluates in (fp16
+ *                        autocast: config/a100l.yaml:9, tools/eval_video_controlnet.py:110-118); inference plans of fp16 models
+ * Wherever this header says "bf16" for an activation / packed weight / residual buffer, read "the library's element
+ * type".  The dtype CODES of the model boundary (0 fp32, 1 fp16, 2 bf16: sample, ehs, parameters, outputs) mean the same
+ * in both libraries.  A process may load both (the host layer selects by the model's dtype).
  */
 #ifndef CTRLV_HIP_H
 #define CTRLV_HIP_H
@@ -35,6 +43,8 @@ enum {
 
 /* Library ABI version (bumped on any signature change). */
 int ctrlv_abi_version(void);
+/* dtype code (1 fp16 / 2 bf16) of the element type this library was built for (see above). */
+int ctrlv_elem_dtype(void);
 /* Copies the build id (hash of the kernel sources + this header the library was compiled from) into buf; returns its
  * length.  The Python host layer compares it with the sources it sits next to and refuses a stale library. */
 int ctrlv_build_id(char* buf, size_t n);

@@ -47,7 +47,8 @@ def parity_err(a, b, what=None):
 def make_pair(config, device, seed=0, zero_conv_std=0.02, time_context_order="sb", dtype=torch.bfloat16,
               lean=False):
     """(oracle_unet, oracle_ctrl, hip_unet, hip_ctrl) sharing one seeded state dict.  The oracle weights are
-    rounded to bf16 first so both sides see exactly the same parameters.  `lean`: build the HIP models straight on
+    rounded to `dtype` first (bf16, or fp16 for the libctrlv_hip_f16.so models) so both sides see exactly the same
+    parameters.  `lean`: build the HIP models straight on
     the device (no fp32 host copy) -- for the full-width configuration."""
     import ctrlv_ref as R
     from ctrlv_amd.models import ControlNetModel, UNetSpatioTemporalConditionModel
@@ -58,7 +59,7 @@ def make_pair(config, device, seed=0, zero_conv_std=0.02, time_context_order="sb
     for m in (ou, oc):
         with torch.no_grad():
             for p in m.parameters():
-                p.copy_(p.to(torch.bfloat16).float())
+                p.copy_(p.to(dtype).float())
         m.eval()
     if lean:
         from ctrlv_amd.utils import build_on_device
@@ -87,7 +88,7 @@ def set_context_order(models, order):
                 sub.time_context_order = order
 
 
-def make_inputs(config, B, F, h, w, seed=123):
+def make_inputs(config, B, F, h, w, seed=123, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
     dc = config["cross_attention_dim"]
     if not isinstance(dc, int):
@@ -100,7 +101,7 @@ def make_inputs(config, B, F, h, w, seed=123):
         ehs[: B // 2] = 0
         cond[: B // 2] = 0
     t = torch.tensor(1.6377)
-    bf = lambda x: x.to(torch.bfloat16).float()   # noqa: E731
+    bf = lambda x: x.to(dtype).float()   # noqa: E731  (inputs exactly representable in the HIP models' dtype)
     return bf(sample), t, bf(ehs), ids, bf(cond)
 
 
@@ -120,7 +121,8 @@ def oracle_forward(ou, oc, inputs, scale=0.8, with_unet_no_ctrl=True):
 @torch.no_grad()
 def hip_forward(hu, hc, inputs, device, scale=0.8, with_unet_no_ctrl=True):
     sample, t, ehs, ids, cond = inputs
-    dev = lambda x: x.to(device=device, dtype=torch.bfloat16)   # noqa: E731
+    mdt = hu.dtype if hu.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+    dev = lambda x: x.to(device=device, dtype=mdt)   # noqa: E731
     d, m = hc(dev(sample), t.to(device), dev(ehs), ids.to(device), control_cond=dev(cond), conditioning_scale=scale,
               return_dict=False)
     y = hu(dev(sample), t.to(device), dev(ehs), ids.to(device), d, m, return_dict=False)[0]
@@ -140,23 +142,24 @@ def compare(got, ref, fn=parity_err):
 
 @torch.no_grad()
 def run_parity(config, device="cuda:0", B=2, F=3, h=16, w=16, time_context_order="sb", verbose=False, pair=None,
-               torch_bf16=True, lean=False, with_unet_no_ctrl=True):
+               torch_bf16=True, lean=False, with_unet_no_ctrl=True, dtype=torch.bfloat16):
     """Runs the HIP models and three oracle variants on the same inputs and returns the error tables
 
       fp32        HIP  vs the fp32 oracle                                  (rel-L2 and element bound, `parity_err`)
-      storage     HIP  vs the fp32 oracle with bf16 rounding at exactly the HIP path's storage points
+      storage     HIP  vs the fp32 oracle with `dtype` rounding at exactly the HIP path's storage points
       torch_bf16  PyTorch's own bf16 execution of the oracle (on the GPU: rocBLAS / MIOpen / SDPA) vs the fp32 oracle
                   -- the yardstick for "what bf16 costs through this network"; rel-L2 only
       fp32_l2     rel-L2 part of `fp32` alone (comparable with torch_bf16)
     """
     import ctrlv_ref as R
     ou, oc, hu, hc = pair if pair is not None else make_pair(config, device, time_context_order=time_context_order,
-                                                             lean=lean)
+                                                             lean=lean, dtype=dtype)
     if pair is not None:
         set_context_order((ou, oc, hu, hc), time_context_order)
-    inputs = make_inputs(config, B, F, h, w)
+        dtype = hu.dtype
+    inputs = make_inputs(config, B, F, h, w, dtype=dtype)
     ref = oracle_forward(ou, oc, inputs, with_unet_no_ctrl=with_unet_no_ctrl)
-    with R.storage_rounding(torch.bfloat16):
+    with R.storage_rounding(dtype):
         ref_q = oracle_forward(ou, oc, inputs, with_unet_no_ctrl=with_unet_no_ctrl)
     got = hip_forward(hu, hc, inputs, device, with_unet_no_ctrl=with_unet_no_ctrl)
     out = {"fp32": compare(got, ref), "storage": compare(got, ref_q), "fp32_l2": compare(got, ref, rel_l2)}
@@ -171,10 +174,12 @@ def run_parity(config, device="cuda:0", B=2, F=3, h=16, w=16, time_context_order
 
 
 @torch.no_grad()
-def run_tiny_parity(device="cuda:0", B=2, F=3, h=16, w=16, time_context_order="sb", verbose=False):
+def run_tiny_parity(device="cuda:0", B=2, F=3, h=16, w=16, time_context_order="sb", verbose=False,
+                    dtype=torch.bfloat16):
     """Tiny-config HIP-vs-fp32-oracle errors (smoke() and the model tests)."""
     import ctrlv_ref as R
-    return run_parity(dict(R.TINY_CONFIG), device, B, F, h, w, time_context_order, verbose, torch_bf16=False)["fp32"]
+    return run_parity(dict(R.TINY_CONFIG), device, B, F, h, w, time_context_order, verbose, torch_bf16=False,
+                      dtype=dtype)["fp32"]
 
 
 @torch.no_grad()
@@ -195,7 +200,8 @@ def error_growth_trace(ou, hu, inputs, device, oc=None, hc=None):
                 hooks.append(mod.register_forward_hook(lambda m, a, y: ref.append((names[m], y.detach().float()))))
         hnames = {m: n for n, m in h_model.named_modules()}
         h_model._trace = []
-        dev = lambda x: x.to(device=device, dtype=torch.bfloat16)   # noqa: E731
+        mdt = h_model.dtype if h_model.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+        dev = lambda x, mdt=mdt: x.to(device=device, dtype=mdt)   # noqa: E731
         try:
             if kind == "controlnet":
                 d_ref, m_ref = o_model(sample, t, ehs, ids, control_cond=cond, conditioning_scale=0.8)

@@ -39,18 +39,21 @@ def _fwd(hu, hc, inputs, dtype, with_ctrl=True):
 @torch.no_grad()
 @pytest.mark.parametrize("order", ["sb", "bs"])
 @pytest.mark.parametrize("B,F,h,w", [(2, 3, 16, 16), (1, 5, 24, 8)])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_plan_and_python_executors_are_bit_identical(hip_lib, order, B, F, h, w, dtype):
+@pytest.mark.parametrize("mdt,dtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                       (torch.float16, torch.float16), (torch.float16, torch.float32)])
+def test_plan_and_python_executors_are_bit_identical(hip_lib, order, B, F, h, w, mdt, dtype):
+    """mdt = the models' dtype (bf16: libctrlv_hip.so, fp16: libctrlv_hip_f16.so), dtype = the sample's."""
     import ctrlv_ref as R
     cfg = dict(R.TINY_CONFIG)
-    _, _, hu, hc = make_pair(cfg, DEV, time_context_order=order)
-    inputs = make_inputs(cfg, B, F, h, w)
+    _, _, hu, hc = make_pair(cfg, DEV, time_context_order=order, dtype=mdt)
+    inputs = make_inputs(cfg, B, F, h, w, dtype=mdt)
     res = {}
     for ex in ("plan", "python"):
         hu.executor = hc.executor = ex
         res[ex] = _fwd(hu, hc, inputs, dtype)
         res[ex + "_plain"] = _fwd(hu, hc, inputs, dtype, with_ctrl=False)
     assert hu._plan is not None and hc._plan is not None and hu._packed and hc._packed     # both executors really ran
+    assert hu._plan.dtype == mdt and hu._pk["cin_w"].dtype == mdt and res["plan"]["mid"].dtype == mdt
     a, b = res["plan"], res["python"]
     assert a["unet"].dtype == dtype and torch.equal(a["unet"], b["unet"])
     assert torch.equal(a["mid"], b["mid"]) and all(torch.equal(x, y) for x, y in zip(a["down"], b["down"]))
