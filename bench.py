@@ -68,7 +68,18 @@ def parse():
                     help="no GPU work: ranks rendezvous over gloo and run the barrier / MAX-reduce bracket only "
                          "(checks the N > 1 launch path on a machine without GPUs; prints value = null)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="element type of activations / packed weights: bf16 (BASELINE.json's dtype, libctrlv_hip.so) or "
+                         "fp16 (the reference's autocast dtype, libctrlv_hip_f16.so: model-level parity 1e-3 instead of 1e-2)")
+    ap.add_argument("--no-fp16-leg", action="store_true",
+                    help="bf16 runs: skip the extra leg that runs the SAME weights / sample through the fp16 build "
+                         "(its parity and step time are reported as `fp16_build` beside the bf16 headline)")
     return ap.parse_args()
+
+
+def torch_dtype(name):
+    import torch
+    return torch.float16 if name == "fp16" else torch.bfloat16
 
 
 def log(*a):
@@ -85,7 +96,10 @@ def launch_ranks(args):
 
 
 # ---------------------------------------------------------------------------------------------------- GPU side
-def build_models(device, workload, frames):
+def build_models(device, workload, frames, dtype):
+    """Random-init SVD-XT weights, created in bf16 (the benchmark's weights whatever the element type: an fp16 run holds the
+    same values -- bf16 -> fp16 is exact for every weight above fp16's subnormal range)."""
+    import torch
     from ctrlv_amd.models import ControlNetModel, UNetSpatioTemporalConditionModel
     from ctrlv_amd.utils import build_on_device, random_init_
     unet = build_on_device(UNetSpatioTemporalConditionModel, device, num_frames=frames)
@@ -94,6 +108,10 @@ def build_models(device, workload, frames):
     if workload == "box2video":
         ctrl = build_on_device(ControlNetModel, device, num_frames=frames)
         random_init_(ctrl, seed=1, zero_conv_std=0.02)
+    if dtype != torch.bfloat16:
+        unet.to(dtype)
+        if ctrl is not None:
+            ctrl.to(dtype)
     return unet, ctrl
 
 
@@ -108,7 +126,7 @@ def make_stepper(unet, ctrl, device, args, clip_index):
     F, h, w = args.frames, args.height // 8, args.width // 8
     sched = EulerDiscreteScheduler()
     sched.set_timesteps(25, device=device)
-    bf = torch.bfloat16
+    bf = unet.dtype
     latents = (torch.randn(1, F, 4, h, w, generator=g) * sched.init_noise_sigma).to(device)
     img = torch.randn(1, 4, h, w, generator=g)
     image_latents = torch.cat([torch.zeros_like(img), img]).unsqueeze(1).repeat(1, F, 1, 1, 1).to(device, bf)
@@ -134,7 +152,9 @@ def run_step(st, i):
 def cpu_sample_inputs(F, h, w, seed=0):
     import torch
     g = torch.Generator().manual_seed(seed)
-    q = lambda x: x.to(torch.bfloat16).float()   # noqa: E731  (bf16-representable: both sides see identical inputs)
+    # bf16-representable, hence fp16-representable too (8 bits of mantissa; N(0,1) values below fp16's normal range differ
+    # by < 3e-8): both sides, both element builds, see identical inputs
+    q = lambda x: x.to(torch.bfloat16).float()   # noqa: E731
     return dict(sample=q(torch.randn(1, F, 8, h, w, generator=g)), cond=q(torch.randn(1, F, 4, h, w, generator=g)),
                 ehs=q(torch.randn(1, 1, 1024, generator=g)), ids=torch.tensor([[6.0, 127.0, 0.02]]),
                 t=torch.tensor(1.6377))
@@ -243,10 +263,10 @@ def cpu_baseline(args, unet, ctrl, device):
                                capture_output=True, text=True, timeout=timeout)
         except subprocess.TimeoutExpired:
             return ({"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
-                     "sample": f"CPU oracle sample ({F} frames at {h}x{w}) exceeded {timeout} s on this host"}, None)
+                     "sample": f"CPU oracle sample ({F} frames at {h}x{w}) exceeded {timeout} s on this host"}, None, None)
         if r.returncode != 0 or not os.path.exists(os.path.join(xdir, "result.json")):
             return ({"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
-                     "sample": "CPU oracle child failed: " + r.stderr[-300:]}, None)
+                     "sample": "CPU oracle child failed: " + r.stderr[-300:]}, None, None)
         res = json.load(open(os.path.join(xdir, "result.json")))
         ref = torch.load(os.path.join(xdir, "out.pt"))
     finally:
@@ -264,9 +284,21 @@ def cpu_baseline(args, unet, ctrl, device):
                      f"step's {frames_per_step} frame-images at the full {h}x{w} latent, measured {sec:.1f} s"
                      + (" (x2 for the CFG pair)" if full else "")}
     # ---- parity of the HIP path on the same sample
+    ref = ref.float()
+    parity = hip_parity(unet, ctrl, ref, F, h, w, device)
+    return cpu, parity, ref
+
+
+PARITY_TOL = {"bf16": 1.5e-2, "fp16": 3e-3}
+
+
+def hip_parity(unet, ctrl, ref, F, h, w, device):
+    """The HIP models' output on the CPU-baseline sample against the oracle's (`ref`), in the models' own dtype."""
+    import torch
+    from tests.parity_utils import max_err, rel_l2
     inp = cpu_sample_inputs(F, h, w)
-    bf = torch.bfloat16
-    dv = lambda x: x.to(device, bf)   # noqa: E731
+    el = "fp16" if unet.dtype == torch.float16 else "bf16"
+    dv = lambda x: x.to(device, unet.dtype)   # noqa: E731
     with torch.no_grad():
         down = mid = None
         if ctrl is not None:
@@ -274,18 +306,42 @@ def cpu_baseline(args, unet, ctrl, device):
                              control_cond=dv(inp["cond"]), return_dict=False)
         got = unet(dv(inp["sample"]), inp["t"].to(device), dv(inp["ehs"]), inp["ids"].to(device), down, mid,
                    return_dict=False)[0].float().cpu()
-    ref = ref.float()
     rms = ref.pow(2).mean().sqrt().item()
     # one bound for both measures (tests/parity_utils.parity_err): rel-L2 < tol AND every element within
     # tol * (6 rms(ref) + 2 |ref|)
-    from tests.parity_utils import max_err, rel_l2
     parity = {"rel_l2": round(rel_l2(got, ref), 6), "max_elem": round(max_err(got, ref), 6),
               "max_abs": round((got - ref).abs().max().item(), 6), "ref_rms": round(rms, 6),
-              "tolerance": 1.5e-2,
-              "what": f"HIP UNet output (bf16 storage) vs the fp32 CPU oracle, same weights / inputs, {F} frames at {h}x{w}; "
+              "tolerance": PARITY_TOL[el],
+              "what": f"HIP UNet output ({el} storage) vs the fp32 CPU oracle, same weights / inputs, {F} frames at {h}x{w}; "
                       "ok = rel-L2 < tolerance and |a - ref| < tolerance * (6 rms(ref) + 2 |ref|) for every element"}
     parity["ok"] = bool(parity["rel_l2"] < parity["tolerance"] and parity["max_elem"] < parity["tolerance"])
-    return cpu, parity
+    return parity
+
+
+def fp16_leg(args, unet, ctrl, ref, device):
+    """bf16 runs only: the SAME weights and the SAME sample through the fp16 element build (libctrlv_hip_f16.so) -- its
+    parity against the oracle output `ref` (north_star's 1e-3 needs fp16 storage: DESIGN.md 4) and its step time,
+    reported beside the bf16 headline.  Not part of `value`."""
+    import copy
+    import torch
+    u16 = copy.deepcopy(unet).to(torch.float16)
+    c16 = copy.deepcopy(ctrl).to(torch.float16) if ctrl is not None else None
+    F = args.frames if (args.cpu_full_step or args.cpu_frames <= 0 or args.cpu_frames >= args.frames) else args.cpu_frames
+    out = {"parity": hip_parity(u16, c16, ref, F, args.height // 8, args.width // 8, device)}
+    st = make_stepper(u16, c16, device, args, clip_index=0)
+    i = 0
+    for _ in range(2):
+        run_step(st, i); i += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(st, i); i += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out.update(value=round(args.steps / dt, 4), unit="steps/s", ms_per_step=round(dt / args.steps * 1e3, 2), steps=args.steps,
+               finite=bool(torch.isfinite(st.latents).all()),
+               what="the same weights, workload and HIP-graph step with fp16 elements (bench.py --dtype fp16 is the full line)")
+    return out
 
 
 def launcher_selftest(args, D):
@@ -337,10 +393,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    unet, ctrl = build_models(device, args.workload, args.frames)
+    unet, ctrl = build_models(device, args.workload, args.frames, torch_dtype(args.dtype))
     clip = D.shard_clips(world, rank, world)[0]                        # one clip per rank (weak scaling)
     st = make_stepper(unet, ctrl, device, args, clip_index=clip)
-    log(f"rank {rank}/{world}: models built on {device}, hip_graph={args.hip_graph}, lib build {_lib.build_id()}")
+    lib = _lib.load(unet.el_dtype)
+    log(f"rank {rank}/{world}: models built on {device} ({args.dtype} elements), hip_graph={args.hip_graph}, "
+        f"lib build {_lib.build_id(lib)}")
 
     i = 0
     for _ in range(max(args.warmup, 2 if args.hip_graph else 1)):      # graph mode: 1 eager + 1 capture step
@@ -396,9 +454,9 @@ def main():
             pmc_note = "PMC summary is for the default box2video 25x576x1024 shape only"
         else:
             raw = json.load(open(cands[-1]))
-            if raw.get("_build_id") != _lib.build_id():
+            if raw.get("_build_id") != _lib.build_id(lib) or args.dtype != "bf16":
                 pmc_note = (f"{os.path.relpath(cands[-1], ROOT)} was collected from library build "
-                            f"{raw.get('_build_id', 'unstamped')}, running {_lib.build_id()}: traffic = null")
+                            f"{raw.get('_build_id', 'unstamped')} (bf16), running {_lib.build_id(lib)} ({args.dtype}): traffic = null")
             else:
                 alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
                          "groupnorm": ["gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
@@ -440,7 +498,7 @@ def main():
                    else f"denoising steps/sec, SVD UNet-only {shape}"),
         "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {'ControlNet + ' if ctrl is not None else ''}UNet forward, CFG batch 2, "
                                f"{args.frames} frames, latent {args.height // 8}x{args.width // 8}, 25-step Karras Euler "
                                "schedule, random-init SVD-XT weights", "clips_per_gpu": 1, "parallelism": f"clip-shard x{world}",
@@ -455,7 +513,7 @@ def main():
                                                if alg else None),
         "kernel_ms_per_step": round(sum(d["ms"] for d in fams.values()), 2),
         "finite": finite,
-        "lib_build_id": _lib.build_id(),
+        "lib_build_id": _lib.build_id(lib),
         "roofline": roofline, "rooflines": rooflines,
         "traffic_source": pmc.get("_source"), "traffic_note": pmc_note,
     }
@@ -463,7 +521,10 @@ def main():
         del st
         torch.cuda.empty_cache()
         log("timing the CPU oracle baseline (same weights; by default the complete no-CFG step, ~2-4 minutes) and checking the HIP output against it ...")
-        line["cpu_baseline"], line["parity"] = cpu_baseline(args, unet, ctrl, device)
+        line["cpu_baseline"], line["parity"], ref = cpu_baseline(args, unet, ctrl, device)
+        if args.dtype == "bf16" and ref is not None and not args.no_fp16_leg:
+            log("fp16 leg: the same weights / sample through libctrlv_hip_f16.so ...")
+            line["fp16_build"] = fp16_leg(args, unet, ctrl, ref, device)
     print(json.dumps(line))
 
 

@@ -53,7 +53,7 @@ def test_plan_and_python_executors_are_bit_identical(hip_lib, order, B, F, h, w,
         res[ex] = _fwd(hu, hc, inputs, dtype)
         res[ex + "_plain"] = _fwd(hu, hc, inputs, dtype, with_ctrl=False)
     assert hu._plan is not None and hc._plan is not None and hu._packed and hc._packed     # both executors really ran
-    assert hu._plan.dtype == mdt and hu._pk["cin_w"].dtype == mdt and res["plan"]["mid"].dtype == mdt
+    assert hu._plan.dtype == mdt and hu._pk["cin_w"].dtype == mdt and res["plan"]["mid"].dtype == dtype
     a, b = res["plan"], res["python"]
     assert a["unet"].dtype == dtype and torch.equal(a["unet"], b["unet"])
     assert torch.equal(a["mid"], b["mid"]) and all(torch.equal(x, y) for x, y in zip(a["down"], b["down"]))
