@@ -67,7 +67,7 @@ SIGNATURES = {
     "ctrlv_softmax_rows": (c_int, [c_void_p, c_int, c_int, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p]),
     "ctrlv_ff_fused_w1f_bytes": (c_int, []),
     "ctrlv_ff_fused_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ctrlv_ff_fused_serves": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, c_int]),
+    "ctrlv_ff_fused_serves": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
     "ctrlv_ff_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_ff_fused_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p,
                                   c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),

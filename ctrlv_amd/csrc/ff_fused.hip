@@ -335,6 +335,44 @@ extern "C" int ctrlv_ff_fused_pack(const void* w1_packed, const float* b1, const
   return CTRLV_OK;
 }
 
+// Every condition under which the fused kernel serves a second-projection descriptor -- ONE function for the launcher
+// and for the callers' switch (ctrlv_ff_fused_serves), so that a layer the switch accepts is never refused at launch.
+// `fold` (out): the row vector rides in the accumulator start.  report = false: no error text (a "no" is not an error).
+static int ff_check(const ctrlv_gemm_desc& d, int ldx, bool report, bool* fold) {
+#define FF_REQ(cond, code, ...)                        \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      if (report) ctrlv_set_error(__VA_ARGS__);        \
+      return code;                                     \
+    }                                                  \
+  } while (0)
+  *fold = false;
+  FF_REQ(d.out != nullptr, CTRLV_E_BAD_ARG, "ctrlv_ff_fused: null pointer");
+  FF_REQ(d.M > 0 && d.N == kC && d.Cin == kHid && d.taps == 1 && d.mode == 0 && ldx >= kC && ldx % 8 == 0, CTRLV_E_BAD_SHAPE,
+         "ctrlv_ff_fused: serves M x 320 <- 1280 <- 320 only (N=%d Cin=%d ldx=%d)", d.N, d.Cin, ldx);
+  FF_REQ(!d.geglu && !d.act && !d.out_f32 && !d.raw_out && !d.A2 && d.n_scale2 == 0, CTRLV_E_BAD_ARG,
+         "ctrlv_ff_fused: plain element-type output only");
+  FF_REQ(d.n_store == kC && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) && (!d.R2 || d.ldr2 % 8 == 0), CTRLV_E_BAD_SHAPE,
+         "ctrlv_ff_fused: n_store must be 320 and the row pitches multiples of 8");
+  const long lim = 0xFFFFFFF0L;
+  FF_REQ((long)d.M * d.ldo * 2 <= lim && (long)d.M * ldx * 2 <= lim && (!d.R1 || (long)d.M * d.ldr1 * 2 <= lim) &&
+             (!d.R2 || (long)d.M * d.ldr2 * 2 <= lim),
+         CTRLV_E_BAD_SHAPE, "ctrlv_ff_fused: operands beyond 32-bit byte offsets");
+  FF_REQ(!d.R2 || d.R1, CTRLV_E_BAD_ARG, "ctrlv_ff_fused: R2 without R1");
+  if (d.vmode) {
+    FF_REQ((d.vmode == 1 || d.vmode == 2) && d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv >= kC && d.ldv % 4 == 0 &&
+               (d.vmode == 1 || d.vS > 0),
+           CTRLV_E_BAD_ARG, "ctrlv_ff_fused: bad row-vector operand");
+    // one vector per 256-row tile, unscaled (the frame embedding of ff_in): it rides in the accumulator start (kernel)
+    // and the epilogue has no row-vector reads; anything else is the shared epilogue's row-vector operand (EPI bit 0)
+    *fold = d.vmode == 1 && d.vdiv % 256 == 0 && d.s_acc == 1.0f;
+    FF_REQ(*fold || !d.R2, CTRLV_E_BAD_ARG,
+           "ctrlv_ff_fused: R1 + R2 + a row vector is served only in the per-tile form (vmode 1, vdiv %% 256 == 0, s_acc 1)");
+  }
+  return CTRLV_OK;
+#undef FF_REQ
+}
+
 extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                  const float* ln_V, int ln_vdiv, int ln_vmod, int ln_ldv, const void* w1f, const void* w2f,
                                  const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream) {
@@ -350,34 +388,28 @@ extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, 
   a.x = (const el_t*)x; a.ldx = ldx; a.w1f = (const el_t*)w1f; a.w2f = (const el_t*)w2f;
   a.o = *out_desc;
   a.vtab = nullptr; a.vdiv = 1; a.vmod = 1; a.ldv = 0;
-  if (a.o.vmode) {
-    // the row vector is folded into the accumulator start (kernel): one vector per 256-row tile, unscaled
-    CTRLV_CHECK_ARG(a.o.vmode == 1 && a.o.V && a.o.vdiv > 0 && a.o.vdiv % 256 == 0 && a.o.vmod > 0 && a.o.s_acc == 1.0f &&
-                        a.o.ldv % 4 == 0,
-                    "ctrlv_ff_fused: a row-vector operand needs vmode 1, vdiv a multiple of 256 and s_acc == 1 "
-                    "(ctrlv_ff_fused_serves() tells; use the two ctrlv_gemm launches otherwise)");
+  bool fold = false;
+  const int rc = ff_check(a.o, ldx, true, &fold);
+  if (rc != CTRLV_OK) return rc;
+  if (fold) {
     a.vtab = a.o.V; a.vdiv = a.o.vdiv; a.vmod = a.o.vmod; a.ldv = a.o.ldv;
     a.o.vmode = 0; a.o.V = nullptr;
   }
   const ctrlv_gemm_desc& d = a.o;
-  CTRLV_CHECK_SHAPE(d.M > 0 && d.N == kC && d.Cin == kHid && d.taps == 1 && d.mode == 0 && ldx >= kC && ldx % 8 == 0,
-                    "ctrlv_ff_fused: serves M x 320 <- 1280 <- 320 only (N=%d Cin=%d ldx=%d)", d.N, d.Cin, ldx);
-  CTRLV_CHECK_ARG(!d.geglu && !d.act && !d.out_f32 && !d.raw_out && !d.A2 && d.n_scale2 == 0,
-                  "ctrlv_ff_fused: plain bf16 output only");
-  CTRLV_CHECK_SHAPE(d.n_store == kC && d.ldo % 8 == 0 && (!d.R1 || d.ldr1 % 8 == 0) && (!d.R2 || d.ldr2 % 8 == 0),
-                    "ctrlv_ff_fused: n_store must be 320 and the row pitches multiples of 8");
-  const long lim = 0xFFFFFFF0L;
-  CTRLV_CHECK_SHAPE((long)d.M * d.ldo * 2 <= lim && (!d.R1 || (long)d.M * d.ldr1 * 2 <= lim) &&
-                        (!d.R2 || (long)d.M * d.ldr2 * 2 <= lim),
-                    "ctrlv_ff_fused: operands beyond 32-bit byte offsets");
   hipStream_t st = (hipStream_t)stream;
+  // (EPI = 1 / 3: the row-vector operand through the epilogue.  The R1 + V instantiation at this wave shape -- TM = 1,
+  // TN = 10 -- is the one that "intermittently stored zero dwords" in round 3: the store-data hazard of gemm_pp_kernel.h
+  // (store_data_hazard_guard), a zero-initialisation of the next sub-tile's row-vector registers scheduled right behind a
+  // buffer store whose data registers it reused.  Guarded, it is back in the build; tests: 48-run bit-stability.)
   switch (pp_epi_of(d)) {
     case 0: return launch_ff<0>(a, st);
+    case 1: return launch_ff<1>(a, st);
     case 2: return launch_ff<2>(a, st);
+    case 3: return launch_ff<3>(a, st);
     case 6: return launch_ff<6>(a, st);
     default: break;
   }
-  ctrlv_set_error("ctrlv_ff_fused: epilogue operand combination not served (bias, +R1, +R1+R2, each with an optional V)");
+  ctrlv_set_error("ctrlv_ff_fused: epilogue operand combination not served (bias [+ V], + R1 [+ V], + R1 + R2 [+ a per-tile V])");
   return CTRLV_E_BAD_ARG;
 }
 
@@ -386,11 +418,11 @@ extern "C" int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const voi
   return ctrlv_ff_fused_ln(x, ldx, nullptr, nullptr, 0.f, nullptr, 1, 1, 0, w1f, w2f, out_desc, stream);
 }
 
-// 1 if ctrlv_ff_fused serves a second-projection descriptor with these row-vector settings (the callers' switch between
-// the fused kernel and the two ctrlv_gemm launches)
-extern "C" int ctrlv_ff_fused_serves(int n, int cin, int vmode, int vdiv, float s_acc, int has_r1, int has_r2) {
-  if (n != kC || cin != kHid) return 0;
-  if (has_r2 && !has_r1) return 0;
-  if (vmode == 0) return 1;
-  return vmode == 1 && vdiv > 0 && vdiv % 256 == 0 && s_acc == 1.0f;
+// 1 if ctrlv_ff_fused serves this second-projection descriptor with input rows of pitch ldx (the callers' switch between
+// the fused kernel and the two ctrlv_gemm launches): exactly the launcher's own conditions
+extern "C" int ctrlv_ff_fused_serves(const ctrlv_gemm_desc* out_desc, int ldx) {
+  if (!out_desc) return 0;
+  bool fold = false;
+  if (ff_check(*out_desc, ldx, false, &fold) != CTRLV_OK) return 0;
+  return (out_desc->act || (out_desc->out_f32 & 1)) ? 0 : 1;
 }

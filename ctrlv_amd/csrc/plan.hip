@@ -587,16 +587,20 @@ int ff_rows_per_chunk(long M, int C) {
   const long n = (u_bytes + (160L << 20) - 1) / (160L << 20);
   return (int)(((M + n - 1) / n + 255) / 256 * 256);
 }
-int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C) {
+// `u` = the 4C-wide intermediate of the two-launch path, allocated HERE on first need (a transformer whose three
+// feed-forwards all run fused never reserves it: 1.2 GB per lane at the 72 x 128 level); proj.out / outd.A are set from it.
+int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C, el_t** u) {
   // C = 320: one fused launch, the 4C-wide intermediate stays on chip (ff_fused.hip): 234.5 -> 231.3 ms per step (three
   // alternations on one device).  CTRLV_FF_FUSED=0: the two launches.
   static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
-  if (fuse && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
-                                             outd.R2 != nullptr)) {
+  if (fuse && f.w1f && ctrlv_ff_fused_serves(&outd, proj.lda)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, f.w2f, &outd, c.st);
   }
+  if (*u == nullptr) *u = c.rows(proj.M, 4 * C);
+  proj.out = *u;
+  outd.A = *u;
   const int M = proj.M, rows = ff_rows_per_chunk(M, C);
   for (int m0 = 0; m0 < M; m0 += rows) {
     const int mc = M - m0 < rows ? M - m0 : rows;
@@ -619,17 +623,16 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
 // (224.2 vs 224.2 and 230.3 vs 230.4 ms per step, three alternations each: the LayerNorm family drops 7.9 -> 5.3 ms, the
 // fused kernel's per-tile prologue takes it back), so the default keeps ctrlv_layernorm in front of the fused kernel.
 int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const el_t* xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
-          el_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C) {
+          el_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C, el_t** u) {
   static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
   static const bool fold = [] { const char* e = getenv("CTRLV_FF_LN"); return e && atoi(e) != 0; }();
-  if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(outd.N, outd.Cin, outd.vmode, outd.vdiv, outd.s_acc, outd.R1 != nullptr,
-                                                     outd.R2 != nullptr)) {
+  if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(&outd, C)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     return ctrlv_ff_fused_ln(xraw, C, nm.g, nm.b, 1e-5f, lnV, lnvdiv, lnvmod, lnldv, f.w1f, f.w2f, &outd, c.st);
   }
   TRY(layernorm(c, xraw, proj.M, C, nm, tt, lnV, lnvdiv, lnvmod, lnldv));
-  return ff_pair(c, f, proj, outd, C);
+  return ff_pair(c, f, proj, outd, C, u);
 }
 
 // ---- TransformerSpatioTemporalModel (blocks.py::TransformerSpatioTemporalModel.run)
@@ -665,14 +668,14 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     d.V = c.xattn + t.xattn_off[0]; d.ldv = c.ldx; d.vmode = 1; d.vdiv = F * S;
     TRY(gemm(c, d));
   }
-  el_t* u = c.rows(M, 4 * C);
+  el_t* u = nullptr;  // 4C-wide GEGLU output of the two-launch path: allocated by ff_pair on first need
   el_t* h2 = h0;      // h0 is dead from here on
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
     d.R1 = h1; d.ldr1 = C;
-    TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C));
+    TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
   el_t* g0 = h1;      // h1 is dead
@@ -682,7 +685,7 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0, C, (int)M, C, 4 * C, C);
     d.R1 = h2; d.ldr1 = C;
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
-    TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C));
+    TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C, &u));
   }
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
@@ -703,7 +706,7 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
     d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
     d.s2 = (float)t.alpha;
-    TRY(ln_ff(c, t.t_ff, t.t_ln3, g1, nullptr, 1, 1 << 30, 0, tt, dp, d, C));
+    TRY(ln_ff(c, t.t_ff, t.t_ln3, g1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   {
     ctrlv_gemm_desc d = gd(h3, C, t.pout, out, C, (int)M, C, C, C);

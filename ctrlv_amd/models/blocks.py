@@ -139,16 +139,19 @@ def _ff_rows_per_chunk(M, C):
 _FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
 
 
-def _ff_pair(x, ffp, u, out, C, **epi):
+def _ff_pair(ws, x, ffp, ubox, out, C, **epi):
     """u = GEGLU(x); out = epilogue(u @ wout^T).  ffp = (wproj, bproj, wout, bout[, w1f, w2f]): at C = 320 one fused launch
     that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs, issued as
-    M-chunked pairs (same arithmetic, same bits)."""
+    M-chunked pairs (same arithmetic, same bits).  `ubox` = [u or None]: the 4C-wide intermediate of the two-launch path is
+    allocated from the arena on first need (csrc/plan.hip ff_pair)."""
     wproj, bproj, wout, bout = ffp[:4]
-    if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(C, 4 * C, epi.get("vmode", 0) if "V" in epi else 0,
-                                                           epi.get("vdiv", 1), epi.get("s_acc", 1.0), "R1" in epi, "R2" in epi):
+    if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(x, out, **epi):
         ops.ff_fused(x, ffp[4], ffp[5], out, bias=bout, **epi)
         return
     M = x.shape[0]
+    if ubox[0] is None:
+        ubox[0] = ws.alloc((M, 4 * C))
+    u = ubox[0]
     rows = _ff_rows_per_chunk(M, C)
     for m0 in range(0, M, rows):
         m1 = min(M, m0 + rows)
@@ -160,12 +163,10 @@ def _ff_pair(x, ffp, u, out, C, **epi):
 _FF_LN = os.environ.get("CTRLV_FF_LN", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ln_ff)
 
 
-def _ln_ff(xraw, ln, t, ffp, u, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, **epi):
+def _ln_ff(ws, xraw, ln, t, ffp, ubox, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, **epi):
     """out = epilogue(FF(LayerNorm(xraw + ln_V))): with the fused kernel the norm is folded into its prologue, else
     ops.layernorm into `t` followed by _ff_pair (csrc/plan.hip ln_ff)."""
-    if _FF_FUSED and _FF_LN and len(ffp) == 6 and ops.ff_fused_serves(C, 4 * C, epi.get("vmode", 0) if "V" in epi else 0,
-                                                                      epi.get("vdiv", 1), epi.get("s_acc", 1.0), "R1" in epi,
-                                                                      "R2" in epi):
+    if _FF_FUSED and _FF_LN and len(ffp) == 6 and ops.ff_fused_serves(xraw, out, **epi):
         ops.ff_fused(xraw, ffp[4], ffp[5], out, bias=ffp[3], ln=(ln[0], ln[1], 1e-5), ln_V=ln_V, ln_vdiv=ln_vdiv,
                      ln_vmod=ln_vmod, **epi)
         return
@@ -173,7 +174,7 @@ def _ln_ff(xraw, ln, t, ffp, u, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, *
         ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, V=ln_V, vdiv=ln_vdiv, vmod=ln_vmod)
     else:
         ops.layernorm(xraw, ln[0], ln[1], 1e-5, t)
-    _ff_pair(t, ffp, u, out, C, **epi)
+    _ff_pair(ws, t, ffp, ubox, out, C, **epi)
 
 
 def _gn_scratch(ctx, n_img, S, C, ips):
@@ -358,12 +359,12 @@ class TransformerSpatioTemporalModel(nn.Module):
         h1 = ws.alloc((M, C))
         xs_vec = ctx.xattn[:, self.xattn_off[0]:]      # attn2 with one key == to_out(to_v(ehs[b])) for every query
         ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)
-        u = ws.alloc((M, 4 * C))
+        u = [None]                                      # 4C-wide GEGLU output: allocated by _ff_pair on first need
         h2 = h0                                         # h0 is dead from here on
-        _ln_ff(h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, R1=h1)
+        _ln_ff(ws, h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, R1=h1)
         # ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
         g0 = h1                                         # h1 is dead
-        _ln_ff(h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, R1=h2, V=emb, vmode=1, vdiv=S,
+        _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, R1=h2, V=emb, vmode=1, vdiv=S,
                vmod=F)
         ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
         ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
@@ -378,7 +379,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
-        _ln_ff(g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
+        _ln_ff(ws, g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
         if ctx.trace is not None:

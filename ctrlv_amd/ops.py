@@ -180,9 +180,26 @@ def ff_fused_pack(w1_packed, b1, w2_packed):
     return w1f, w2f
 
 
-def ff_fused_serves(n, cin, vmode=0, vdiv=1, s_acc=1.0, has_r1=False, has_r2=False):
-    """Whether `ff_fused` serves a second projection with these settings (else: the two `gemm` launches)."""
-    return bool(_lib.load().ctrlv_ff_fused_serves(n, cin, vmode, vdiv, float(s_acc), int(has_r1), int(has_r2)))
+def _ff_out_desc(out, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1):
+    """The second projection's descriptor of a C = 320 feed-forward (what ctrlv_ff_fused / ctrlv_ff_fused_serves take)."""
+    d = GemmDesc()
+    d.out, d.bias, d.R1, d.R2, d.V = _p(out), _p(bias), _p(R1), _p(R2), _p(V)
+    d.M, d.N, d.Cin, d.taps, d.mode = out.shape[0], out.shape[1], 4 * out.shape[1], 1, 0
+    d.ldo, d.n_store = out.stride(0), out.shape[1]
+    d.ldr1 = R1.stride(0) if R1 is not None else 0
+    d.ldr2 = R2.stride(0) if R2 is not None else 0
+    d.s_acc, d.s1, d.s2 = s_acc, s1, s2
+    d.vmode = vmode if V is not None else 0
+    d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
+    d.ldv = V.stride(0) if V is not None else 0
+    return d
+
+
+def ff_fused_serves(x, out, **epi):
+    """Whether `ff_fused(x, ..., out, **epi)` is served by the fused kernel (else: the two `gemm` launches) -- the
+    launcher's own conditions (csrc/ff_fused.hip ff_check)."""
+    d = _ff_out_desc(out, **{k: v for k, v in epi.items() if k != "bias"})
+    return bool(_L(x).ctrlv_ff_fused_serves(ctypes.byref(d), x.stride(0)))
 
 
 def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1,
@@ -190,24 +207,15 @@ def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s
     """out = s_acc * (GEGLU(x W1^T + b1) W2^T + bias) + s1 R1 + s2 R2 + V[idx(m)] for a C = 320 feed-forward, the 4C-wide
     intermediate kept on chip (csrc/ff_fused.hip).  The epilogue operands are those of `gemm`."""
     _need_gpu(x, "x")
-    d = GemmDesc()
-    d.out, d.bias, d.R1, d.R2, d.V = _p(out), _p(bias), _p(R1), _p(R2), _p(V)
-    d.M, d.N, d.Cin, d.taps, d.mode = out.shape[0], 320, 1280, 1, 0
-    d.ldo, d.n_store = out.stride(0), 320
-    d.ldr1 = R1.stride(0) if R1 is not None else 0
-    d.ldr2 = R2.stride(0) if R2 is not None else 0
-    d.s_acc, d.s1, d.s2 = s_acc, s1, s2
-    d.vmode = vmode if V is not None else 0
-    d.vdiv, d.vmod, d.vS = vdiv, vmod, vS
-    d.ldv = V.stride(0) if V is not None else 0
+    d = _ff_out_desc(out, bias, R1, s1, R2, s2, s_acc, V, vmode, vdiv, vmod, vS)
     ev = _prof.begin()
     if ln is None:        # ln = (gamma, beta, eps): the LayerNorm in front of the feed-forward, folded into the kernel
         check(_L(x).ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
               "ctrlv_ff_fused")
     else:
         check(_L(x).ctrlv_ff_fused_ln(_p(x), x.stride(0), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(ln_V), ln_vdiv,
-                                            ln_vmod, ln_V.stride(0) if ln_V is not None else 0, _p(w1f), _p(w2f),
-                                            ctypes.byref(d), _stream()), "ctrlv_ff_fused_ln")
+                                      ln_vmod, ln_V.stride(0) if ln_V is not None else 0, _p(w1f), _p(w2f),
+                                      ctypes.byref(d), _stream()), "ctrlv_ff_fused_ln")
     if ev is not None:
         M = out.shape[0]
         nbytes = M * 320 * 2 * (2 + (R1 is not None) + (R2 is not None))

@@ -149,9 +149,11 @@ int ctrlv_ff_fused(const void* x, int ldx, const void* w1f, const void* w2f, con
 int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                       const float* ln_V, int ln_vdiv, int ln_vmod, int ln_ldv, const void* w1f, const void* w2f,
                       const ctrlv_gemm_desc* out_desc, ctrlv_stream_t stream);
-/* 1 if ctrlv_ff_fused serves these settings of the second projection (N = 320, Cin = 1280; epilogue bias, +R1 or +R1+R2;
- * a row-vector operand only with vmode 1, vdiv a multiple of 256 and s_acc == 1), 0 = use the two ctrlv_gemm launches. */
-int ctrlv_ff_fused_serves(int n, int cin, int vmode, int vdiv, float s_acc, int has_r1, int has_r2);
+/* 1 if ctrlv_ff_fused serves this second-projection descriptor with input rows of pitch ldx -- N = 320, Cin = 1280,
+ * n_store 320, every operand within 32-bit byte offsets, pitches multiples of 8; epilogue bias, +R1 or +R1+R2; a row-vector
+ * operand (vmode 1 / 2) with bias or +R1, and with +R1+R2 only in the per-tile form (vmode 1, vdiv a multiple of 256,
+ * s_acc == 1) -- 0 = use the two ctrlv_gemm launches.  The launcher applies exactly these conditions. */
+int ctrlv_ff_fused_serves(const ctrlv_gemm_desc* out_desc, int ldx);
 
 /* Row softmax of fp32 scores into bf16 probabilities: probs[r, :cols] = softmax(scores[r, :cols]) (cols a multiple of 4,
  * <= 16384).  The VAE mid block's single-head attention (head dim 512; AutoencoderKLTemporalDecoder, called by

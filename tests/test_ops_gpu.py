@@ -494,7 +494,8 @@ def test_time_conv_rows_to_nchw(ops):
         assert parity_err(out, ref) < (1e-5 if dt == torch.float32 else 3e-3)
 
 
-@pytest.mark.parametrize("M,epi", [(256, "r1"), (1000, "r1"), (2048 + 72, "r1r2"), (777, "r1v"), (512, "none"), (256 * 70, "r1v")])
+@pytest.mark.parametrize("M,epi", [(256, "r1"), (1000, "r1"), (2048 + 72, "r1r2"), (777, "r1v"), (512, "none"), (256 * 70, "r1v"),
+                                   (777, "r1v_epi"), (256 * 9 + 5, "v_epi"), (1500, "r1v2_epi")])
 def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     """ctrlv_ff_fused (C = 320 feed-forward with the 4C-wide intermediate on chip) against the two ctrlv_gemm launches it
     replaces, same packed weights: GEMM 1, the GELU table and the bf16 rounding of u are the same operations, GEMM 2 sums in
@@ -513,17 +514,27 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     w2p = packing.pack_linear(w2.to(DEV))
     w1f, w2f = ops.ff_fused_pack(w1p, b1p.float().contiguous(), w2p)
     kw = {}
-    if epi in ("r1", "r1r2", "r1v"):
+    if epi in ("r1", "r1r2", "r1v", "r1v_epi", "r1v2_epi"):
         kw.update(R1=r1.to(DEV), s1=1.0)
     if epi == "r1r2":
         kw.update(R2=r2.to(DEV), s2=0.25, s_acc=0.75, s1=0.75)
-    if epi == "r1v":        # a row vector per 512 rows (vdiv must be a multiple of the 256-row tile: ff_fused_serves)
+    vidx = None
+    if epi == "r1v":        # a row vector per 512 rows: constant over a 256-row tile, s_acc 1 -> rides in the accumulator start
         kw.update(V=V.to(DEV), vmode=1, vdiv=512, vmod=5)
-        assert ops.ff_fused_serves(320, 1280, vmode=1, vdiv=512, has_r1=True)
-        assert not ops.ff_fused_serves(320, 1280, vmode=1, vdiv=200, has_r1=True)
-        assert not ops.ff_fused_serves(320, 1280, vmode=2, vdiv=512, has_r1=True)
+        vidx = (torch.arange(M) // 512) % 5
+    if epi in ("r1v_epi", "v_epi"):   # vdiv NOT a multiple of the tile: the shared epilogue's row-vector operand (EPI 3 / 1:
+        kw.update(V=V.to(DEV), vmode=1, vdiv=200, vmod=5, s_acc=0.5)    # the instantiations round 3 could not ship)
+        vidx = (torch.arange(M) // 200) % 5
+    if epi == "r1v2_epi":             # the diffusers-0.27.2 context-order map (vmode 2)
+        kw.update(V=V.to(DEV), vmode=2, vdiv=500, vS=100, vmod=5)
+        mm = torch.arange(M)
+        vidx = ((mm // 500) * 100 + mm % 100) % 5
     xd = x.to(DEV)
     out = torch.full((M, C), float("nan"), dtype=EL, device=DEV)
+    assert ops.ff_fused_serves(xd, out, **kw)            # (the launcher's own conditions)
+    if "V" in kw:
+        assert not ops.ff_fused_serves(xd, out, **dict(kw, vmode=1, vdiv=200, R2=r2.to(DEV)))   # R1 + R2 + unfoldable V
+    assert not ops.ff_fused_serves(xd, out[:, :256], **kw) and not ops.ff_fused_serves(xd[:, :312], out, **kw)
     ops.ff_fused(xd, w1f, w2f, out, bias=b2.to(DEV), **kw)
     # the two launches
     u = torch.empty(M, I, dtype=EL, device=DEV)
@@ -542,7 +553,7 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     if "R2" in kw:
         ref = ref + kw["s2"] * r2.double()
     if "V" in kw:
-        ref = ref + V.double()[(torch.arange(M) // 512) % 5]
+        ref = ref + V.double()[vidx]
     assert parity_err(ref2, ref.float()) < tol(3e-3)
     assert parity_err(out, ref.float()) < tol(3e-3)
     assert parity_err(out, ref2.float().cpu()) < tol(3e-3)
@@ -586,11 +597,13 @@ def test_ff_fused_with_the_layernorm_folded_in(ops, M, with_v):
         assert torch.equal(again, out)
 
 
-@pytest.mark.parametrize("epi", ["r1", "r1r2", "r1v"])
+@pytest.mark.parametrize("epi", ["r1", "r1r2", "r1v", "r1v_epi"])
 def test_ff_fused_full_size_is_stable_run_to_run(ops, epi):
     """The fused feed-forward at the benchmark's own size (M = 50 x 9216 rows: 1800 tiles, 8 per workgroup) against the two
     launches, and 12 repeats bit for bit (a race between the wave groups, the LDS rings or the epilogue's staging would
-    show as a difference between runs: the kernel has no atomics)."""
+    show as a difference between runs: the kernel has no atomics).  "r1v_epi" = R1 + a row vector through the shared
+    epilogue (EPI = 3 at TM = 1, TN = 10), the instantiation that stored zero dwords intermittently in round 3 (the
+    store-data hazard, csrc/gemm_pp_kernel.h): 48 repeats."""
     from ctrlv_amd import packing
     C, I, M = 320, 1280, 50 * 9216
     gd = torch.Generator(device=DEV).manual_seed(3)
@@ -605,6 +618,8 @@ def test_ff_fused_full_size_is_stable_run_to_run(ops, epi):
         kw.update(R2=r(M, C).to(EL), s2=0.25, s_acc=0.75, s1=0.75)
     if epi == "r1v":
         kw.update(V=r(25, C), vmode=1, vdiv=9216, vmod=25)
+    if epi == "r1v_epi":
+        kw.update(V=r(25, C), vmode=1, vdiv=9216 + 40, vmod=25)
     u = torch.empty(M, I, dtype=EL, device=DEV)
     ref = torch.empty(M, C, dtype=EL, device=DEV)
     ops.gemm(x, w1p, u, N=2 * I, cin=C, bias=b1, geglu=1)
@@ -617,7 +632,7 @@ def test_ff_fused_full_size_is_stable_run_to_run(ops, epi):
     d = (out.float() - ref.float()).abs()
     assert float(d.max()) < 0.13 and float(d.mean()) < tol(4e-3)          # bf16 outputs of magnitude ~2-4: a few ulps apart at most
     again = torch.empty_like(out)
-    for _ in range(12):
+    for _ in range(48 if epi == "r1v_epi" else 12):
         again.fill_(float("nan"))
         ops.ff_fused(x, w1f, w2f, again, bias=b2, **kw)
         assert torch.equal(again, out)
