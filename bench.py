@@ -322,10 +322,17 @@ def fp16_leg(args, unet, ctrl, ref, device):
     """bf16 runs only: the SAME weights and the SAME sample through the fp16 element build (libctrlv_hip_f16.so) -- its
     parity against the oracle output `ref` (north_star's 1e-3 needs fp16 storage: DESIGN.md 4) and its step time,
     reported beside the bf16 headline.  Not part of `value`."""
-    import copy
     import torch
-    u16 = copy.deepcopy(unet).to(torch.float16)
-    c16 = copy.deepcopy(ctrl).to(torch.float16) if ctrl is not None else None
+    from ctrlv_amd.utils import build_on_device
+
+    def clone16(m):
+        if m is None:
+            return None
+        cfg = {k: v for k, v in dict(m.config).items() if not k.startswith("_")}
+        m2 = build_on_device(type(m), device, torch.bfloat16, **cfg)
+        m2.load_state_dict(m.state_dict())
+        return m2.to(torch.float16)
+    u16, c16 = clone16(unet), clone16(ctrl)
     F = args.frames if (args.cpu_full_step or args.cpu_frames <= 0 or args.cpu_frames >= args.frames) else args.cpu_frames
     out = {"parity": hip_parity(u16, c16, ref, F, args.height // 8, args.width // 8, device)}
     st = make_stepper(u16, c16, device, args, clip_index=0)

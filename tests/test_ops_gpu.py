@@ -534,7 +534,8 @@ def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     assert ops.ff_fused_serves(xd, out, **kw)            # (the launcher's own conditions)
     if "V" in kw:
         assert not ops.ff_fused_serves(xd, out, **dict(kw, vmode=1, vdiv=200, R2=r2.to(DEV)))   # R1 + R2 + unfoldable V
-    assert not ops.ff_fused_serves(xd, out[:, :256], **kw) and not ops.ff_fused_serves(xd[:, :312], out, **kw)
+    x_odd = torch.empty(M, C + 4, dtype=EL, device=DEV)[:, :C]      # row pitch 324: not a multiple of 8 elements
+    assert not ops.ff_fused_serves(xd, out[:, :256], **kw) and not ops.ff_fused_serves(x_odd, out, **kw)
     ops.ff_fused(xd, w1f, w2f, out, bias=b2.to(DEV), **kw)
     # the two launches
     u = torch.empty(M, I, dtype=EL, device=DEV)
