@@ -60,6 +60,42 @@ __device__ __forceinline__ f32x16 mfma_keep_c(const elx8& a, const elx8& b, cons
   return d;
 }
 
+// ---- softmax row sums on the matrix pipe (attn_spatial64_kernel, round 4): EXPERIMENT, -DCTRLV_ATTN_MFMA_SUM.
+// Measured (profiles/r04_attention_mfma_rowsum_ab.txt, A/B on one device): 239 instead of 294 instructions per 64-key tile
+// and wave (VALU 186 -> 131), 8 more MFMAs of 4 passes -- and the SAME time (S = 9216: 4.59-4.61 ms both; in the step 39.8
+// ms both).  Halving the VALU stream does not move the kernel: it is not VALU-issue-bound (as DESIGN.md said until round
+// 3) but bound by the matrix pipe at the clock the chip holds under this load (32 + 4 MFMA-passes-equivalents per tile and
+// wave = 2304 pipe cycles per SIMD and tile pair of ~3200).  Both forms pass the same tests; the VALU sums stay the
+// default (three rounds of full-pipeline runs behind them).
+// l += sum_k P[q][k] is a product with a ones vector.  v_mfma_f32_16x16x32 takes the packed P fragment AS IT SITS (the B
+// operand of the P.V MFMAs: lane = (query r32, key half hsel), 8 keys) as its B operand -- lane l supplies column l % 16,
+// K block l / 16 -- and a constant A operand that has ones in row 0 for K blocks 0, 2 and in row 1 for K blocks 1, 3:
+//   D[0][n] = sum over the 16 keys of the fragment for query n,   D[1][n] = the same for query n + 16
+// (a sum does not care which key sits in which K slot).  Four MFMAs of 4 passes per row block and 64-key tile accumulate
+// in a 16 x 16 result of which lanes 0..15 hold, in elements 0 / 1, the running sums of queries n / n + 16: FOUR registers
+// per row block instead of the 72 v_add_f32 per tile of the VALU form -- the loop is bound by VALU issue, not by the matrix
+// pipe.  The sums are those of the ROUNDED P (what P.V multiplies), in the pipe's accumulation order.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__device__ __forceinline__ f32x4v mfma_16x16x32(const elx8& a, const elx8& b, const f32x4v& c) {
+#ifdef CTRLV_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// P is kept SCALED by 2^-kPShift (the shift rides in the running-max operand: exp2(s - (m + kPShift))) so that "some
+// P >= 2^(kPShift + 1)" -- the slow-path condition -- is ONE BIT of the packed value: bit 14, the exponent's top bit, is
+// set exactly for |x| >= 2 in bf16 and in fp16 alike (P >= 0; inf / NaN have it too).  The test of a whole tile is then
+// an OR over its 32 packed registers (16 v_or3_b32) instead of a sum or a max over 64 scores.  bf16: shift 11, the 2^12
+// limit of the VALU form.  fp16: shift 4 (limit 32 = a score 5 above the kept max, log2 domain): fp16's normal range
+// ends at 2^-14, so P' = P 2^-4 keeps full precision for P >= 2^-10 and the rest is below 1e-3 of the row's largest term.
+// O and l carry the same factor, O / l does not; L = m + kPShift + log2(l').
+#ifdef CTRLV_ELEM_F16
+constexpr float kPShift = 4.0f;
+#else
+constexpr float kPShift = 11.0f;
+#endif
+
 __device__ __forceinline__ elx8 pack_p(const f32x16& p, int s) {
   elx8 r;
 #pragma unroll
@@ -377,7 +413,21 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[rb][dt][e] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+#ifndef CTRLV_ATTN_MFMA_SUM
+  float l_run[2] = {0.f, 0.f};
+#else
+  // running row sums of P' = P 2^-kPShift on the matrix pipe: lanes 0..15, elements 0 / 1 (see mfma_16x16x32)
+  f32x4v lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  elx8 ones;
+  {
+    const int m16 = lane & 15, kb = lane >> 4;
+    const bool on = (m16 == 0 && (kb & 1) == 0) || (m16 == 1 && (kb & 1) == 1);
+    const unsigned one2 = CTRLV_ELEM_DTYPE == 1 ? 0x3C003C00u : 0x3F803F80u;
+    const uint4 u = on ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
+    ones = __builtin_bit_cast(elx8, u);
+  }
+#endif
   // PRE: -m of each row block as the C operand of its score chains (+inf before the first tile: the first tile's sums
   // are inf and take the slow path, exactly as with m = -inf in the subtracting form)
   f32x16 negm[2];
@@ -434,7 +484,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
   auto exp_pack = [&](const f32x16 (&sacc)[2], elx8 (&pf)[2][2], float m, auto direct_tag) -> float {
     constexpr bool DIRECT = decltype(direct_tag)::value;
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#ifndef CTRLV_ATTN_MFMA_SUM
     const float nm = -m;
+#else
+    const float nm = -(m + kPShift);
+#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -454,10 +508,27 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
         elx8& d = pf[kt][e >> 3];
         const int o = e & 7;
         d[o] = (el_native_t)p0; d[o + 1] = (el_native_t)p1; d[o + 2] = (el_native_t)p2; d[o + 3] = (el_native_t)p3;
+#ifndef CTRLV_ATTN_MFMA_SUM
         r0 += p0; r1 += p1; r2 += p2; r3 += p3;
+#endif
       }
     return (r0 + r1) + (r2 + r3);
   };
+#ifdef CTRLV_ATTN_MFMA_SUM
+  // OR of a row block's packed P' registers: bit 14 / 30 set <=> some P' >= 2 (or inf / NaN)
+  auto p_bits = [&](const elx8 (&pf)[2][2]) -> unsigned {
+    unsigned acc = 0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const uint4 u = __builtin_bit_cast(uint4, pf[kt][st]);
+        acc |= u.x | u.y;
+        acc |= u.z | u.w;
+      }
+    return acc;
+  };
+#endif
   auto tile = [&](int t, auto masked_tag) {
     const char* kst = smem + (t % kNS64) * 16384;
     const char* vst = kst + 8192;
@@ -469,7 +540,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::integral_constant<bool, PRE>{});
     }
+#ifndef CTRLV_ATTN_MFMA_SUM
     if (!__all(rs[0] <= kSumLimit && rs[1] <= kSumLimit)) {       // slow path: see attn_spatial_kernel
+#else
+    if (__any(((p_bits(pf[0]) | p_bits(pf[1])) & 0x40004000u) != 0u)) {
+#endif
       f32x16 sacc[2][2];
       scores(kst, sacc, t, masked_tag, std::false_type{});
 #pragma unroll
@@ -483,24 +558,40 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
         const float m_new = fmaxf(m_run[rb], mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
         m_run[rb] = m_new;
+#ifndef CTRLV_ATTN_MFMA_SUM
         l_run[rb] *= alpha;
+#else
+        // the sums of queries n / n + 16 live in lane n (elements 0 / 1): fetch their rescale factors from the query lanes
+        lacc[rb][0] *= __shfl(alpha, lane & 15);
+        lacc[rb][1] *= __shfl(alpha, (lane & 15) + 16);
+#endif
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
         if (PRE) {
 #pragma unroll
+#ifndef CTRLV_ATTN_MFMA_SUM
           for (int e = 0; e < 16; ++e) negm[rb][e] = -m_new;
+#else
+          for (int e = 0; e < 16; ++e) negm[rb][e] = -(m_new + kPShift);
+#endif
         }
         rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::false_type{});
       }
     }
+#ifndef CTRLV_ATTN_MFMA_SUM
     l_run[0] += rs[0];
     l_run[1] += rs[1];
+#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+#ifdef CTRLV_ATTN_MFMA_SUM
+        lacc[0] = mfma_16x16x32(ones, pf[0][kt][s], lacc[0]);
+        lacc[1] = mfma_16x16x32(ones, pf[1][kt][s], lacc[1]);
+#endif
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -533,10 +624,18 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
 
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
+#ifndef CTRLV_ATTN_MFMA_SUM
     const float l_tot = half_sum(l_run[rb]);
+    const float m_fin = m_run[rb];
+#else
+    // query r32's sum: lane r32 & 15, element r32 >> 4 (both key halves are already in it)
+    const float l_lo = __shfl(lacc[rb][0], r32 & 15), l_hi = __shfl(lacc[rb][1], r32 & 15);
+    const float l_tot = (r32 & 16) ? l_hi : l_lo;
+    const float m_fin = m_run[rb] + kPShift;
+#endif
     const float inv = 1.0f / l_tot;
     if (lse && qrow[rb] < S && hsel == 0)
-      lse[((long)img * gridDim.y + head) * S + qrow[rb]] = m_run[rb] + __builtin_amdgcn_logf(l_tot);
+      lse[((long)img * gridDim.y + head) * S + qrow[rb]] = m_fin + __builtin_amdgcn_logf(l_tot);
     if (qrow[rb] < S) {
       el_t* op = out + (row0 + qrow[rb]) * C + head * 64;
 #pragma unroll
