@@ -172,8 +172,8 @@ def cpu_baseline_child(xdir):
     F, h, w = job["frames"], job["h"], job["w"]
     threads = job["threads"]
     if not threads:
-        # calibrate on the workload's own shape (a 2-frame forward at a quarter of the latent: convs, GEMMs, attention in
-        # the oracle's proportions), sweeping the thread count up to the PHYSICAL core count; the fastest wins
+        # calibrate on the workload's own shape (a 1-frame forward at the FULL latent: convs, GEMMs and the 9216-token
+        # attention at their real per-frame size), sweeping the thread count up to the PHYSICAL core count; the fastest wins
         total = os.cpu_count() or 1
         try:
             sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read()
@@ -207,7 +207,7 @@ def cpu_baseline_child(xdir):
         fwd(cpu_sample_inputs(F, 8, 8))          # thread-pool / allocator warm-up on a tiny latent
         sweep = {}
         if not threads:
-            cal = cpu_sample_inputs(2, max(8, h // 16 * 8), max(8, w // 16 * 8))     # half the latent, a multiple of 8
+            cal = cpu_sample_inputs(1, h, w)         # ONE frame at the FULL latent: the per-frame work of the timed sample
             for thr in job["calibrate"]:
                 torch.set_num_threads(thr)
                 t0 = time.perf_counter()
@@ -423,12 +423,7 @@ def main():
     t0 = time.perf_counter()
     timer = None
     for k in range(args.steps):
-        if k == args.steps - 1 and rank == 0 and not args.hip_graph:
-            timer = profiler.KernelTimer()
-            with timer:
-                run_step(st, i)
-        else:
-            run_step(st, i)
+        run_step(st, i)
         i += 1
     torch.cuda.synchronize()
     D.barrier()
@@ -436,10 +431,12 @@ def main():
     finite = bool(torch.isfinite(st.latents).all())
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
-    if rank == 0 and args.hip_graph:
-        # per-kernel HIP-event timing needs eager launches: one extra identical step outside the timed region
+    if rank == 0:
+        # per-kernel HIP-event timing needs eager launches: one extra identical step outside the timed region, through the
+        # SAME executor as the timed steps -- the C++ plan brackets its own launches (ctrlv_plan_profile), so every dispatch
+        # decision of the plan (tile choice, fused feed-forward, column groups) is what the roofline describes
         st.use_hip_graph = False
-        timer = profiler.KernelTimer()
+        timer = profiler.PlanTimer(unet, ctrl) if unet.executor == "plan" else profiler.KernelTimer()
         with timer:
             run_step(st, i)
         torch.cuda.synchronize()
@@ -450,7 +447,7 @@ def main():
     # HBM traffic per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections
     # applied by tools/pmc_summary.py) committed under profiles/.  Only valid for the library it was collected from:
     # the summary carries that library's build id (hash of csrc/ + include/) and is ignored when it differs.
-    pmc, pmc_note = {}, None
+    pmc, pmc_note, pmc_launches = {}, None, {}
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_summary.json")))
@@ -473,6 +470,10 @@ def main():
                     keys = [k for k in keys if k in raw]
                     if keys:
                         pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
+                        # launches per step of the kernels the PMC figure covers (the ping-pong + fused GEMM kernels of a
+                        # family, not its tiny 2-stage launches): traffic x traffic_launches = the family's bytes per step
+                        if all("launches_per_step" in raw[k] for k in keys):
+                            pmc_launches[fam] = max(raw[k]["launches_per_step"] for k in keys)
                 pmc["_source"] = os.path.relpath(cands[-1], ROOT)
     except Exception as ex:       # noqa: BLE001
         pmc_note = f"PMC summary unreadable: {ex}"
@@ -483,13 +484,14 @@ def main():
             ach = d["flops"] / sec / 1e12
             rooflines[fam] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
-                              "traffic": pmc.get(fam),
+                              "traffic": pmc.get(fam), "traffic_launches": pmc_launches.get(fam),
                               "ms_per_step": round(d["ms"], 3), "launches": d["calls"],
                               "avg_launch_ms": round(d["ms"] / d["calls"], 4)}
         else:
             ach = d["bytes"] / sec / 1e9
             rooflines[fam] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc.get(fam),
+                              "traffic_launches": pmc_launches.get(fam),
                               "ms_per_step": round(d["ms"], 3), "launches": d["calls"],
                               "avg_launch_ms": round(d["ms"] / d["calls"], 4)}
     dominant = max(rooflines, key=lambda f: rooflines[f]["ms_per_step"]) if rooflines else None

@@ -44,6 +44,16 @@ class ModelConfig(ctypes.Structure):
     ]
 
 
+class ProfileRecord(ctypes.Structure):
+    """Mirror of `ctrlv_profile_record`."""
+    _fields_ = [("family", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("flags", c_int), ("ms", c_float),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
+FAMILIES = ("gemm_linear", "gemm_conv3x3", "gemm_conv_temporal", "attention_spatial", "attention_temporal", "groupnorm",
+            "layernorm", "residual_add")
+
+
 class TensorDesc(ctypes.Structure):
     """Mirror of `ctrlv_tensor_desc`."""
     _fields_ = [("name", ctypes.c_char_p), ("data", c_void_p), ("dtype", c_int), ("on_device", c_int),
@@ -117,6 +127,8 @@ SIGNATURES = {
                                          c_float, ctypes.POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                          c_size_t, c_void_p]),
     "ctrlv_plan_destroy": (c_int, [c_void_p]),
+    "ctrlv_plan_profile": (c_int, [c_void_p, c_int]),
+    "ctrlv_plan_profile_read": (c_int, [c_void_p, ctypes.POINTER(ProfileRecord), c_int]),
 }
 
 _libs = {}                # element dtype code (2 bf16 / 1 fp16) -> CDLL

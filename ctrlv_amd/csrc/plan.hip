@@ -155,6 +155,11 @@ struct ctrlv_plan {
   std::vector<void*> owned;   // every device allocation of load_weights
   struct WsEntry { int B, F, H, W; size_t bytes; };
   std::vector<WsEntry> ws_cache;   // ctrlv_plan_workspace_bytes per input shape (check_workspace)
+  // per-launch profile of the plan's OWN launches (ctrlv_plan_profile): HIP events on the launch stream around every
+  // kernel the walk issues, with the launch's algorithmic FLOPs / bytes -- bench.py's roofline leg and tools/shape_table.py
+  struct ProfRec { ctrlv_profile_record r; hipEvent_t e0, e1; };
+  bool profiling = false;
+  std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -448,6 +453,37 @@ struct Ctx {
   void release(size_t m) { off = m; }
 };
 
+// One launch (or launch group) of the walk under the profiler: events on the launch stream before / after it.
+struct ProfScope {
+  ctrlv_plan* p = nullptr;
+  hipStream_t st;
+  size_t idx = 0;
+  ProfScope(Ctx& c, int family, double flops, double bytes, int M = 0, int N = 0, int K = 0, int flags = 0) : st(c.st) {
+    if (c.dry || !c.p->profiling) return;
+    ctrlv_plan::ProfRec pr;
+    memset(&pr.r, 0, sizeof(pr.r));
+    pr.r.family = family; pr.r.M = M; pr.r.N = N; pr.r.K = K; pr.r.flags = flags; pr.r.flops = flops; pr.r.bytes = bytes;
+    if (hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess) return;
+    (void)hipEventRecord(pr.e0, st);
+    p = c.p;
+    idx = p->prof.size();
+    p->prof.push_back(pr);
+  }
+  ~ProfScope() {
+    if (p) (void)hipEventRecord(p->prof[idx].e1, st);
+  }
+};
+// algorithmic work of a gather-GEMM launch (the accounting of ops.py: 2 MAC per output element and K step; operands once)
+void gemm_work(const ctrlv_gemm_desc& d, int* fam, double* flops, double* bytes) {
+  *fam = d.mode == 1 ? CTRLV_FAM_GEMM_CONV3X3 : (d.mode == 2 ? CTRLV_FAM_GEMM_CONV_TEMPORAL : CTRLV_FAM_GEMM_LINEAR);
+  const double n_alg = d.geglu ? d.N : (d.N < d.n_store ? d.N : d.n_store);
+  const double n_out = d.geglu ? (d.n_store < d.N / 2 ? d.n_store : d.N / 2) : d.n_store;
+  const double K = (double)d.taps * d.Cin;
+  *flops = 2.0 * d.M * n_alg * K;
+  *bytes = (double)d.M * d.Cin * 2 + (double)d.M * n_out * ((d.out_f32 & 1) ? 4 : 2) + (double)d.N * K * 2 +
+           (d.R1 ? (double)d.M * n_out * 2 : 0) + (d.R2 ? (double)d.M * n_out * 2 : 0);
+}
+
 ctrlv_gemm_desc gd(const void* A, int lda, const Linear& w, void* out, int ldo, int M, int N, int cin, int n_store) {
   ctrlv_gemm_desc d;
   memset(&d, 0, sizeof(d));
@@ -461,6 +497,9 @@ ctrlv_gemm_desc gd(const void* A, int lda, const Linear& w, void* out, int ldo, 
 int gemm(Ctx& c, const ctrlv_gemm_desc& d) {
   if (c.dry) return CTRLV_OK;
   if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+  int fam; double fl, by;
+  gemm_work(d, &fam, &fl, &by);
+  ProfScope ps(c, fam, fl, by, d.M, d.N, d.taps * d.Cin, (d.geglu ? 1 : 0) | ((d.R1 ? 1 : 0) + (d.R2 ? 1 : 0)) << 1 | d.vmode << 3);
   return ctrlv_gemm(&d, c.st);
 }
 int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
@@ -472,6 +511,7 @@ int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int
   int rc = CTRLV_OK;
   if (!c.dry) {
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * n_img * (double)S * C, n_img * S, C);   // algorithmic: 1 read + 1 write
     rc = ctrlv_groupnorm_stats(x, x2, c_split, n_img, S, C, ips, eps, part, c.st);
     if (rc == CTRLV_OK) rc = ctrlv_groupnorm_apply(x, x2, c_split, n_img, S, C, ips, part, nm.g, nm.b, silu, y, c.st);
   }
@@ -481,6 +521,7 @@ int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int
 int layernorm(Ctx& c, const el_t* x, int M, int C, const Norm& nm, el_t* y, const float* V = nullptr, int vdiv = 1,
               int vmod = 1 << 30, int ldv = 0) {
   if (c.dry) return CTRLV_OK;
+  ProfScope ps(c, CTRLV_FAM_LAYERNORM, 0.0, 2.0 * 2 * (double)M * C, M, C);
   return ctrlv_layernorm(x, M, C, nm.g, nm.b, 1e-5f, V, vdiv, vmod, ldv, y, c.st);
 }
 
@@ -596,6 +637,8 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
   if (fuse && f.w1f && ctrlv_ff_fused_serves(&outd, proj.lda)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
+                 (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0)), outd.M, 320, 320, 0x100);
     return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, f.w2f, &outd, c.st);
   }
   if (*u == nullptr) *u = c.rows(proj.M, 4 * C);
@@ -629,6 +672,8 @@ int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const el_t* xraw, const floa
   if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(&outd, C)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
+                 (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0)), outd.M, 320, 320, 0x300);
     return ctrlv_ff_fused_ln(xraw, C, nm.g, nm.b, 1e-5f, lnV, lnvdiv, lnvmod, lnldv, f.w1f, f.w2f, &outd, c.st);
   }
   TRY(layernorm(c, xraw, proj.M, C, nm, tt, lnV, lnvdiv, lnvmod, lnldv));
@@ -660,7 +705,10 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     TRY(gemm(c, d));
   }
   el_t* a = c.rows(M, C);
-  if (!c.dry) TRY(ctrlv_attention_spatial_prescaled(qkv, a, N, S, C, c.st));
+  if (!c.dry) {
+    ProfScope ps(c, CTRLV_FAM_ATTENTION_SPATIAL, 4.0 * N * (C / 64) * (double)S * S * 64, 2.0 * 4 * N * (double)S * C, N, S, C);
+    TRY(ctrlv_attention_spatial_prescaled(qkv, a, N, S, C, c.st));
+  }
   el_t* h1 = c.rows(M, C);
   {   // attn2 with one key == to_out(to_v(ehs[b])) for every query: a per-clip row vector
     ctrlv_gemm_desc d = gd(a, C, t.s_o, h1, C, (int)M, C, C, C);
@@ -689,7 +737,11 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
   }
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
-  if (!c.dry) TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
+  if (!c.dry) {
+    ProfScope ps(c, CTRLV_FAM_ATTENTION_TEMPORAL, 4.0 * B * S * (C / 64) * (double)F * F * 64, 2.0 * 4 * B * F * (double)S * C, B * S,
+                 F, C);
+    TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
+  }
   el_t* g1 = c.rows(M, C);
   {
     ctrlv_gemm_desc d = gd(a, C, t.t_o, g1, C, (int)M, C, C, C);
@@ -877,9 +929,12 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
       for (size_t i = 0; i < taps.size(); ++i) {
         CTRLV_CHECK_ARG(down_res[i] != nullptr, "unet_forward: down_res[%zu] is null", i);
         const size_t n = (size_t)N * taps[i].H * taps[i].W * taps[i].C;
+        ProfScope ps(c, CTRLV_FAM_RESIDUAL_ADD, 0.0, 2.0 * 3 * (double)n, (int)(n / taps[i].C), taps[i].C);
         TRY(ctrlv_axpby(taps[i].x, down_res[i], 1.0f, 1.0f, taps[i].x, n, c.st));
       }
-      TRY(ctrlv_axpby(x, mid_res, 1.0f, 1.0f, x, (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1], c.st));
+      const size_t nm_ = (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1];
+      ProfScope ps(c, CTRLV_FAM_RESIDUAL_ADD, 0.0, 2.0 * 3 * (double)nm_, N * H * W, p->cfg.block_out_channels[p->cfg.n_blocks - 1]);
+      TRY(ctrlv_axpby(x, mid_res, 1.0f, 1.0f, x, nm_, c.st));
     }
   }
   for (auto& b : p->up) {           // :140-158 -- torch.cat([hidden, skip], dim=1) is read in place (x | x2)
@@ -986,6 +1041,7 @@ extern "C" int ctrlv_plan_destroy(ctrlv_plan* p) {
   const bool sw = hipGetDevice(&dev) == hipSuccess && dev != p->device;
   if (sw) (void)hipSetDevice(p->device);
   free_owned(p);
+  for (auto& r : p->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (sw) (void)hipSetDevice(dev);
   delete p;
   return CTRLV_OK;
@@ -1231,4 +1287,30 @@ extern "C" int ctrlv_controlnet_forward(ctrlv_plan* p, const void* sample, const
                                     conditioning_scale, out_down, out_mid, H, W);
   if (rc == CTRLV_OK && c.overflow) { ctrlv_set_error("controlnet_forward: workspace too small (need >= %zu bytes)", c.peak + 256); return CTRLV_E_WORKSPACE; }
   return rc;
+}
+
+// ---- per-launch profile of the plan's own launches (include/ctrlv_hip.h)
+extern "C" int ctrlv_plan_profile(ctrlv_plan* p, int enable) {
+  CTRLV_CHECK_ARG(p != nullptr, "plan_profile: null plan");
+  for (auto& r : p->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  p->prof.clear();
+  p->profiling = enable != 0;
+  return CTRLV_OK;
+}
+extern "C" int ctrlv_plan_profile_read(ctrlv_plan* p, ctrlv_profile_record* out, int max_records) {
+  CTRLV_CHECK_ARG(p != nullptr && (out != nullptr || max_records == 0), "plan_profile_read: null pointer");
+  const int n = (int)p->prof.size();
+  if (max_records == 0) return n;                            // (count query)
+  const int m = n < max_records ? n : max_records;
+  for (int i = 0; i < m; ++i) {
+    auto& r = p->prof[i];
+    CTRLV_HIP_TRY(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    CTRLV_HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+    r.r.ms = ms;
+    out[i] = r.r;
+  }
+  for (auto& r : p->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  p->prof.clear();
+  return m;
 }

@@ -97,6 +97,21 @@ class Plan:
         check(self._lib.ctrlv_plan_load_weights(self._h, arr, len(items)), "ctrlv_plan_load_weights")
         del keep
 
+    def profile(self, enable=True):
+        """Bracket every kernel the plan issues with HIP events (eager forwards only; not under graph capture)."""
+        check(self._lib.ctrlv_plan_profile(self._h, 1 if enable else 0), "ctrlv_plan_profile")
+
+    def profile_read(self):
+        """[(family, ms, flops, bytes, (M, N, K, flags))] of the launches since profile(True), in launch order."""
+        n = self._lib.ctrlv_plan_profile_read(self._h, None, 0)
+        if n <= 0:
+            return []
+        arr = (_lib.ProfileRecord * n)()
+        m = self._lib.ctrlv_plan_profile_read(self._h, arr, n)
+        if m < 0:
+            check(m, "ctrlv_plan_profile_read")
+        return [(_lib.FAMILIES[r.family], r.ms, r.flops, r.bytes, (r.M, r.N, r.K, r.flags)) for r in arr[:m]]
+
     def set_time_context_order(self, order):
         check(self._lib.ctrlv_plan_set_time_context_order(self._h, 0 if order == "sb" else 1),
               "ctrlv_plan_set_time_context_order")

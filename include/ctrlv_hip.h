@@ -352,6 +352,25 @@ int ctrlv_controlnet_forward(ctrlv_plan* plan, const void* sample, const void* c
                              int H, int W, void* workspace, size_t workspace_bytes, ctrlv_stream_t stream);
 int ctrlv_plan_destroy(ctrlv_plan* plan);
 
+/* Per-launch profile of the plan's OWN launches (measurement aid: bench.py's roofline leg, tools/shape_table.py).  While
+ * enabled, every kernel a forward issues is bracketed by HIP events on the launch stream and recorded with its algorithmic
+ * FLOPs / bytes (SURVEY.md Appendix B accounting).  Enable OUTSIDE HIP-graph capture and for eager forwards only.
+ * ctrlv_plan_profile_read synchronises on the recorded events, writes up to max_records records in launch order, clears
+ * the list and returns the number written (max_records == 0: the number pending, nothing cleared); <0 on error. */
+enum {
+  CTRLV_FAM_GEMM_LINEAR = 0, CTRLV_FAM_GEMM_CONV3X3 = 1, CTRLV_FAM_GEMM_CONV_TEMPORAL = 2, CTRLV_FAM_ATTENTION_SPATIAL = 3,
+  CTRLV_FAM_ATTENTION_TEMPORAL = 4, CTRLV_FAM_GROUPNORM = 5, CTRLV_FAM_LAYERNORM = 6, CTRLV_FAM_RESIDUAL_ADD = 7,
+};
+typedef struct ctrlv_profile_record {
+  int32_t family;             /* CTRLV_FAM_* */
+  int32_t M, N, K;            /* GEMM: rows, weight rows, taps * Cin; attention: images, tokens, channels; norms: rows, channels */
+  int32_t flags;              /* GEMM: bit 0 GEGLU, bits 1-2 residual operands, bits 3-4 vmode, bit 8 fused feed-forward */
+  float ms;                   /* elapsed between the launch's two events */
+  double flops, bytes;        /* algorithmic work of the launch */
+} ctrlv_profile_record;
+int ctrlv_plan_profile(ctrlv_plan* plan, int enable);
+int ctrlv_plan_profile_read(ctrlv_plan* plan, ctrlv_profile_record* out, int max_records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,3 +183,33 @@ def test_unet_encoder_forward_matches_the_python_executor(hip_lib):
     assert len(rows) == len(want)
     for got, ref in zip(rows, want):
         assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+@torch.no_grad()
+def test_plan_profile_matches_the_python_executors_accounting(hip_lib):
+    """ctrlv_plan_profile: the plan brackets its OWN launches with HIP events (what bench.py's roofline leg reads).  Per
+    family, the number of launches and the algorithmic FLOPs / bytes equal what the per-op Python executor records for the
+    same forward (ctrlv_amd/profiler.KernelTimer) -- the two executors issue the same kernels -- and every launch has a time."""
+    import ctrlv_ref as R
+    from ctrlv_amd import profiler
+    cfg = dict(R.TINY_CONFIG)
+    _, _, hu, hc = make_pair(cfg, DEV)
+    inputs = make_inputs(cfg, 2, 3, 16, 16)
+    _fwd(hu, hc, inputs, torch.bfloat16)                      # plans exist
+    with profiler.PlanTimer(hu, hc) as pt:
+        a = _fwd(hu, hc, inputs, torch.bfloat16)
+    with profiler.KernelTimer() as kt:                        # (switches the models to the Python executor)
+        b = _fwd(hu, hc, inputs, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(a["unet"], b["unet"])
+    ps, ks = pt.summary(), kt.summary()
+    assert set(ps) == set(ks) and len(pt.launches) > 300
+    for fam in ks:
+        assert ps[fam]["calls"] == ks[fam]["calls"], (fam, ps[fam], ks[fam])
+        assert abs(ps[fam]["flops"] - ks[fam]["flops"]) <= 1e-9 * max(1.0, ks[fam]["flops"]), fam
+        assert abs(ps[fam]["bytes"] - ks[fam]["bytes"]) <= 1e-9 * max(1.0, ks[fam]["bytes"]), fam
+        assert ps[fam]["ms"] > 0.0
+    with profiler.PlanTimer(hu, hc) as pt2:                   # a second use starts from an empty list
+        _fwd(hu, hc, inputs, torch.bfloat16, with_ctrl=False)
+    assert 0 < len(pt2.launches) < len(pt.launches)
+    assert hu._plan.profile_read() == []                      # ... and leaves none behind

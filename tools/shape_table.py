@@ -18,23 +18,23 @@ def main():
     from ctrlv_amd import profiler
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    unet, ctrl = bench.build_models(dev, args.workload, args.frames)
+    unet, ctrl = bench.build_models(dev, args.workload, args.frames, bench.torch_dtype(args.dtype))
     args.hip_graph = False
     st = bench.make_stepper(unet, ctrl, dev, args, clip_index=0)
     st.use_hip_graph = False
     for i in range(2):
         bench.run_step(st, i)
     torch.cuda.synchronize()
-    timer = profiler.KernelTimer()
+    timer = profiler.PlanTimer(unet, ctrl)         # the C++ plan's own launches (ctrlv_plan_profile)
     with timer:
         bench.run_step(st, 2)
-    torch.cuda.synchronize()
     agg = {}
-    for (fam, fl, by, s, e), det in zip(timer.records, timer.details):
-        if det is None:
+    for fam, ms, fl, by, (M, N, K, flags) in timer.launches:
+        if not fam.startswith("gemm"):
             continue
+        det = ("ff_fused" if flags & 0x100 else fam, M, N, K, flags & 1, (flags >> 1) & 3, (flags >> 3) & 3, 0)
         d = agg.setdefault(det, [0, 0.0, 0.0, 0.0])
-        d[0] += 1; d[1] += s.elapsed_time(e); d[2] += fl; d[3] += by
+        d[0] += 1; d[1] += ms; d[2] += fl; d[3] += by
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for _, v in rows)
     print(f"{'family':20s} {'M':>7s} {'N':>6s} {'K':>6s} gg R V act  calls     ms   TFLOP/s    GB/s   bound-ms  of-bound")
