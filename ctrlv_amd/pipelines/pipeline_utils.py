@@ -198,7 +198,7 @@ def resolve_pretrained_dir(name_or_path):
 class ClipJob:
     """Everything one pipeline call has prepared before its denoising loop (SVDPipelineBase.prepare_clip)."""
     __slots__ = ("height", "width", "num_frames", "decode_chunk", "clips", "device", "clip_embeds", "cond_latents",
-                 "time_ids", "latents", "vae_was_fp16")
+                 "time_ids", "latents", "vae_was_fp16", "cfg")
 
 
 class SVDPipelineBase:
@@ -449,7 +449,10 @@ class SVDPipelineBase:
             job.clips = len(image) if isinstance(image, list) else image.shape[0]
         dev = job.device = self._execution_device
         self._guidance_scale = max_guidance_scale              # scalar first: do_classifier_free_guidance reads it
-        cfg = self.do_classifier_free_guidance
+        # ONE classifier-free-guidance decision per call, taken from the scalar like the reference's encoders do
+        # (pipeline_video_control.py:206-284 run before the per-frame ramp is installed, :287-290): every conditioning
+        # tensor and the loop use it -- no device read of ramp.max(), no half-doubled inputs when min > 1 >= max
+        cfg = job.cfg = bool(self.do_classifier_free_guidance)
         job.clip_embeds = self._encode_image(image, dev, num_videos_per_prompt, cfg)
         dt = job.clip_embeds.dtype
         # first frame -> (noise-augmented) VAE latent, repeated over the frames
@@ -489,13 +492,14 @@ class SVDPipelineBase:
 
     def _denoise(self, latents, image_latents, image_embeddings, added_time_ids, cond_em, num_inference_steps,
                  min_guidance_scale, max_guidance_scale, control_condition_scale, callback_on_step_end,
-                 callback_on_step_end_tensor_inputs, progress_bar):
+                 callback_on_step_end_tensor_inputs, progress_bar, do_cfg=None):
         """Loop of pipeline_video_control.py:298-343.  `latents` (B, F, 4, h, w) any float dtype."""
         model_dtype = image_embeddings.dtype
         controlnet = getattr(self, "controlnet", None) if cond_em is not None else None
         stepper = DenoiseStepper(self.unet, controlnet, self.scheduler, latents, image_latents, image_embeddings,
                                  added_time_ids, cond_em, min_guidance_scale, max_guidance_scale,
-                                 control_condition_scale, do_cfg=bool(self.do_classifier_free_guidance),
+                                 control_condition_scale,
+                                 do_cfg=bool(self.do_classifier_free_guidance) if do_cfg is None else bool(do_cfg),
                                  use_hip_graph=bool(self.use_hip_graph))
         for i, t in enumerate(self.scheduler.timesteps):
             noise_pred = stepper.step(i)

@@ -68,9 +68,9 @@ class StableVideoControlPipeline(SVDPipelineBase):
         control = None
         if cond_images is not None:
             control = self._encode_vae_condition(cond_images, job.device, num_videos_per_prompt,
-                                                 self.do_classifier_free_guidance).to(job.clip_embeds.dtype)
+                                                 job.cfg).to(job.clip_embeds.dtype)
         with self.progress_bar(total=num_inference_steps) as bar:          # the loop (:295-343) on the HIP models
             out = self._denoise(job.latents, job.cond_latents, job.clip_embeds, job.time_ids, control,
                                 num_inference_steps, min_guidance_scale, max_guidance_scale, control_condition_scale,
-                                callback_on_step_end, callback_on_step_end_tensor_inputs, bar)
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, bar, do_cfg=job.cfg)
         return self.finish_clip(job, out, output_type, return_dict)

@@ -63,11 +63,11 @@ class VideoDiffusionPipeline(SVDPipelineBase):
             max_guidance_scale=max_guidance_scale, num_inference_steps=num_inference_steps)
         if bbox_images is not None:        # bbox-frame latents replace the first / last conditioning frames (:200-206)
             boxes = self._encode_vae_condition(bbox_images, job.device, num_videos_per_prompt,
-                                               self.do_classifier_free_guidance).to(job.cond_latents.dtype)
+                                               job.cfg).to(job.cond_latents.dtype)
             job.cond_latents[:, 0:num_cond_bbox_frames] = boxes[:, 0:num_cond_bbox_frames]
             job.cond_latents[:, -1] = boxes[:, -1]
         with self.progress_bar(total=num_inference_steps) as bar:
             out = self._denoise(job.latents, job.cond_latents, job.clip_embeds, job.time_ids, None,
                                 num_inference_steps, min_guidance_scale, max_guidance_scale, 1.0,
-                                callback_on_step_end, callback_on_step_end_tensor_inputs, bar)
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, bar, do_cfg=job.cfg)
         return self.finish_clip(job, out, output_type, return_dict, clamp=True)      # decoded frames clamped (:297)

@@ -257,7 +257,13 @@ class GradientBuckets:
     its bucket down and launches the bucket's asynchronous all-reduce (RCCL: on its own stream) the moment the last
     gradient of the bucket exists, while the backward pass keeps running.  `finish()` -- after `loss.backward()` --
     flushes buckets whose parameters got no gradient (zeros: every rank issues identical collectives), waits, divides by
-    the world size and writes the averaged gradients back.  One instance per model; re-armed by `finish()`."""
+    the world size and writes the averaged gradients back.  One instance per model; re-armed by `finish()`.
+
+    Collective ORDER is fixed: bucket i is launched only after buckets 0 .. i-1 (the expected completion order), whatever
+    the order in which the hooks fire -- ranks whose graphs differ (a branch that is taken on one rank only) still issue
+    the same sequence of all-reduces.  A parameter learnt as "unused" that receives a gradient after all, after its
+    bucket has gone out, marks the bucket DIRTY: `finish()` agrees on the dirty set across ranks (one MAX all-reduce of a
+    byte mask) and reduces those buckets again with the gradient in place, so no gradient is ever dropped."""
 
     def __init__(self, params, bucket_bytes=25 * 1024 * 1024, group=None):
         import torch.distributed as dist
@@ -289,6 +295,8 @@ class GradientBuckets:
         self.inflight = [None] * len(self.buckets)
         self.launch_order = []
         self.fired = set()
+        self.next = 0                     # buckets [0, next) have been launched: the collective order is the bucket order
+        self.dirty = set()                # buckets that went out before a (formerly unused) parameter's gradient arrived
 
     def _launch(self, i):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).float().reshape(-1) for p in self.buckets[i]])
@@ -300,19 +308,31 @@ class GradientBuckets:
             return
         i = self.bucket_of[id(p)]
         self.fired.add(id(p))
-        if id(p) in self.unused:          # (it has a gradient after all: count it again from the next step on)
-            self.unused.discard(id(p))
+        if id(p) in self.unused:          # it has a gradient after all: count it again from the next step on, and
+            self.unused.discard(id(p))    # reduce its bucket again if that has already gone out without this gradient
+            if self.inflight[i] is not None:
+                self.dirty.add(i)
             return
         self.pending[i] -= 1
-        if self.pending[i] == 0 and self.inflight[i] is None:
-            self._launch(i)
+        while self.next < len(self.buckets) and self.pending[self.next] <= 0:
+            self._launch(self.next)
+            self.next += 1
 
     def finish(self):
         if not self.active or not self.enabled:
             return 0
-        for i in range(len(self.buckets)):
-            if self.inflight[i] is None:
-                self._launch(i)
+        while self.next < len(self.buckets):
+            self._launch(self.next)
+            self.next += 1
+        # late gradients: every rank must re-reduce the same buckets, in the same order
+        mask = torch.zeros(len(self.buckets), dtype=torch.uint8, device=self.inflight[0][0].device)
+        for i in self.dirty:
+            mask[i] = 1
+        self.dist.all_reduce(mask, op=self.dist.ReduceOp.MAX, group=self.group)
+        redo = [i for i, v in enumerate(mask.tolist()) if v]
+        for i in redo:
+            self.inflight[i][1].wait()
+            self._launch(i)
         for i, b in enumerate(self.buckets):
             flat, work = self.inflight[i]
             work.wait()

@@ -176,6 +176,18 @@ def _overlap_worker(rank, world, port, out):
     local_sum = [p.grad.clone() for p in net.parameters()]       # (hooks fired on the accumulated .grad)
     gb.finish()
     res.append((local_sum[0].numpy().tobytes(), next(net.parameters()).grad.numpy().tobytes()))
+    # a parameter learnt as unused (no gradient in the steps above) that receives one after all, on ONE rank only and late
+    # (it is the first layer's companion: its hook fires after its bucket has gone out): nothing may be dropped
+    late = unused
+    for p in params:
+        p.grad = None
+    x = torch.randn(16, 64, generator=torch.Generator().manual_seed(500 + rank))
+    y = net(x).square().mean()
+    if rank == 1:
+        y = y + (late * torch.arange(5.0)).sum()
+    y.backward()
+    gb.finish()
+    res.append((late.grad.numpy().tobytes(), next(net.parameters()).grad.numpy().tobytes()))
     out.put((rank, res))
     dist.destroy_process_group()
 
@@ -195,6 +207,9 @@ def test_gradient_buckets_overlap_backward_over_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     import numpy as np
+    (l0, w0), (l1, w1) = got[0][3], got[1][3]            # the late gradient of rank 1: mean of (0, arange(5)), on both ranks
+    assert l0 == l1 and w0 == w1
+    assert np.allclose(np.frombuffer(l0, np.float32), np.arange(5.0) / 2)
     (s0, a0), (s1, a1) = got[0][2], got[1][2]            # accumulated micro-batches: mean over ranks of the local SUMS
     assert a0 == a1
     assert np.allclose(np.frombuffer(a0, np.float32), (np.frombuffer(s0, np.float32) + np.frombuffer(s1, np.float32)) / 2,
@@ -202,7 +217,11 @@ def test_gradient_buckets_overlap_backward_over_gloo_world2():
     for step in range(2):
         (n0, early0, loc0, avg0, u0), (n1, early1, loc1, avg1, u1) = got[0][step], got[1][step]
         assert n0 == n1 >= 3 and u0 == u1 == 0.0
-        assert early0 == early1 and len(early0) >= n0 - 1 and early0 == sorted(early0)      # launched inside backward, in order
+        # launched inside backward, in BUCKET ORDER (the collective order is fixed).  Step 0 does not know yet that the
+        # parameter at the head of bucket 0 never gets a gradient: it waits for it, so everything goes out in finish();
+        # from step 1 on the unused parameter is known and all buckets but (at most) the last go out during backward.
+        assert early0 == early1 and early0 == list(range(len(early0)))
+        assert len(early0) >= (n0 - 1 if step == 1 else 0)
         assert avg0 == avg1
         for a, b, m in zip(loc0, loc1, avg0):
             mean = (np.frombuffer(a, np.float32) + np.frombuffer(b, np.float32)) / 2
