@@ -196,6 +196,9 @@ def test_plan_profile_matches_the_python_executors_accounting(hip_lib):
     _, _, hu, hc = make_pair(cfg, DEV)
     inputs = make_inputs(cfg, 2, 3, 16, 16)
     _fwd(hu, hc, inputs, torch.bfloat16)                      # plans exist
+    hu.executor = hc.executor = "python"                      # ... and the Python executor's per-model caches (its frame
+    _fwd(hu, hc, inputs, torch.bfloat16)                      # embeddings are two GEMMs per transformer on first use; the
+    hu.executor = hc.executor = "plan"                        # plan computes them when the weights are loaded)
     with profiler.PlanTimer(hu, hc) as pt:
         a = _fwd(hu, hc, inputs, torch.bfloat16)
     with profiler.KernelTimer() as kt:                        # (switches the models to the Python executor)
