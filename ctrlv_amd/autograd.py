@@ -14,6 +14,7 @@ Second slice: LayerNorm, GEGLU, the attention cores (flash-style backward, csrc/
 whole fused epilogue (FusedLinear / BlendLinear) => a complete `TransformerSpatioTemporalModel`; stride-2 and
 upsample-fused convs.  The model-level training step built from these lives in ctrlv_amd/training.py.
 """
+import contextlib
 import math
 import os
 import weakref
@@ -287,19 +288,97 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dg.to(pdt), db.to(pdt), dV, None, None
 
 
+# ---- gradient checkpointing of the GEGLU feed-forwards (`enable_gradient_checkpointing()`, reference:
+# tools/train_video_controlnet.py:185-186).  The two 4C / 8C-wide intermediates of a feed-forward -- u (saved by the
+# output projection for its wgrad) and the raw projection (saved for the GEGLU backward) -- are 31 GB of the step's 101 GB
+# at the reference's size.  Checkpointed, NEITHER is kept: the forward does not even write the raw projection, and the
+# backward recomputes both with the forward's own launch (one GEGLU GEMM with raw_out: the same bits).  u is saved by
+# whichever Function consumes it (FusedLinear / BlendLinear), so it is swapped for a recompute cell by a saved-tensor hook
+# that is active around the feed-forward pair only.
+_CKPT = [False]
+
+
+@contextlib.contextmanager
+def gradient_checkpointing(enabled):
+    """Training forwards built inside run their GEGLU feed-forwards checkpointed (see above)."""
+    prev = _CKPT[0]
+    _CKPT[0] = bool(enabled)
+    try:
+        yield
+    finally:
+        _CKPT[0] = prev
+
+
+class _GegluCell:
+    """Recompute cell of one checkpointed GEGLU projection: holds its small inputs, hands out u / raw once each."""
+
+    def __init__(self, x, weight, bias):
+        self.x, self.w, self.b = x, weight, bias
+        self.u = self.raw = None
+        self.done = False
+        self.u_ptr = 0
+
+    def _recompute(self):
+        if self.done:
+            return
+        two_i = self.w.shape[0]
+        wp, bp = _pack_fwd(self.w, 0, geglu=True), packing.geglu_interleave(self.b.detach()).float().contiguous()
+        M = self.x.shape[0]
+        self.u, self.raw = _rows(M, two_i // 2, self.x), _rows(M, two_i, self.x)
+        ops.gemm(self.x, wp, self.u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=self.raw)
+        self.done = True
+
+    def take(self, which):
+        self._recompute()
+        t = getattr(self, which)
+        setattr(self, which, None)
+        return t
+
+
+_CELLS = {}          # data_ptr of a live checkpointed u -> its cell (only while the feed-forward pair is being built)
+
+
+def _ckpt_pack(t):
+    cell = _CELLS.pop(t.data_ptr(), None) if t.is_cuda else None
+    return (cell,) if cell is not None else t
+
+
+def _ckpt_unpack(obj):
+    return obj[0].take("u") if isinstance(obj, tuple) else obj
+
+
+@contextlib.contextmanager
+def _ff_region():
+    """Around one GEGLU projection + its output projection: under checkpointing the consumer's saved u becomes a cell."""
+    if not _CKPT[0]:
+        yield
+        return
+    with torch.autograd.graph.saved_tensors_hooks(_ckpt_pack, _ckpt_unpack):
+        try:
+            yield
+        finally:
+            _CELLS.clear()
+
+
 class GegluProj(torch.autograd.Function):
     """u = a * gelu_erf(g), (a | g) = x @ W^T + b   (diffusers GEGLU: `proj` Linear(C -> 2 I), chunk, exact gelu).  The
     forward is ONE GEMM with the GEGLU epilogue that ALSO writes the raw projection (bf16, packed column order) for the
     backward -- u itself comes from the fp32 accumulators exactly as in the inference path; shapes the ping-pong tiles do
-    not serve (K < 128) recompute the raw projection in the backward instead."""
+    not serve (K < 128) recompute the raw projection in the backward instead.  Under gradient checkpointing (above) the
+    raw projection is neither written nor kept: the backward takes it from the recompute cell."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         two_i, cin = weight.shape
         wp, bp = _pack_fwd(weight, 0, geglu=True), packing.geglu_interleave(bias.detach()).float().contiguous()
         u = _rows(x.shape[0], two_i // 2, x)
-        raw = _rows(x.shape[0], two_i, x) if (cin >= 128 and cin % 32 == 0) else None
+        ckpt = _CKPT[0] and cin >= 128 and cin % 32 == 0
+        raw = _rows(x.shape[0], two_i, x) if (cin >= 128 and cin % 32 == 0 and not ckpt) else None
         ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=raw)
+        ctx.cell = None
+        if ckpt:
+            ctx.cell = _GegluCell(x, weight, bias)
+            _CELLS[u.data_ptr()] = ctx.cell
         ctx.save_for_backward(x, weight, bias, raw if raw is not None else torch.empty(0, device=x.device))
         ctx.has_raw = raw is not None
         return u
@@ -310,7 +389,10 @@ class GegluProj(torch.autograd.Function):
         two_i, cin = weight.shape
         inner = two_i // 2
         wi = packing.geglu_interleave(weight.detach())                 # rows in the packed (value, gate) block order
-        if not ctx.has_raw:
+        if ctx.cell is not None:
+            raw = ctx.cell.take("raw")                                 # (recomputed together with u: one launch)
+            ctx.cell = None
+        elif not ctx.has_raw:
             wp, bp = packing.pack_geglu(weight, bias)
             raw = _rows(x.shape[0], two_i, x)
             ops.gemm(x, wp, raw, N=two_i, cin=wp.shape[1], bias=bp)    # activation recompute (no GEGLU epilogue)
@@ -526,16 +608,22 @@ def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
     a = SpatialAttention.apply(qkv, N, S, C)
     h1 = FusedLinear.apply(a, sb.attn1.to_out[0].weight, sb.attn1.to_out[0].bias, h0, None, xvec(sb.attn2),
                            dict(vdiv=F * S))
-    u = GegluProj.apply(ln(h1, sb.norm3), sb.ff.net[0].proj.weight, sb.ff.net[0].proj.bias)
-    h2 = FusedLinear.apply(u, sb.ff.net[2].weight, sb.ff.net[2].bias, h1, None, None, {})
+    with _ff_region():
+        u = GegluProj.apply(ln(h1, sb.norm3), sb.ff.net[0].proj.weight, sb.ff.net[0].proj.bias)
+        h2 = FusedLinear.apply(u, sb.ff.net[2].weight, sb.ff.net[2].bias, h1, None, None, {})
+    del u
     # ---- temporal block: rows stay ordered (b, f, s); the frame embedding is added inside the consumers
-    u = GegluProj.apply(ln(h2, tb.norm_in, emb, S, F), tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias)
-    g0 = FusedLinear.apply(u, tb.ff_in.net[2].weight, tb.ff_in.net[2].bias, h2, None, emb, dict(vdiv=S, vmod=F))
+    with _ff_region():
+        u = GegluProj.apply(ln(h2, tb.norm_in, emb, S, F), tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias)
+        g0 = FusedLinear.apply(u, tb.ff_in.net[2].weight, tb.ff_in.net[2].bias, h2, None, emb, dict(vdiv=S, vmod=F))
+    del u
     qkv = FusedLinear.apply(ln(g0, tb.norm1), qkv_w(tb.attn1), None, None, None, None, {})
     a = TemporalAttention.apply(qkv, B, F, S, C)
     g1 = FusedLinear.apply(a, tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, g0, None, xvec(tb.attn2),
                            dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if quirk else dict(vdiv=F * S))
-    u = GegluProj.apply(ln(g1, tb.norm3), tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
-    h3 = BlendLinear.apply(u, tb.ff.net[2].weight, tb.ff.net[2].bias, g1, h2, tr.time_mixer.mix_factor)
+    with _ff_region():
+        u = GegluProj.apply(ln(g1, tb.norm3), tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
+        h3 = BlendLinear.apply(u, tb.ff.net[2].weight, tb.ff.net[2].bias, g1, h2, tr.time_mixer.mix_factor)
+    del u
     return FusedLinear.apply(h3, tr.proj_out.weight, tr.proj_out.bias, x, None, None, {})
 

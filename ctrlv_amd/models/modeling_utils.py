@@ -117,9 +117,17 @@ class HipModelMixin(nn.Module):
         model.eval()
         return model
 
-    # --- training-side hooks the reference calls; inference-only build accepts them as no-ops --------------------
+    # --- training-side hooks the reference calls --------------------------------------------------------------------
+    gradient_checkpointing = False
+
     def enable_gradient_checkpointing(self):
+        """tools/train_video_controlnet.py:185-186.  ctrlv_amd.training builds this model's training forward with its GEGLU
+        feed-forwards CHECKPOINTED: their 4C / 8C-wide intermediates (31 GB of a 101 GB step at the reference's size) are
+        recomputed in the backward instead of kept (ctrlv_amd/autograd.py)."""
         self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
 
     def enable_xformers_memory_efficient_attention(self, *_, **__):
         pass  # attention is always the fused HIP kernel

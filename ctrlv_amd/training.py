@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as Fn
 
 from . import ops
-from .autograd import (FusedLinear, GatherGemm, GroupNormSiLU, res_block_train_forward, sinusoid,
+from .autograd import (FusedLinear, GatherGemm, GroupNormSiLU, gradient_checkpointing, res_block_train_forward, sinusoid,
                        transformer_train_forward, zero_conv_train_forward)
 from .models.blocks import TransformerSpatioTemporalModel  # noqa: F401  (documentation anchor)
 
@@ -134,10 +134,13 @@ def controlnet_train_forward(model, sample, timestep, encoder_hidden_states, add
     wi, bi = _input_conv_weight(convs, cp, kp)
     x = FusedLinear.apply(col, wi, bi, None, None, None, {})
     taps, H, W = [(x, h, w)], h, w
-    for blk in model.down_blocks:
-        x, H, W, t = down_block_train(blk, x, emb_s, ehs, B, F, H, W, order)
-        taps += t
-    x = mid_block_train(model.mid_block, x, emb_s, ehs, B, F, H, W, order)
+    # `model.enable_gradient_checkpointing()` (the reference's trainer calls it: tools/train_video_controlnet.py:185-186):
+    # the GEGLU feed-forward intermediates are recomputed in the backward instead of kept (autograd.py)
+    with gradient_checkpointing(getattr(model, "gradient_checkpointing", False)):
+        for blk in model.down_blocks:
+            x, H, W, t = down_block_train(blk, x, emb_s, ehs, B, F, H, W, order)
+            taps += t
+        x = mid_block_train(model.mid_block, x, emb_s, ehs, B, F, H, W, order)
     down = [(zero_conv_train_forward(zc, r, conditioning_scale), hh, ww)
             for (r, hh, ww), zc in zip(taps, model.controlnet_down_blocks)]
     mid = (zero_conv_train_forward(model.controlnet_mid_block, x, conditioning_scale), H, W)
@@ -178,8 +181,9 @@ def unet_train_forward(unet, sample, timestep, encoder_hidden_states, added_time
         raise ValueError(f"expected {len(taps)} down_block_additional_residuals, got {len(down_res)}")
     skips = [s + r for (s, _, _), (r, _, _) in zip(taps, down_res)]            # :119-127 (out of place: s is arena memory)
     x = x + mid_res[0]                                                         # :136-137
-    for blk in unet.up_blocks:
-        x, H, W = up_block_train(blk, x, emb_s, ehs, B, F, H, W, skips, order)
+    with gradient_checkpointing(getattr(unet, "gradient_checkpointing", False)):
+        for blk in unet.up_blocks:
+            x, H, W = up_block_train(blk, x, emb_s, ehs, B, F, H, W, skips, order)
     c0 = x.shape[1]
     xn = GroupNormSiLU.apply(x, unet.conv_norm_out.weight, unet.conv_norm_out.bias, N, H * W, 1, 1e-5, True)
     return GatherGemm.apply(xn, unet.conv_out.weight, unet.conv_out.bias, None, None, 1.0,

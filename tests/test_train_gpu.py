@@ -174,3 +174,36 @@ def test_forward_after_an_optimizer_step_uses_the_updated_weights(hip_lib):
         after = fwd(ex)
         assert float((after - before[ex]).abs().max()) > 0.0, ex           # the forward saw the optimizer's update
         assert parity_err(after, ref.float(), f"mid residual after training, {ex} executor") < 2e-2
+
+
+def test_gradient_checkpointing_gives_the_same_bits_with_less_memory(hip_lib):
+    """`enable_gradient_checkpointing()` (tools/train_video_controlnet.py:185-186): the GEGLU feed-forward intermediates are
+    recomputed in the backward by the forward's own launch, so the loss and EVERY gradient are bit-identical to the plain
+    step -- and the step's peak memory is lower."""
+    import ctrlv_ref as R
+    from ctrlv_amd.training import train_step
+    config = dict(R.TINY_CONFIG)
+    _, _, hu, hc = make_pair(config, DEV, seed=3)
+    b = {k: v.to(DEV) for k, v in _batch(config, 2, 4, 32, 32).items()}
+    hc.float()
+    for p in hc.parameters():
+        p.requires_grad_(True)
+    for p in hu.parameters():
+        p.requires_grad_(False)
+    res = {}
+    for ck in (False, True, False):
+        (hu.enable_gradient_checkpointing if ck else hu.disable_gradient_checkpointing)()
+        (hc.enable_gradient_checkpointing if ck else hc.disable_gradient_checkpointing)()
+        for p in hc.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = train_step(hc, hu, b, conditioning_scale=0.8)
+        torch.cuda.synchronize()
+        res[ck] = (float(loss), [p.grad.clone() for p in hc.parameters()], torch.cuda.max_memory_allocated() - base)
+    (l0, g0, m0), (l1, g1, m1) = res[False], res[True]
+    assert l0 == l1 and math.isfinite(l0)
+    assert all(torch.equal(a, c) for a, c in zip(g0, g1))
+    print(f"  peak above the resident set: plain {m0 / 2**20:.1f} MiB, checkpointed {m1 / 2**20:.1f} MiB")
+    assert m1 < 0.9 * m0

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--fused-adamw", type=int, default=1, help="torch.optim.AdamW(fused=...)")
+    ap.add_argument("--gradient-checkpointing", type=int, default=0,
+                    help="1: unet.enable_gradient_checkpointing() + controlnet.enable_gradient_checkpointing() (the GEGLU "
+                         "feed-forward intermediates are recomputed in the backward; tools/train_video_controlnet.py:185-186)")
     ap.add_argument("--gpus", type=int, default=0,
                     help="N > 1 without a torchrun environment: start N rank processes (one per GPU) from this GPU-free parent")
     args = ap.parse_args()
@@ -60,6 +63,9 @@ def main():
     random_init_(ctrl, seed=1, zero_conv_std=0.02)
     for p in unet.parameters():
         p.requires_grad_(False)
+    if args.gradient_checkpointing:
+        unet.enable_gradient_checkpointing()
+        ctrl.enable_gradient_checkpointing()
     params = [p for p in ctrl.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=1e-2, fused=bool(args.fused_adamw))
     buckets = training.GradientBuckets(params) if world > 1 else None
@@ -116,7 +122,8 @@ def main():
                       "forward_ms": round(avg[1], 1), "backward_ms": round(avg[2], 1), "optimizer_ms": round(avg[3], 1),
                       "steps": n, "warmup": args.warmup, "frames": F, "latent": [h, w], "analytic_tflop_per_step": round(tf, 1),
                       "tflops": round(tf / avg[0] * 1e3, 1), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-                      "losses": [round(v, 5) for v in losses], "dtype": "bf16 compute, fp32 master parameters + AdamW",
+                      "losses": [round(v, 5) for v in losses],
+                      "gradient_checkpointing": bool(args.gradient_checkpointing), "dtype": "bf16 compute, fp32 master parameters + AdamW",
                       "data": "synthetic, random-init weights"}))
 
 
