@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="element type of activations / packed weights: bf16 (BASELINE.json's dtype, libctrlv_hip.so) or "
                          "fp16 (the reference's autocast dtype, libctrlv_hip_f16.so: model-level parity 1e-3 instead of 1e-2)")
+    ap.add_argument("--no-profile-step", action="store_true",
+                    help="skip the extra instrumented eager step (no `roofline` in the output): for runs under rocprofv3 --pmc")
     ap.add_argument("--no-fp16-leg", action="store_true",
                     help="bf16 runs: skip the extra leg that runs the SAME weights / sample through the fp16 build "
                          "(its parity and step time are reported as `fp16_build` beside the bf16 headline)")
@@ -431,7 +433,7 @@ def main():
     finite = bool(torch.isfinite(st.latents).all())
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
-    if rank == 0:
+    if rank == 0 and not args.no_profile_step:
         # per-kernel HIP-event timing needs eager launches: one extra identical step outside the timed region, through the
         # SAME executor as the timed steps -- the C++ plan brackets its own launches (ctrlv_plan_profile), so every dispatch
         # decision of the plan (tile choice, fused feed-forward, column groups) is what the roofline describes

@@ -14,10 +14,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python3 $R/bench.py --steps 4 --warmup 2 --hip-graph 0 --no-cpu-baseline > $OUT/prof.log 2>&1
 cp $OUT/prof/p_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 1 --warmup 1 --hip-graph 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 1 --warmup 1 --hip-graph 0 --no-cpu-baseline --no-profile-step > $OUT/pmc_$C.log 2>&1
 done
 cd $R
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_hbm_traffic_summary.json 3 > $OUT/pmc_summary.txt 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_hbm_traffic_summary.json 2 > $OUT/pmc_summary.txt 2>&1
 tail -12 $OUT/pmc_summary.txt
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/prof/p_kernel_trace.csv
 # 4. the other configurations of the same build (no CPU leg): SVD UNet only (cfg2), the reference's default 320x512 size,
