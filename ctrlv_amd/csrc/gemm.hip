@@ -22,6 +22,8 @@
 // ping-pong schedule (gemm_pp_kernel.h, gemm_pp_m*.hip): tile 5 = 256x256, tile 6 = 256x320 (7 / 8: non-persistent)
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);
+bool ctrlv_conv_halo_order(const ctrlv_gemm_desc& d);      // gemm_pp_m0.hip: K order (dy, 32-channel block, dx) for this conv?
+constexpr int kHaloOrderFlag = 0x100;                      // set in the kernel's copy of d.tile (host-side field otherwise)
 
 namespace {
 
@@ -89,9 +91,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   const char* zsrc = (const char*)g_ctrlv_zeros + pslot * 16;
   const int hlim = d.H << d.up, wlim = d.Wd << d.up;
 
+  // Stride-1 3x3 convs whose row width divides the ping-pong tile are summed in the order (dy, 32-channel block, dx) by
+  // every kernel (gemm_pp_kernel.h conv_halo_geometry: the row-halo kernels stage one slot per (dy, block) for the three
+  // dx).  Here a 64-wide K step is two consecutive 32-channel UNITS of that order: a lane's 16-B chunk belongs to unit
+  // 2 kt + (chunk >> 2), which fixes its tap and channel offset -- the same sequence of products per output element.
+  const bool halo_order = (d.tile & kHaloOrderFlag) != 0;
+  const int nb32 = d.Cin >> 5;
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
+    if (halo_order) {
+#pragma unroll
+      for (int q = 0; q < A_INSTR; ++q) {
+        const int lc = a_coff[q] >> 3;
+        const int u = 2 * kt + (lc >> 2), rest = u / 3, dxi = u - rest * 3, dyi = rest / nb32, cb = rest - dyi * nb32;
+        const int yi = a_y0[q] + dyi, xi = a_x0[q] + dxi;
+        const bool ok = a_ok[q] && (unsigned)yi < (unsigned)d.H && (unsigned)xi < (unsigned)d.Wd;
+        const long row = a_base[q] + (long)yi * d.Wd + xi;
+        const char* p = ok ? (const char*)((const el_t*)d.A + row * d.lda + cb * 32 + (lc & 3) * 8) : zsrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sa + (q * NW + wid) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_INSTR; ++q) {
+        const int lc = b_coff[q] >> 3;
+        const int u = 2 * kt + (lc >> 2), rest = u / 3, dxi = u - rest * 3, dyi = rest / nb32, cb = rest - dyi * nb32;
+        const long wcol = (long)(dyi * 3 + dxi) * d.Cin + cb * 32 + (lc & 3) * 8;
+        const char* p = b_ok[q] ? (const char*)((const el_t*)d.W + b_row[q] + wcol) : zsrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (q * NW + wid) * 1024), 16, 0, 0);
+      }
+      return;
+    }
     // K order: tap outermost (gemm_pp_kernel.h issue_end: the same order, so the same bits; the block-major alternative
     // behind the same macro)
 #ifdef CTRLV_CONV_BLOCK_MAJOR
@@ -266,6 +295,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
       tile = 1;
     }
   }
+  d.tile = ctrlv_conv_halo_order(d) ? kHaloOrderFlag : 0;     // (from here on d.tile only carries the K-order flag)
   switch (tile) {
     case 1: return launch<128, 128, 2, 2>(d, stream);
     case 2: return launch<256, 256, 2, 4>(d, stream);

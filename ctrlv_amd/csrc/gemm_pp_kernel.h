@@ -35,6 +35,10 @@
 #define PP_SETPRIO(x)
 #endif
 
+// K order (dy, 32-channel block, dx) + row-halo staging for this 3x3 conv?  One decision for every kernel that may serve
+// the layer (defined in gemm_pp_m0.hip: conv_halo_geometry() below and the CTRLV_CONV_HALO switch, default on).
+bool ctrlv_conv_halo_order(const ctrlv_gemm_desc& d);
+
 namespace {
 
 // Diagnostic build only (-DCTRLV_PP_STAMP, tools/gemm_stamp.py): per-wave cycle sums of the phases of the schedule,
@@ -74,6 +78,23 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "me
 // EPI: compile-time operand set -- bit 0: row-vector table V, bit 1: residual R1, bit 2: residual R2 (bias and s_acc
 // are always honoured).  SiLU / fp32 output are served by the 128x128 kernel of gemm.hip only.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// ROW-HALO staging of the 3x3 gather (round 4; north_star: "convs with coalesced HBM reads and LDS halo staging").
+// The three horizontal taps (dx = -1, 0, +1) of one (dy, 32-channel block) read the SAME input pixels shifted by one:
+// for stride 1 without upsampling and a row width that divides the 256-row tile, the tile's R = 256 / W image rows are
+// staged ONCE per (dy, channel block) as R rows of W + 2 pixels (a zero column on either side, written by out-of-range
+// DMA lanes) and the three half-steps read their fragments at pixel offsets 0 / 1 / 2 -- 17-18 KiB through the texture
+// path per three half-steps instead of 48, one A piece per wave and half-step instead of two.  Why it matters
+// (profiles/r04_conv3x3_phase_stamps.txt): the CU's vector-memory path takes 64 B per clock, i.e. 576 cycles for the
+// 36 KiB of a 256 x 320 half-step against 640 cycles of MFMA work -- LDS-DMA issue was 400 of the load phase's 780
+// cycles.  The K traversal of such a layer is (dy, channel block, dx) in EVERY kernel that serves it (conv_halo_geometry
+// is a function of the layer, never of M; gemm.hip follows the same order), so the bits do not depend on the kernel.
+__host__ __device__ inline bool conv_halo_geometry(const ctrlv_gemm_desc& d) {
+  // (rows narrower than 32 pixels: a wave's 32 lanes straddle slot rows, the shifted fragment reads collide in the LDS
+  //  banks and the M = 7200 layers of the 9 x 16 level lost 5 % inside the model: per-tap gather there)
+  return d.mode == 1 && d.taps == 9 && d.stride == 1 && d.up == 0 && d.Wd >= 32 && d.Wd <= 256 && (256 % d.Wd) == 0 &&
+         d.A2 == nullptr;
+}
 
 // rows of the row-vector table V that rows [0, M) can address (vmod may be "no modulus" = 1 << 30)
 __host__ __device__ inline long pp_vtable_rows(const ctrlv_gemm_desc& d) {
@@ -403,7 +424,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 // HAS_A2: the launch has a second A source for channels >= c_split (skip concat).  Only the plain-GEMM / bias-only
 // combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
 // output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, const int cgrp) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -411,7 +432,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int A_SLOT = BM * 64, B_SLOT = BN * 64, SLOT = A_SLOT + B_SLOT;
   constexpr int A_TOT = BM / 16, B_TOT = BN / 16;            // 1-KiB DMA pieces (16 rows x 64 B) per half-step
-  constexpr int A_Q = A_TOT / NW;                            // per wave (2)
+  static_assert(!HALO || (MODE == 1 && !HAS_A2 && !GEGLU), "row-halo staging: 3x3 gather only");
+  // HALO: one A piece per wave and half-step (piece POS * 8 + wid of the row-halo slot of the NEXT (dy, channel block)
+  // triple, POS = half-step mod 3); pieces beyond the slot's real ones go to the dummy KiB
+  constexpr int A_Q = HALO ? 1 : A_TOT / NW;                 // per wave (2)
   constexpr int B_Q = (B_TOT + NW - 1) / NW;                 // per wave (2 or 3; see the dummy piece below)
   static_assert(WM * WN == NW && A_TOT % NW == 0, "bad wave layout");
   // A wave's pieces of one half-step, in issue order: A_0 .. A_{A_Q-1}, B_0 .. B_{B_Q-1}.  The first NL are issued in
@@ -424,7 +448,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 #ifdef CTRLV_PP_NL
   constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
 #else
-  constexpr int NL = BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q);
+#ifdef CTRLV_PP_NL_HALO      // A/B handle of the row-halo kernels alone
+  constexpr int NL = HALO ? (CTRLV_PP_NL_HALO < NPIECE ? CTRLV_PP_NL_HALO : NPIECE - 1)
+                          : (BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q));
+#else
+  constexpr int NL = HALO ? NPIECE - 1 : (BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q));
+#endif
 #endif
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
   static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
@@ -432,12 +461,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // issue a DUMMY one -- out-of-range source (zeros, no memory traffic) into a private 1-KiB scratch strip -- so that
   // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
   constexpr bool UNEVEN = (B_TOT % NW) != 0;
+  // HALO: a ring of NA row-halo slots of up to 24 pieces (A_HSLOT) in front of the 4-slot ring of weight tiles
+  constexpr int NA = 3, A_HSLOT = 24 * 1024, A_RING = HALO ? NA * A_HSLOT : 0;
   // (one dummy KiB serves all waves: it is only ever written, with zeros)
-  constexpr int BIAS_OFF = NH * SLOT, DUMMY_OFF = BIAS_OFF + NW * WTN * 4;
+  constexpr int BIAS_OFF = HALO ? A_RING + NH * B_SLOT : NH * SLOT, DUMMY_OFF = BIAS_OFF + NW * WTN * 4;
   // The epilogue stages through FOUR wave-private 1-KiB pieces: the wave's two A pieces and two B pieces of the slot
   // consumed last.  A 128-wide tile has only one B piece per wave: its fourth piece is a private strip behind the ring.
   constexpr bool OWN_P3 = B_TOT < 2 * NW;
-  constexpr int P3_OFF = DUMMY_OFF + (UNEVEN ? 1024 : 0);
+  constexpr int P3_OFF = DUMMY_OFF + ((UNEVEN || HALO) ? 1024 : 0);
   constexpr int TAB_OFF = P3_OFF + (OWN_P3 ? NW * 1024 : 0);      // Phi table of the GEGLU epilogue (common.h)
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | dummy piece | P3 | Phi
@@ -503,12 +534,35 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   unsigned a_voff[A_Q], a_voff2[A_Q];                        // per-lane row offsets into A / A2 (kOOB if the row is invalid)
   unsigned a_mask[A_Q];                                      // modes 1/2, bits 0..8: tap validity; bits 16,17: y/x parity (upsample)
   unsigned b_voff[B_Q];                                      // byte offset of the weight row (+chunk), kOOB if out of range
+  // HALO: the row-halo slot of a tile holds R = 256 / W image rows of W + 2 pixels (64 B each): slot pixel sp = jr * (W + 2)
+  // + x + 1.  A wave fills pieces POS * 8 + wid (POS = 0..2, 16 slot pixels each): per lane and POS the byte offset of
+  // its pixel's CENTRE row (dy = 0; a (dy, channel block) adds a scalar) -- out of range for the zero columns, for rows
+  // past M and for pieces past the slot -- and its three dy-validity bits (image top / bottom).
+  unsigned ah_voff[HALO ? 3 : 1], ah_mask[HALO ? 3 : 1];
+  const int hw2 = d.Wd + 2, npa = HALO ? (256 + 2 * (256 / (d.Wd > 0 ? d.Wd : 1)) + 15) / 16 : 0;
+  auto setup_a_halo = [&](int tile) {
+    int mt_, nt_;
+    tile_mn(tile, mt_, nt_);
+    const int bm = mt_ * BM;
+#pragma unroll
+    for (int pos = 0; pos < 3; ++pos) {
+      const int piece = pos * NW + wid;
+      const int sp = piece * 16 + prow;
+      const int jr = sp / hw2, x = sp - jr * hw2 - 1;
+      const int m = bm + jr * d.Wd + x;
+      const bool ok = piece < npa && jr * d.Wd < BM && (unsigned)x < (unsigned)d.Wd && m < d.M;
+      const int y = ok ? (m / d.Wd) % d.H : 0;
+      ah_voff[pos] = ok ? (unsigned)m * (unsigned)(d.lda * 2) + coff : kOOB;
+      ah_mask[pos] = ok ? ((y > 0 ? 1u : 0u) | 2u | (y < d.H - 1 ? 4u : 0u)) : 0u;
+    }
+  };
   auto setup = [&](int tile) {
     int mt_, nt_;
     tile_mn(tile, mt_, nt_);
     const int bm = mt_ * BM, bn = nt_ * BN;
+    (void)bm;
 #pragma unroll
-    for (int q = 0; q < A_Q; ++q) {
+    for (int q = 0; q < (HALO ? 0 : A_Q); ++q) {
       const int m = bm + (q * NW + wid) * 16 + prow;
       const bool ok = m < d.M;
       int row = m;
@@ -547,12 +601,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // issue-stream state (scalars): tile-local half-step about to be issued = (is_tap, is_cc); the tile itself is switched
   // by the K loop below (three half-steps before the consuming stream gets there)
   int is_tap = 0, is_cc = 0;
+  // HALO: the weight stream walks (dy, channel block, dx); the row-halo stream is ONE TRIPLE AHEAD of it: the unit issued
+  // for half-step h carries the weight pieces of h and piece h % 3 of the slot of the triple AFTER h's (so a slot is
+  // complete, and retired by the counted waits, a whole triple before its first read).  ia_* = the triple being filled.
+  int is_dy = -1, is_dx = -1;
+  int ia_dy = -1, ia_cc = 0, ia_t = 0;
   char* is_sa = nullptr;
   char* is_sb = nullptr;
   bool is_second = false;
   unsigned is_so_a = 0, is_so_w = 0;
   int is_dyo = 0, is_dxo = 0, is_ld2 = 0;
   auto issue_begin = [&](int g) {
+    if constexpr (HALO) {
+      is_sa = smem + (ia_t % NA) * A_HSLOT;
+      is_sb = smem + A_RING + (g & (NH - 1)) * B_SLOT;
+      is_ld2 = d.lda * 2;
+      is_so_a = __builtin_amdgcn_readfirstlane((unsigned)(((ia_dy + 1) * d.Wd + 1) * is_ld2) + (unsigned)(ia_cc * 2));
+      is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((((is_dy + 1) * 3 + is_dx + 1) * d.Cin) + is_cc) * 2));
+      return;
+    }
     is_sa = smem + (g & (NH - 1)) * SLOT;
     is_sb = is_sa + A_SLOT;
     is_second = HAS_A2 && is_cc >= d.c_split;
@@ -591,8 +658,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst), 16, b_voff[q], is_so_w, 0, 0);
     }
   };
+  // HALO: piece `pos` (= half-step mod 3) of the slot being filled
+  auto issue_a_halo = [&](int pos) {
+    unsigned voff = pos == 0 ? ah_voff[0] : (pos == 1 ? ah_voff[HALO ? 1 : 0] : ah_voff[HALO ? 2 : 0]);
+    const unsigned msk = pos == 0 ? ah_mask[0] : (pos == 1 ? ah_mask[HALO ? 1 : 0] : ah_mask[HALO ? 2 : 0]);
+    if (!((msk >> (ia_dy + 1)) & 1u)) voff = kOOB;
+    const int piece = pos * NW + wid;
+    char* dst = piece < npa ? is_sa + piece * 1024 : smem + DUMMY_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst), 16, voff, is_so_a, 0, 0);
+  };
+  int is_pos = 0;                                            // HALO: position of the unit being issued inside its triple
   auto issue_piece = [&](int pc) {
-    if (pc < A_Q) issue_a(pc); else issue_b(pc - A_Q);
+    if constexpr (HALO) {
+      if (pc < A_Q) issue_a_halo(is_pos); else issue_b(pc - A_Q);
+    } else {
+      if (pc < A_Q) issue_a(pc); else issue_b(pc - A_Q);
+    }
   };
   // K traversal of the 3x3 / temporal gathers: tap outermost, the channels inside it (the 2-stage kernel's order too --
   // gemm.hip -- so the bits do not depend on the kernel).  Every tap then re-reads its A rows from the fabric (the re-use
@@ -604,6 +685,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // one session; 63.6 vs 64.8 ms of conv kernels per step): the reads it saves come out of the Infinity Cache, which is
   // not what these kernels wait for, and its weight reads jump by Cin between consecutive half-steps.  Not the default.
   auto issue_end = [&]() {
+    if constexpr (HALO) {
+      if (++is_dx > 1) {                                     // weights: (dy, channel block, dx)
+        is_dx = -1;
+        is_cc += 32;
+        if (is_cc == d.Cin) { is_cc = 0; ++is_dy; }
+      }
+      if (++is_pos == 3) {                                   // row-halo slot complete: next (dy, channel block)
+        is_pos = 0;
+        ++ia_t;
+        ia_cc += 32;
+        if (ia_cc == d.Cin) { ia_cc = 0; ++ia_dy; }
+      }
+      return;
+    }
 #ifdef CTRLV_CONV_BLOCK_MAJOR
     if (MODE != 0) {
       if (is_cc & 32) {
@@ -628,11 +723,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     setup(tile);                                             // one: its rows are all invalid, the pieces read zeros)
     is_tap = 0;
     is_cc = 0;
+    is_dy = -1; is_dx = -1;
+  };
+  auto next_tile_a = [&](int tile) {                         // HALO: the row-halo stream moves to `tile` (one triple early)
+    setup_a_halo(tile);
+    ia_dy = -1; ia_cc = 0;
   };
 
   const int sw = (r32 >> 2) & 3;
   const int a_frag = (wr * WTM + r32) * 64;
-  const int b_frag = A_SLOT + (wc * WTN + r32) * 64;
+  const int b_frag = (HALO ? 0 : A_SLOT) + (wc * WTN + r32) * 64;
+  // HALO: byte offset of this lane's pixel (row block i) inside a row-halo slot for dx = -1 / 0 / +1, with the chunk
+  // swizzle of THAT slot row folded in for the first k-slice (the second one is the same address ^ 32)
+  unsigned ah_frag[HALO ? 3 : 1][HALO ? TM : 1];
+  if constexpr (HALO) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wr * WTM + i * 32 + r32;
+      const int jr = r / d.Wd, x = r - jr * d.Wd;
+#pragma unroll
+      for (int pos = 0; pos < 3; ++pos) {
+        const int lr = jr * hw2 + x + pos;
+        ah_frag[pos][i] = (unsigned)(lr * 64 + ((hsel ^ ((lr >> 2) & 3)) * 16));
+      }
+    }
+  }
 
   // bias strip of this wave for the first tile (see pp_bias_load); its load is retired before any DMA is issued
   char* const bias_lds = smem + BIAS_OFF + wid * (WTN * 4);
@@ -661,6 +776,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // ---- prologue: 3 half-steps in flight
   int is_tile = my_first;
   next_tile(is_tile);
+  if constexpr (HALO) {
+    // slot of the first triple: all three pieces at once (the loop fills every later slot one piece per half-step)
+    next_tile_a(is_tile);
+    issue_begin(0);
+#pragma unroll
+    for (int pos = 0; pos < 3; ++pos) issue_a_halo(pos);
+    ++ia_t;
+    ia_cc += 32;
+    if (ia_cc == d.Cin) { ia_cc = 0; ++ia_dy; }
+  }
   issue(0);
   issue(1);
   issue(2);
@@ -680,19 +805,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 #endif
   // ================= PING-PONG schedule (see the header of this file)
   if (grp == 1) raw_barrier();                               // stagger: group 1 runs one slot behind
-  auto half_step = [&](int j, bool /*last_of_tile*/, auto first_tag) {
+  auto half_step = [&](int j, bool /*last_of_tile*/, auto first_tag, auto pos_tag) {
     constexpr bool MAY_BE_FIRST = decltype(first_tag)::value;
+    constexpr int POS = decltype(pos_tag)::value;            // HALO: dx + 1 of this half-step (its position in the triple)
     // ---------------- L phase: fragments of half-step g -> registers; DMA for g+3; retire own DMA(g+1)
-    const char* st = smem + (g & (NH - 1)) * SLOT;
+    const char* st = HALO ? smem + A_RING + (g & (NH - 1)) * B_SLOT : smem + (g & (NH - 1)) * SLOT;
     elx8 af[TM][2], wf[TN][2];
     STAMP(t0);
+    if constexpr (HALO) {
+      const char* sa = smem + ((g / 3) % NA) * A_HSLOT;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
 #pragma unroll
-      for (int n = 0; n < TN; ++n) wf[n][ks] = *(const elx8*)(st + b_frag + n * 32 * 64 + coff_);
+        for (int n = 0; n < TN; ++n) wf[n][ks] = *(const elx8*)(st + b_frag + n * 32 * 64 + coff_);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i][ks] = *(const elx8*)(st + a_frag + i * 32 * 64 + coff_);
+        for (int i = 0; i < TM; ++i) af[i][ks] = *(const elx8*)(sa + (ah_frag[POS][i] ^ (ks ? 32u : 0u)));
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff_ = ((ks * 2 + hsel) ^ sw) * 16;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) wf[n][ks] = *(const elx8*)(st + b_frag + n * 32 * 64 + coff_);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][ks] = *(const elx8*)(st + a_frag + i * 32 * 64 + coff_);
+      }
     }
     STAMP(t1);
     // DMA of half-step g+3: the first NL pieces are issued here (load phase), the rest in the gaps of the MFMA
@@ -778,11 +916,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     // (the three-iteration tail is kept rolled: hipcc unrolls it fully, renames the accumulators between the copies and
     // the 320-wide tile then needs 246-256 VGPRs instead of 233-240; the main loop keeps the compiler's own partial
     // unrolling, which makes the ring-slot offsets constants: rolled it measured 3 % slower on the long-K convs)
-    for (int j = 0; j < J - 3; ++j, ++g) half_step(j, false, std::true_type{});
-    is_tile += G;
-    next_tile(is_tile);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    if constexpr (HALO) {
+      // triples of half-steps (dx = -1, 0, +1): J = 9 Cin / 32 is a multiple of 3.  The row-halo stream is one triple
+      // ahead of the weight stream, which is three half-steps ahead of this loop: it changes tile at J - 6, the weights
+      // at J - 3.
+      for (int j = 0; j < J - 6; j += 3) {
+        half_step(j, false, std::true_type{}, P0{}); ++g;
+        half_step(j + 1, false, std::true_type{}, P1{}); ++g;
+        half_step(j + 2, false, std::true_type{}, P2{}); ++g;
+      }
+      next_tile_a(is_tile + G);
+      half_step(J - 6, false, std::false_type{}, P0{}); ++g;
+      half_step(J - 5, false, std::false_type{}, P1{}); ++g;
+      half_step(J - 4, false, std::false_type{}, P2{}); ++g;
+      is_tile += G;
+      next_tile(is_tile);
+      half_step(J - 3, false, std::false_type{}, P0{}); ++g;
+      half_step(J - 2, false, std::false_type{}, P1{}); ++g;
+      half_step(J - 1, true, std::false_type{}, P2{}); ++g;
+    } else {
+      for (int j = 0; j < J - 3; ++j, ++g) half_step(j, false, std::true_type{}, P0{});
+      is_tile += G;
+      next_tile(is_tile);
 #pragma clang loop unroll(disable)
-    for (int j = J - 3; j < J; ++j, ++g) half_step(j, j == J - 1, std::false_type{});
+      for (int j = J - 3; j < J; ++j, ++g) half_step(j, j == J - 1, std::false_type{}, P0{});
+    }
     // Tile boundary.  Group 0 takes one EXTRA barrier before its epilogue (it pairs with group 1's last post-C
     // barrier) and group 1 one after its epilogue (pairing with group 0's first post-L barrier of the next tile), so
     // that the two epilogues run CONCURRENTLY instead of each group stalling at a barrier for the whole epilogue of
@@ -793,7 +954,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     {
       // wave-private staging: this wave's own four DMA pieces of the slot consumed last (every wave retired its reads
       // of that slot before the last barrier; only this wave's own DMA, issued after this epilogue, refills them)
-      char* s0 = smem + ((g - 1) & (NH - 1)) * SLOT;
+      char* s0 = HALO ? smem + A_RING + ((g - 1) & (NH - 1)) * B_SLOT - A_SLOT : smem + ((g - 1) & (NH - 1)) * SLOT;
+      // (HALO: s0 + A_SLOT = the weight slot consumed last; the two A pieces are the wave's pieces 0 / 1 of the row-halo
+      //  slot of the last triple, which is refilled two triples on, i.e. after this epilogue)
+      char* sa0 = HALO ? smem + (((g - 1) / 3) % NA) * A_HSLOT : s0;
       // bias columns of the next tile: loaded now, parked in the LDS strip after this epilogue's last bias read
       const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
       u32x4_t nb = {0, 0, 0, 0};
@@ -807,7 +971,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       // spare.  An opaque copy of the lane id makes them per-tile values: a dozen VALU instructions per tile instead.
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
-      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, s0 + wid * 1024, s0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024,
                                 OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds,
                                 smem + TAB_OFF);
@@ -842,16 +1006,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
-  // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece (ragged B piece count only) + private fourth
-  // staging pieces (128-wide tile only) + the Phi table (GEGLU only)
-  constexpr int smem = 4 * (256 + BN) * 64 + BN * WM * 4 + ((BN / 16) % 8 ? 1024 : 0) + ((BN / 16) < 16 ? 8 * 1024 : 0) +
-                       (GEGLU ? kGeluTabBytes : 0);
+  // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece (ragged B piece count / row-halo staging) +
+  // private fourth staging pieces (128-wide tile only) + the Phi table (GEGLU only); HALO: three 24-KiB row-halo slots in
+  // place of the four A tiles
+  constexpr int smem = (HALO ? 3 * 24 * 1024 + 4 * BN * 64 : 4 * (256 + BN) * 64) + BN * WM * 4 +
+                       (((BN / 16) % 8 || HALO) ? 1024 : 0) + ((BN / 16) < 16 ? 8 * 1024 : 0) + (GEGLU ? kGeluTabBytes : 0);
   static_assert(smem <= 160 * 1024, "ping-pong tile does not fit the LDS");
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW, HALO>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -918,6 +1083,18 @@ inline int pp_epi_of(const ctrlv_gemm_desc& d) {
 
 template <int BN, int WM, int WN, int MODE>
 int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
+  if constexpr (MODE == 1) {
+    // stride-1 3x3 convs whose row width divides the tile: row-halo staging (the kernel AND the K order: see
+    // conv_halo_geometry / ctrlv_conv_halo_order).  A/B handle: CTRLV_CONV_HALO=0 = the per-tap gather in tap-major order.
+    if (ctrlv_conv_halo_order(d)) {
+      switch (pp_epi_of(d)) {
+        case 0: return launch_one<BN, WM, WN, MODE, false, 0, false, false, true>(d, persistent, stream);
+        case 1: return launch_one<BN, WM, WN, MODE, false, 1, false, false, true>(d, persistent, stream);
+        case 2: return launch_one<BN, WM, WN, MODE, false, 2, false, false, true>(d, persistent, stream);
+        default: break;
+      }
+    }
+  }
   switch (pp_epi_of(d)) {
     case 0:
       if constexpr (MODE == 0) {

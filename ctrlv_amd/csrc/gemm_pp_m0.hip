@@ -4,6 +4,12 @@
 int ctrlv_gemm_launch_pp_conv(const ctrlv_gemm_desc& d, int tile, bool persistent, hipStream_t stream);      // gemm_pp_m1.hip
 int ctrlv_gemm_launch_pp_temporal(const ctrlv_gemm_desc& d, int tile, bool persistent, hipStream_t stream);  // gemm_pp_m2.hip
 
+bool ctrlv_conv_halo_order(const ctrlv_gemm_desc& d) {
+  static int on = -1;                    // A/B handle: CTRLV_CONV_HALO=0 -> per-tap gather, tap-major K order (round 3)
+  if (on < 0) { const char* e = getenv("CTRLV_CONV_HALO"); on = e ? atoi(e) : 1; }
+  return on != 0 && conv_halo_geometry(d);
+}
+
 // does the ping-pong family serve this descriptor's epilogue? (gemm.hip falls back to the 128x128 kernel otherwise)
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   // the epilogue addresses out / R1 / R2 / V through buffer descriptors: 32-bit byte offsets

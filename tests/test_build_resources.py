@@ -90,4 +90,4 @@ def test_pingpong_gemm_register_budget():
                     if any(mk in ln for ln in blk for mk in hot_marks):
                         bad = [ln for ln in blk if "scratch_" in ln]
                         assert not bad, (unit, body[0][:90], bad)
-        assert n_kernels == 34      # 26 + the two raw-output GEGLU variants (training forward) + six 256x128 conv variants
+        assert n_kernels == 43      # 26 + two raw-output GEGLU variants + six 256x128 conv variants + nine row-halo 3x3 variants

@@ -221,6 +221,38 @@ def test_gemm_persistent_many_tiles(ops, tile):
     assert parity_err(outl, A.float() @ bf(wl).float().T + R1.float()) < tol(3e-3)
 
 
+@pytest.mark.parametrize("H,W,n,cin,cout", [(10, 64, 7, 64, 320), (36, 128, 3, 128, 96), (18, 32, 9, 192, 640), (5, 256, 5, 64, 64)])
+def test_gemm_conv3x3_row_halo(ops, H, W, n, cin, cout):
+    """The row-halo 3x3 kernels (stride 1, row width dividing the 256-row tile: csrc/gemm_pp_kernel.h conv_halo_geometry):
+    tiles that straddle images (H not a multiple of the tile's 256 / W rows), ragged last tile, several channel blocks, the
+    three epilogue operand sets -- against fp32 PyTorch, and BIT-IDENTICAL across every kernel that can serve the layer
+    (ping-pong tiles 5 / 6 / 10 and the 2-stage tile 1 follow the same (dy, channel block, dx) summation order)."""
+    from ctrlv_amd import packing
+    x = bf(torch.randn(n, cin, H, W, generator=g(1)))
+    wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g(3))
+    M = n * H * W
+    R1 = bf(torch.randn(M, cout, generator=g(4)))
+    V = torch.randn(n, cout, generator=g(5))
+    conv = F.conv2d(x.float(), bf(wt).float(), b, padding=1)
+    rows = rows_from_nchw(conv)
+    xd, wd, bd = rows_from_nchw(x).to(DEV), packing.pack_conv3x3(wt).to(DEV), b.to(DEV)
+    N = wd.shape[0]
+    cases = {"bias": ({}, rows), "r1": (dict(R1=R1.to(DEV), s1=0.5, s_acc=0.75), 0.75 * rows + 0.5 * R1.float()),
+             "v": (dict(V=V.to(DEV), vmode=1, vdiv=H * W), rows + V[torch.arange(M) // (H * W)])}
+    for name, (kw, ref) in cases.items():
+        got = {}
+        for tile in (1, 5, 6, 10):
+            if tile == 10 and cout > 128:
+                continue
+            out = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+            ops.gemm(xd, wd, out, N=N, cin=cin, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=bd, n_store=cout, tile=tile, **kw)
+            assert parity_err(out, ref, f"{name} tile {tile}") < tol(3e-3)
+            got[tile] = out
+        first = next(iter(got.values()))
+        assert all(torch.equal(first, o) for o in got.values()), name
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
