@@ -57,6 +57,19 @@ def test_conv3x3_l0_fullsize(ops):
         got = out[n0 * S0:(n0 + 5) * S0].reshape(5, H, W, c).permute(0, 3, 1, 2)
         err.append(parity_err(got, ref))
     assert max(err) < 3e-3, err
+    # the row-halo kernel (this shape: 1800 tiles, 8 per persistent workgroup, 90 half-steps each through the three-slot
+    # row-halo ring and the four-slot weight ring): 24 repeats bit for bit -- a race between the wave groups, the rings or
+    # the epilogue's staging would show as a difference between runs (no atomics anywhere) -- and against the per-tile
+    # launch of the same kernel (tile 8: no ring carried across tile boundaries)
+    again = torch.empty_like(out)
+    for _ in range(24):
+        again.fill_(float("nan"))
+        ops.gemm(rows, packing.pack_conv3x3(wt.cpu()).to(DEV), again, N=c, cin=c, taps=9, mode=1, conv=(H, W, H, W, 1, 0),
+                 bias=b, V=temb, vmode=1, vdiv=FR * S0)
+        assert torch.equal(again, out)
+    ops.gemm(rows, packing.pack_conv3x3(wt.cpu()).to(DEV), again, N=c, cin=c, taps=9, mode=1, conv=(H, W, H, W, 1, 0),
+             bias=b, V=temb, vmode=1, vdiv=FR * S0, tile=8)
+    assert torch.equal(again, out)
 
 
 def test_temporal_conv_l0_fullsize(ops):
