@@ -32,7 +32,7 @@ def _check(err):
     assert max(err["storage"].values()) < TOL_F16, err
 
 
-@pytest.mark.parametrize("B,order", [(1, "sb"), (2, "bs")])
+@pytest.mark.parametrize("B,order", [(2, "sb")])
 def test_fullwidth_fp16_parity_cfg1_size(full_pair_f16, B, order):
     cfg, pair = full_pair_f16
     assert pair[2].dtype == torch.float16 and pair[2].el_dtype == torch.float16
