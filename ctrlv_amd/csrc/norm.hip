@@ -350,6 +350,78 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// ---- LayerNorm, several rows per wave (round 4).  ln_kernel above gives one row to a wave: at C = 320 only 40 of its 64
+// lanes hold data and every row pays two 6-step wave reductions -- 76 wave-instructions per row, 4.67 TB/s where the
+// device copies at 5.3 (tools/stream_bench.py).  Here LPR = 8 / 16 / 32 lanes share a row (C = 320 / 640 / 1280: NCH = 5
+// chunks of 16 B per lane, chunk k of lane j = column block j + k * LPR, so every load instruction reads LPR * 16
+// contiguous bytes per row) and a wave normalises 64 / LPR rows at once: all lanes busy, log2(LPR)-step reductions, ~32
+// wave-instructions per row.  Same arithmetic as ln_kernel (two passes in registers: mean, then centred squares; the
+// optional row vector added first), different summation tree.  gamma / beta live in LDS (C floats each).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x, int M, int C, int lpr_log2,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
+                                                      el_t* __restrict__ y) {
+  extern __shared__ float gb[];                    // [C] gamma | [C] beta
+  for (int i = threadIdx.x; i < C; i += 256) { gb[i] = gamma[i]; gb[C + i] = beta[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;   // lanes per row, rows per wave
+  const int j = lane & (LPR - 1), rsub = lane >> lpr_log2;
+  const float inv_c = 1.0f / (float)C;
+  const long step = (long)gridDim.x * 4 * RPW;
+  long m = ((long)blockIdx.x * 4 + wid) * RPW + rsub;
+  uint4 nxt[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) nxt[k] = m < M ? *(const uint4*)(x + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+  for (; m - rsub < M; m += step) {                // (wave-uniform trip count: the shuffles below need every lane)
+    uint4 cur[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      cur[k] = nxt[k];
+      nxt[k] = (m + step < M) ? *(const uint4*)(x + (m + step) * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const bool ok = m < M;
+    const float* vrow = (V && ok) ? V + (long)((m / vdiv) % vmod) * ldv : nullptr;
+    float f[NCH][8];
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      unpack_elx8(cur[k], f[k]);
+      if (vrow) {
+        const float4 a = *(const float4*)(vrow + (j + k * LPR) * 8), b = *(const float4*)(vrow + (j + k * LPR) * 8 + 4);
+        f[k][0] += a.x; f[k][1] += a.y; f[k][2] += a.z; f[k][3] += a.w;
+        f[k][4] += b.x; f[k][5] += b.y; f[k][6] += b.z; f[k][7] += b.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += f[k][e];
+    }
+    for (int o = LPR >> 1; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    const float mean = sm * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dl = f[k][e] - mean; sq += dl * dl; }
+    for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * inv_c + eps);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c0 = (j + k * LPR) * 8;
+        const float4 g0 = *(const float4*)(gb + c0), g1 = *(const float4*)(gb + c0 + 4);
+        const float4 b0 = *(const float4*)(gb + C + c0), b1 = *(const float4*)(gb + C + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[k][e] - mean) * rstd * gg[e] + bb[e];
+        *(uint4*)(y + m * C + c0) = pack_elx8(o);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ctrlv_softmax_rows(const float* scores, int rows, int cols, long ld_scores, void* probs, long ld_probs,
@@ -407,9 +479,21 @@ extern "C" int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, 
   CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: C=%d must be a multiple of 8, <= 2048", C);
   if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm: bad row-vector table");
   const int nv = (C / 8 + 63) / 64;
+  hipStream_t st = (hipStream_t)stream;
+  // C = 320 / 640 / 1280 (every LayerNorm of the model): 8 / 16 / 32 lanes per row, 5 chunks per lane (ln_rows_kernel)
+  static const int rows_path = [] { const char* e = getenv("CTRLV_LN_ROWS"); return e ? atoi(e) : 1; }();
+  const int lpr = C / 40;
+  if (rows_path && C % 40 == 0 && (lpr == 8 || lpr == 16 || lpr == 32) && (!V || (ldv % 4 == 0 && ((uintptr_t)V & 15) == 0))) {
+    const int lg = lpr == 8 ? 3 : (lpr == 16 ? 4 : 5), rpb = 4 * (64 >> lg);
+    long nb = ((long)M + rpb - 1) / rpb;
+    if (nb > 256 * 8) nb = 256 * 8;
+    hipLaunchKernelGGL(ln_rows_kernel<5>, dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x, M, C, lg,
+                       gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
+    CTRLV_LAUNCH_CHECK();
+    return CTRLV_OK;
+  }
   long blocks = ((long)M + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipStream_t st = (hipStream_t)stream;
 #define LN_LAUNCH(NV)                                                                                             \
   hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, M, C, gamma, beta, \
                      eps, V, vdiv, vmod, ldv, (el_t*)y)

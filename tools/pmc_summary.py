@@ -22,6 +22,8 @@ def family(name):
         return {"0": "gemm_linear", "1": "gemm_conv3x3", "2": "gemm_conv_temporal"}[m.group(1)]
     if "ff_fused_kernel" in name:   # the fused C = 320 feed-forward: a member of the plain-GEMM family
         return "gemm_linear"
+    if "ln_rows_kernel" in name:    # the rows-per-wave LayerNorm: same family as ln_kernel
+        return "ln_kernel"
     if "attn_spatial" in name:      # 32- and 64-rows-per-wave variants
         return "attn_spatial_kernel"
     for k in ("gemm_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel",
