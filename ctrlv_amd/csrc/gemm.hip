@@ -277,6 +277,11 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
       if ((force == 5 || force == 6) && tile >= 5 && tile <= 6) tile = force;
     }
   }
+  if (d.gn_partials) {  // producer-side GroupNorm statistics: the 256x320 ping-pong tile, whatever M is
+    CTRLV_CHECK_SHAPE(ctrlv_gemm_gn_partials_serves(&d), "ctrlv_gemm: gn_partials is not served for this launch (ask "
+                                                         "ctrlv_gemm_gn_partials_serves first)");
+    tile = 6;
+  }
   if (d.raw_out) {      // second output of the GEGLU projection (training forward): ping-pong tiles only
     CTRLV_CHECK_ARG(d.geglu && d.ld_raw >= d.N, "ctrlv_gemm: raw_out needs geglu = 1 and ld_raw >= N");
     if (tile < 5 || tile > 8) tile = d.N % 320 == 0 ? 6 : 5;   // (tile 10 does not write raw_out)

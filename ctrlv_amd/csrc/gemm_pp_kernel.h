@@ -150,10 +150,18 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
 }
 
-template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false>
+// GNS (producer-side GroupNorm statistics, round 4): the launch also writes, per 64-row wave tile and group of N / 32
+// output channels, the (mean, M2) of the values it stores -- the chunk partials gn_finalize_kernel combines (norm.hip),
+// in place of a gn_stats pass that re-reads the tensor.  Per lane: sums and squares of its 8 channels over the wave
+// tile's rows of column block j (sub-tiles are walked column block by column block); per column block one round trip
+// through the wave's staging pieces turns the 64 lanes' sums into 32 column sums + 32 column square sums; after the last
+// block the wave's WTN column sums go through the staging pieces once more and WTN / cpg lanes fold their group's columns.
+// Needs WTN % cpg == 0 and a wave tile inside one image (S % 64 == 0): ctrlv_gemm_gn_partials_serves.
+template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false, bool GNS = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
-                                                  char* p2, char* p3, const char* bias_lds, const char* gelu_tab) {
+                                                  char* p2, char* p3, const char* bias_lds, const char* gelu_tab,
+                                                  char* gns_strip = nullptr) {
   constexpr unsigned kOOB = 0xFFFFFFFFu;
   constexpr int kFlags = 0x00020000;
   const int r32 = lane & 31, hsel = lane >> 5, l4 = lane & 3;
@@ -178,8 +186,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       (void*)((EPI & 1) ? (const void*)d.V : d.W), 0, (EPI & 1) ? (int)(pp_vtable_rows(d) * d.ldv * 4) : 0, kFlags);
 
   // byte offset of the row-vector table row of (i, pass): two integer divisions per row, hoisted out of the sub-tiles
-  unsigned v_row[TM][2];
-  if (EPI & 1) {
+  // (GNS: the launcher guarantees vmode 1 with vdiv a multiple of the 64-row wave tile: one table row per wave tile, a scalar)
+  unsigned v_row[GNS ? 1 : TM][2];
+  unsigned v_row_s = 0;
+  if constexpr (GNS && (EPI & 1)) {
+    const int mw = bm + wr * WTM;
+    v_row_s = __builtin_amdgcn_readfirstlane((unsigned)(((mw < d.M ? mw : 0) / d.vdiv) % d.vmod) * (unsigned)(d.ldv * 4));
+  } else if (EPI & 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -199,8 +212,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     struct Res { u32x4_t r1[2], r2[2]; };
     constexpr bool HAS_RES = (EPI & 6) != 0;
     // sub-tiles in flight before the first one is processed: bounded by what the 320-wide tile (252+ VGPRs) can hold
-    constexpr int P0 = TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3);
-    constexpr int GROW = (EPI & 4) ? 1 : (TN > 2 ? 2 : 2);          // additional sub-tiles issued per processed one
+    constexpr int P0 = GNS ? 1 : (TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3));
+    constexpr int GROW = ((EPI & 4) || GNS) ? 1 : (TN > 2 ? 2 : 2);   // additional sub-tiles issued per processed one
     Res q[HAS_RES ? NSUB : 1];
     const int ocol0 = wbase_n + l4 * 8;
     // Addresses: ONE per-lane byte offset per operand (row m0, column ocol0) -- or out of range -- and the displacement
@@ -210,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     const unsigned r2_base = (unsigned)m0 * (unsigned)(d.ldr2 * 2) + (unsigned)(ocol0 * 2);
     const unsigned o_base = (unsigned)m0 * (unsigned)(d.ldo * 2) + (unsigned)(ocol0 * 2);
     auto load_res = [&](int s) {
-      const int i = s / TN, j = s % TN;
+      const int i = GNS ? s % TM : s / TN, j = GNS ? s / TM : s % TN;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const int dr = i * 32 + pass * 16;
@@ -225,20 +238,40 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
       for (int s = 0; s < P0 && s < NSUB; ++s) load_res(s);
     }
+    // GNS: this column block's sums (pairs of channels: v_pk_add_f32 / v_pk_fma_f32 -- the epilogue's VALU instructions
+    // issue at a fraction of their rate while the other wave group owns the matrix pipe); column sums per block
+    f32x2_t gcs[GNS ? 4 : 1], gcq[GNS ? 4 : 1];
+    // (column sums of the finished blocks: in the wave's strip of LDS where the kernel has one -- gns_strip, [2][TN * 32]
+    //  floats -- else in registers until the staging pieces are free)
+    float gcol[GNS ? TN : 1];
+    u32x4_t gvv[2] = {};                                             // GNS + row vector: this column block's 8 table entries
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
-      const int i = s / TN, j = s % TN;
+      const int i = GNS ? s % TM : s / TN, j = GNS ? s / TM : s % TN;
       if (HAS_RES) {
 #pragma unroll
         for (int k = P0 + GROW * s; k < P0 + GROW * (s + 1); ++k)
           if (k < NSUB) load_res(k);
+      }
+      if (GNS && i == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gcs[e] = f32x2_t{0.f, 0.f}; gcq[e] = f32x2_t{0.f, 0.f}; }
       }
       const int ocol = ocol0 + j * 32;
       // scale of this 32-column block (wave-uniform): the q block of a fused q|k|v projection takes s_acc2
       const float sc = (wbase_n + j * 32 < d.n_scale2) ? d.s_acc2 : d.s_acc;
       // row-vector operands (L2-resident tables): issued ahead of this sub-tile's LDS round trip
       u32x4_t vv[2][2] = {};
-      if (EPI & 1) {
+      if constexpr (GNS && (EPI & 1)) {
+        // one table row for the whole wave tile: the 8 columns of this lane, loaded once per column block
+        if (i == 0) {
+          const bool okv = bm + wr * WTM < d.M && ocol < d.n_store;
+          gvv[0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, okv ? (unsigned)(ocol * 4) : kOOB, v_row_s, 0);
+          gvv[1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, okv ? (unsigned)(ocol * 4 + 16) : kOOB, v_row_s, 0);
+        }
+        vv[0][0] = vv[1][0] = gvv[0];
+        vv[0][1] = vv[1][1] = gvv[1];
+      } else if (EPI & 1) {
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           const bool okv = m0 + i * 32 + pass * 16 < d.M && ocol < d.n_store;
@@ -297,13 +330,81 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
             o[4 + e] += __uint_as_float(vv[pass][1][e]);
           }
         }
+        if (GNS) {      // (rows past M: the whole wave tile is, M being a multiple of 64 -- its partials are not written)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // channel pairs (0,2) (1,3) (4,6) (5,7): the pairing the compiler's own v_pk_mul / v_pk_add of the epilogue
+            // arithmetic uses (x,z / y,w of the staged float4) -- any other costs two v_mov per pair
+            const int c0 = (e >> 1) * 4 + (e & 1);
+            const f32x2_t o2 = f32x2_t{o[c0], o[c0 + 2]};
+            gcs[e] += o2;
+            gcq[e] += o2 * o2;
+          }
+        }
         const uint4 pk = pack_elx8(o);
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
         pp_store_out(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
       }
+      if (GNS && i == TM - 1) {
+        // 64 lanes x 16 sums -> 64 column sums.  Value v (0..7: sum of channel v, 8..15: its squares) of lane (row_a, l4)
+        // goes to piece v >> 2 at float (v & 3) * 64 + l4 * 16 + row_a; lane L then adds the 16 consecutive floats of
+        // (v = L >> 2, l4 = L & 3): gcol[j] = column 8 * (L & 3) + ((L >> 2) & 7) of block j, kind L >> 5.
+        // (lane constants of this block are rebuilt per column block from an opaque copy of the lane id: kept live across
+        //  the epilogue they push K-loop state into scratch -- and a scratch reload in the K loop is a vmcnt(0) there)
+        int lj = lane;
+        asm volatile("" : "+v"(lj));
+        char* const pc[4] = {p0, p1, p2, p3};
+        const int wofs = ((lj & 3) * 16 + (lj >> 2)) * 4;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int ch = v & 7, pi = (ch >> 2) * 2 + (ch & 1);
+          const f32x2_t pr = v < 8 ? gcs[pi] : gcq[pi];
+          *(float*)(pc[v >> 2] + (v & 3) * 256 + wofs) = ((ch >> 1) & 1) ? pr.y : pr.x;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const char* rsrc = ((lj >> 4) == 0 ? p0 : (lj >> 4) == 1 ? p1 : (lj >> 4) == 2 ? p2 : p3) +
+                           ((lj >> 2) & 3) * 256 + (lj & 3) * 64;
+        f32x2_t t2 = f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v4 = *(const float4*)(rsrc + k * 16);
+          t2 += f32x2_t{v4.x, v4.y} + f32x2_t{v4.z, v4.w};
+        }
+        if (gns_strip) *(float*)(gns_strip + ((lj >> 5) * (TN * 32) + j * 32 + 8 * (lj & 3) + ((lj >> 2) & 7)) * 4) = t2.x + t2.y;
+        else gcol[j] = t2.x + t2.y;
+        __builtin_amdgcn_wave_barrier();
+      }
       // keep the machine scheduler from hoisting the later sub-tiles' loads up here: the prefetch window is sized to
       // the registers that are free at each point, hoisting turns it into hundreds of spills
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (GNS) {
+      // the wave's WTN column sums and square sums through the strip [kind][WTN] (pieces p0 | p1 hold 2 * WTN floats only
+      // if they are adjacent: they are not, so kind 0 lives in p0 and kind 1 in p1), then one lane per group
+      static_assert(TN * 32 * 4 <= 1024, "GNS: a kind's column sums must fit one staging piece");
+      const int kind = lane >> 5, cin = 8 * (lane & 3) + ((lane >> 2) & 7);
+      if (!gns_strip) {
+        char* const strip = kind ? p1 : p0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *(float*)(strip + (j * 32 + cin) * 4) = gcol[j];
+      }
+      const char* const ks = gns_strip ? gns_strip : p0;
+      const char* const kq = gns_strip ? gns_strip + TN * 32 * 4 : p1;
+      __builtin_amdgcn_wave_barrier();
+      const int cpg = d.N >> 5, ng = (TN * 32) / cpg;          // channels per group; groups of this wave's columns
+      const int mw = bm + wr * WTM;                            // first row of the wave tile
+      if (lane < ng && mw < d.M) {
+        float sa = 0.f, sq = 0.f;
+        for (int c = 0; c < cpg; c += 2) {
+          const float2 a = *(const float2*)(ks + (lane * cpg + c) * 4), q = *(const float2*)(kq + (lane * cpg + c) * 4);
+          sa += a.x + a.y;
+          sq += q.x + q.y;
+        }
+        const float cnt = (float)(cpg * WTM), mean = sa / cnt;
+        const int g = wbase_n / cpg + lane;
+        *(float2*)(d.gn_partials + (((long)(mw / WTM) * 32 + g) * 2)) = make_float2(mean, sq - sa * mean);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   } else {
     if constexpr (RAW) {
@@ -424,7 +525,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 // HAS_A2: the launch has a second A source for channels >= c_split (skip concat).  Only the plain-GEMM / bias-only
 // combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
 // output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false,
+          bool GNS = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, const int cgrp) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -618,6 +720,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       is_ld2 = d.lda * 2;
       is_so_a = __builtin_amdgcn_readfirstlane((unsigned)(((ia_dy + 1) * d.Wd + 1) * is_ld2) + (unsigned)(ia_cc * 2));
       is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((((is_dy + 1) * 3 + is_dx + 1) * d.Cin) + is_cc) * 2));
+      // pin the two offsets in SGPRs HERE: left alone, the compiler carries the pre-readfirstlane VGPR values to the issue
+      // points, and under the register pressure of the GNS epilogues one of them went to scratch -- reloaded in the K loop
+      // behind an s_waitcnt vmcnt(0), which drains the LDS-DMA pipeline every half-step
+      asm volatile("" : "+s"(is_so_a), "+s"(is_so_w));
       return;
     }
     is_sa = smem + (g & (NH - 1)) * SLOT;
@@ -971,10 +1077,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       // spare.  An opaque copy of the lane id makes them per-tile values: a dozen VALU instructions per tile instead.
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
-      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW, GNS>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024,
                                 OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds,
-                                smem + TAB_OFF);
+                                smem + TAB_OFF,
+                                // GNS + HALO: the last 6 KiB of a row-halo slot are never written (a slot has <= 18 real
+                                // pieces: conv_halo_geometry; dummies go to the dummy KiB): four waves' strips per slot
+                                (GNS && HALO) ? smem + (wid >> 2) * A_HSLOT + 18 * 1024 + (wid & 3) * (2 * WTN * 4) : nullptr);
       if (refill) pp_bias_store<WTN>(bias_lds, nb, lane);
       // The accumulators are dead here -- the next tile's first MFMAs overwrite them from a literal-zero C operand --
       // but that redefinition sits behind a `j == 0` test inside the K loop, so the compiler would keep all 128-160
@@ -1006,7 +1115,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 #endif
 }
 
-template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false>
+template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false,
+          bool GNS = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece (ragged B piece count / row-halo staging) +
   // private fourth staging pieces (128-wide tile only) + the Phi table (GEGLU only); HALO: three 24-KiB row-halo slots in
@@ -1016,7 +1126,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   static_assert(smem <= 160 * 1024, "ping-pong tile does not fit the LDS");
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW, HALO>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW, HALO, GNS>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1083,6 +1193,21 @@ inline int pp_epi_of(const ctrlv_gemm_desc& d) {
 
 template <int BN, int WM, int WN, int MODE>
 int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
+  if constexpr (BN == 320 && MODE != 0) {
+    // producer-side GroupNorm statistics (gemm_epilogue_lds, GNS): the conv1 / conv2 / temporal conv1 launches of a res
+    // block, whose outputs go straight into a GroupNorm.  ctrlv_gemm has checked ctrlv_gemm_gn_partials_serves(d).
+    if (d.gn_partials) {
+      const int e = pp_epi_of(d);
+      if constexpr (MODE == 1) {
+        if (e == 1) return launch_one<BN, WM, WN, MODE, false, 1, false, false, true, true>(d, persistent, stream);
+        if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, true, true>(d, persistent, stream);
+      } else {
+        if (e == 1) return launch_one<BN, WM, WN, MODE, false, 1, false, false, false, true>(d, persistent, stream);
+      }
+      ctrlv_set_error("ctrlv_gemm: gn_partials not served for this launch");
+      return CTRLV_E_BAD_ARG;
+    }
+  }
   if constexpr (MODE == 1) {
     // stride-1 3x3 convs whose row width divides the tile: row-halo staging (the kernel AND the K order: see
     // conv_halo_geometry / ctrlv_conv_halo_order).  A/B handle: CTRLV_CONV_HALO=0 = the per-tap gather in tap-major order.

@@ -35,6 +35,35 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   return d.mode == 0 || e <= 2;
 }
 
+// Does a launch of this descriptor write GroupNorm chunk partials when gn_partials is set (gemm_epilogue_lds, GNS)?  A
+// function of the layer's shape only -- never of the batch size -- so a clip is normalised through the same path alone
+// and in a batch: ctrlv_gemm serves such a launch on the 256x320 tile whatever M is.
+extern "C" int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* dp) {
+  if (!dp) return 0;
+  const ctrlv_gemm_desc& d = *dp;
+  static int on = -1;                    // A/B handle: CTRLV_GN_FUSED=0 -> every GroupNorm runs its own statistics pass
+  if (on < 0) { const char* e = getenv("CTRLV_GN_FUSED"); on = e ? atoi(e) : 1; }
+  if (!on) return 0;
+  const int cpg = d.N / 32;
+  if (d.N <= 0 || d.N % 320 != 0 || !(cpg == 10 || cpg == 20 || cpg == 40)) return 0;      // 160-column wave tiles hold whole groups
+  if (d.n_store != d.N || d.ldo % 8 != 0 || d.geglu || d.A2 || d.raw_out || d.n_scale2) return 0;
+  if ((d.R1 && d.ldr1 % 8 != 0) || (d.vmode && d.ldv % 8 != 0) || d.Cin % 64 != 0) return 0;
+  const int e = pp_epi_of(d);
+  long S = 0;
+  if (d.mode == 1) {
+    if (!(e == 1 || e == 2) || !ctrlv_conv_halo_order(d)) return 0;
+    S = (long)d.Ho * d.Wo;
+  } else if (d.mode == 2) {
+    if (e != 1) return 0;
+    S = d.S;
+  } else {
+    return 0;
+  }
+  if (S <= 0 || S % 64 != 0 || d.M <= 0 || d.M % S != 0) return 0;      // a 64-row wave tile never straddles two images
+  if (d.vmode && !(d.vmode == 1 && d.vdiv % 64 == 0)) return 0;          // ... nor two rows of the row-vector table
+  return ctrlv_gemm_pp_supports(d) ? 1 : 0;
+}
+
 // tile 5: 256x256 (waves 2x4); tile 6: 256x320 (waves 4x2); tiles 7 / 8: the same kernels launched with one
 // workgroup per output tile instead of one persistent workgroup per CU; tile 10: 256x128 (waves 4x2; 3x3 and temporal
 // convs with N <= 128 -- on the 256-wide tile half of every MFMA would be padding).

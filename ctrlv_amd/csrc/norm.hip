@@ -113,40 +113,45 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
   }
 }
 
-// Pass 1b.  One workgroup per statistics row: combine its chunk partials (fixed order, fp64) into (mean, rstd) per group,
-// written behind the partials.  Keeps the per-workgroup prologue of the apply pass at 64 floats instead of a walk over
-// up to 25 x 36 chunks (230 KiB from L2 per workgroup at the L0 temporal norm).
-constexpr int kFinSlices = 32;          // 1024 threads: 32 slices x 32 groups (the 5-D norms have up to 900 chunks per row)
+// Pass 1b.  Per statistics row: combine its chunk partials (fixed order, fp64) into (mean, rstd) per group, written behind
+// the partials.  Keeps the per-workgroup prologue of the apply pass at 64 floats instead of a walk over up to 25 x 36 chunks
+// (230 KiB from L2 per workgroup at the L0 temporal norm).  One workgroup per (statistics row, 4 groups): 256 slices of
+// the chunk list x 4 groups -- the 5-D norms have 900 chunks per row, 3600 when the producing GEMM wrote them (64-row
+// chunks), and one workgroup per row walked them in 113 dependent-latency trips (~50 us; 14 trips now).
+constexpr int kFinSlices = 256, kFinGroups = 4;
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(GnShape s, const float* __restrict__ partials, float eps,
                                                            float* __restrict__ stats) {
-  __shared__ double dred[kFinSlices][32][2];
+  __shared__ double dred[16][kFinGroups][2];
   const int tid = threadIdx.x, stat = blockIdx.x;
   const int tot_chunks = s.imgs_per_stat * s.n_chunks;
-  const int g = tid & 31, sl = tid >> 5;
+  const int g = blockIdx.y * kFinGroups + (tid & 3), sl = tid >> 2;
   double a = 0.0, b = 0.0;                        // a = sum n_c*mean_c,  b = sum (M2_c + n_c*mean_c^2), exact in fp64
   const float* p = partials + ((long)stat * tot_chunks) * 64;
   const int cpg = s.C / 32;
+  const int last_rows = s.S - (s.n_chunks - 1) * s.rows_per_chunk;
   for (int k = sl; k < tot_chunks; k += kFinSlices) {
     const int ck = k % s.n_chunks;
-    const int rows = min(s.S, (ck + 1) * s.rows_per_chunk) - ck * s.rows_per_chunk;
+    const int rows = ck == s.n_chunks - 1 ? last_rows : s.rows_per_chunk;
     const double nc = (double)(cpg * rows);
     const float2 pm = *(const float2*)(p + (k * 32 + g) * 2);
     const double mc = (double)pm.x;
     a += nc * mc;
     b += (double)pm.y + nc * mc * mc;
   }
-  dred[sl][g][0] = a;
-  dred[sl][g][1] = b;
+  // slices of one group sit 4 lanes apart: xor-reduce over lane bits 2..5, then the 16 waves through LDS (fixed order)
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if ((tid & 63) < 4) { dred[tid >> 6][tid & 3][0] = a; dred[tid >> 6][tid & 3][1] = b; }
   __syncthreads();
-  if (tid < 32) {
+  if (tid < kFinGroups) {
     a = 0.0; b = 0.0;
-    for (int k = 0; k < kFinSlices; ++k) { a += dred[k][tid][0]; b += dred[k][tid][1]; }
+    for (int k = 0; k < 16; ++k) { a += dred[k][tid][0]; b += dred[k][tid][1]; }
     const double cnt = (double)cpg * (double)s.S * (double)s.imgs_per_stat;
     const double mean = a / cnt;
     double var = b / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    stats[((long)stat * 32 + tid) * 2] = (float)mean;
-    stats[((long)stat * 32 + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[((long)stat * 32 + g) * 2] = (float)mean;
+    stats[((long)stat * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -453,8 +458,8 @@ extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split,
                      (const el_t*)x, (const el_t*)x2, s, partials);
   CTRLV_LAUNCH_CHECK();
   // (mean, rstd) per (statistics row, group), behind the chunk partials
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat), dim3(1024), 0, (hipStream_t)stream, s, partials,
-                     eps, partials + (size_t)n_img * s.n_chunks * 64);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat, 32 / kFinGroups), dim3(1024), 0, (hipStream_t)stream, s,
+                     partials, eps, partials + (size_t)n_img * s.n_chunks * 64);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -469,6 +474,30 @@ extern "C" int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split,
   const int nt = s.CV * s.RPP;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
                      (const el_t*)x2, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (el_t*)y);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+// GroupNorm whose chunk partials were written by the producing GEMM's epilogue (ctrlv_gemm_desc.gn_partials: 64-row chunks,
+// gemm_pp_kernel.h GNS): finalize + apply, no statistics pass over the tensor.
+extern "C" int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, int C, int imgs_per_stat, float eps,
+                                             float* partials, const float* gamma, const float* beta, int silu, void* y,
+                                             ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_from_partials: null pointer");
+  CTRLV_CHECK_SHAPE(S > 0 && S % 64 == 0, "groupnorm_from_partials: S=%d must be a multiple of 64", S);
+  GnShape s;
+  int rc = gn_shape(n_img, S, C, imgs_per_stat, 0, false, &s);
+  if (rc < 0) return rc;
+  GnShape sp = s;                       // the producer's chunking
+  sp.rows_per_chunk = 64;
+  sp.n_chunks = S / 64;
+  float* stats = partials + (size_t)n_img * sp.n_chunks * 64;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat, 32 / kFinGroups), dim3(1024), 0, (hipStream_t)stream, sp,
+                     partials, eps, stats);
+  CTRLV_LAUNCH_CHECK();
+  const int nt = s.CV * s.RPP;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                     (const el_t*)nullptr, s, stats, gamma, beta, silu, (el_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -518,6 +518,32 @@ int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int
   c.release(m);          // stream order keeps the scratch alive until the apply pass has read it
   return rc;
 }
+// A GEMM whose output goes straight into a GroupNorm (conv1 -> norm2, conv2 -> temporal norm1, temporal conv1 -> temporal
+// norm2 of a res block): where the launch serves it, its epilogue writes the norm's chunk partials and the norm is
+// finalize + apply -- one read and one write of the tensor instead of two reads.  The scratch is sized from the shape alone
+// (the measuring walk has no operand pointers to ask the predicate with).
+int gemm_groupnorm(Ctx& c, ctrlv_gemm_desc d, int n_img, int S, int C, int ips, const Norm& nm, float eps, int silu, el_t* y) {
+  if (S % 64 != 0) {
+    TRY(gemm(c, d));
+    return groupnorm(c, (const el_t*)d.out, nullptr, 0, n_img, S, C, ips, nm, eps, silu, y);
+  }
+  const size_t m = c.mark();
+  float* part = (float*)c.alloc(((size_t)n_img * (S / 64) + n_img / ips) * 64 * 4);
+  int rc = CTRLV_OK;
+  if (!c.dry && ctrlv_gemm_gn_partials_serves(&d)) {
+    d.gn_partials = part;
+    rc = gemm(c, d);
+    if (rc == CTRLV_OK) {
+      ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * n_img * (double)S * C, n_img * S, C, 1);   // flags 1: fused statistics
+      rc = ctrlv_groupnorm_from_partials(d.out, n_img, S, C, ips, eps, part, nm.g, nm.b, silu, y, c.st);
+    }
+    c.release(m);
+    return rc;
+  }
+  c.release(m);
+  TRY(gemm(c, d));
+  return groupnorm(c, (const el_t*)d.out, nullptr, 0, n_img, S, C, ips, nm, eps, silu, y);
+}
 int layernorm(Ctx& c, const el_t* x, int M, int C, const Norm& nm, el_t* y, const float* V = nullptr, int vdiv = 1,
               int vmod = 1 << 30, int ldv = 0) {
   if (c.dry) return CTRLV_OK;
@@ -536,14 +562,14 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
   el_t* xn = c.rows(M, cin);
   TRY(groupnorm(c, x, x2, x2 ? c1 : 0, N, S, cin, 1, r.n1, r.eps, 1, xn));
   el_t* h = c.rows(M, cout);
+  el_t* hn = nullptr;
   {
     ctrlv_gemm_desc d = gd(xn, cin, r.c1, h, cout, (int)M, cout, cin, cout);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1; d.up = 0;
     d.V = c.temb + r.temb_off[0]; d.ldv = c.ldtemb; d.vmode = 1; d.vdiv = F * S;
-    TRY(gemm(c, d));
+    hn = c.rows(M, cout);
+    TRY(gemm_groupnorm(c, d, N, S, cout, 1, r.n2, r.eps, 1, hn));
   }
-  el_t* hn = c.rows(M, cout);
-  TRY(groupnorm(c, h, nullptr, 0, N, S, cout, 1, r.n2, r.eps, 1, hn));
   const el_t* res = x;
   int ldres = cin;
   if (r.has_sc) {
@@ -559,16 +585,14 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
     ctrlv_gemm_desc d = gd(hn, cout, r.c2, xs, cout, (int)M, cout, cout, cout);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1;
     d.R1 = res; d.ldr1 = ldres;
-    TRY(gemm(c, d));
+    TRY(gemm_groupnorm(c, d, N, S, cout, F, r.tn1, r.eps, 1, hn));
   }
-  TRY(groupnorm(c, xs, nullptr, 0, N, S, cout, F, r.tn1, r.eps, 1, hn));
   {
     ctrlv_gemm_desc d = gd(hn, cout, r.tc1, h, cout, (int)M, cout, cout, cout);
     d.taps = 3; d.mode = 2; d.F = F; d.S = S;
     d.V = c.temb + r.temb_off[1]; d.ldv = c.ldtemb; d.vmode = 1; d.vdiv = F * S;
-    TRY(gemm(c, d));
+    TRY(gemm_groupnorm(c, d, N, S, cout, F, r.tn2, r.eps, 1, hn));
   }
-  TRY(groupnorm(c, h, nullptr, 0, N, S, cout, F, r.tn2, r.eps, 1, hn));
   {   // AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
     ctrlv_gemm_desc d = gd(hn, cout, r.tc2, out, cout, (int)M, cout, cout, cout);
     d.taps = 3; d.mode = 2; d.F = F; d.S = S;

@@ -184,6 +184,20 @@ def _gn_scratch(ctx, n_img, S, C, ips):
     return ctx.gn_part
 
 
+def _gemm_groupnorm(ctx, A, W, out, gkw, n_img, S, C, ips, gamma, beta, eps, y):
+    """`gemm` whose output goes straight into GroupNorm + SiLU (plan.hip gemm_groupnorm): where the launch serves it, its
+    epilogue writes the norm's chunk partials and the norm is finalize + apply."""
+    if S % 64 == 0 and ops.gemm_gn_partials_serves(A, W, out, **gkw):
+        need = ops.groupnorm_fused_scratch_floats(n_img, S, ips)
+        if ctx.gn_part is None or ctx.gn_part.numel() < need:
+            ctx.gn_part = torch.empty(max(need, 1 << 18), dtype=torch.float32, device=ctx.ws.device)
+        ops.gemm(A, W, out, gn_partials=ctx.gn_part, **gkw)
+        ops.groupnorm_from_partials(out, n_img, S, C, ips, gamma, beta, eps, True, y, ctx.gn_part)
+    else:
+        ops.gemm(A, W, out, **gkw)
+        ops.groupnorm(out, None, n_img, S, C, ips, gamma, beta, eps, True, y, _gn_scratch(ctx, n_img, S, C, ips))
+
+
 # ------------------------------------------------------------------------------------------- res block
 class SpatioTemporalResBlock(nn.Module):
     def __init__(self, in_channels, out_channels, temb_channels, eps=1e-6):
@@ -230,10 +244,10 @@ class SpatioTemporalResBlock(nn.Module):
         ops.groupnorm(x, x2, N, S, cin, 1, pk["g1"], pk["b1"], self.eps, True, xn, part)
         h = ws.alloc((M, cout))
         vs = ctx.temb[:, self.temb_off[0]:]
-        ops.gemm(xn, pk["w1"], h, N=cout, cin=cin, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=pk["cb1"],
-                 V=vs, vmode=1, vdiv=F * S)
         hn = ws.alloc((M, cout))
-        ops.groupnorm(h, None, N, S, cout, 1, pk["g2"], pk["b2"], self.eps, True, hn, part)
+        _gemm_groupnorm(ctx, xn, pk["w1"], h, dict(N=cout, cin=cin, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=pk["cb1"],
+                                                   V=vs, vmode=1, vdiv=F * S),
+                        N, S, cout, 1, pk["g2"], pk["b2"], self.eps, hn)
         if "wsc" in pk:
             res = ws.alloc((M, cout))
             ops.gemm(x, pk["wsc"], res, N=cout, cin=cin, A2=x2, c_split=x.shape[1] if x2 is not None else 0,
@@ -241,13 +255,14 @@ class SpatioTemporalResBlock(nn.Module):
         else:
             res = x
         xs = ws.alloc((M, cout))
-        ops.gemm(hn, pk["w2"], xs, N=cout, cin=cout, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=pk["cb2"], R1=res)
         # temporal res block on (B, C, F, H, W): GroupNorm statistics over (C/32, F, H, W), conv along F
-        ops.groupnorm(xs, None, N, S, cout, F, pk["tg1"], pk["tb1"], self.eps, True, hn, part)
+        _gemm_groupnorm(ctx, hn, pk["w2"], xs, dict(N=cout, cin=cout, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=pk["cb2"],
+                                                    R1=res),
+                        N, S, cout, F, pk["tg1"], pk["tb1"], self.eps, hn)
         vt = ctx.temb[:, self.temb_off[1]:]
-        ops.gemm(hn, pk["tw1"], h, N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb1"],
-                 V=vt, vmode=1, vdiv=F * S)
-        ops.groupnorm(h, None, N, S, cout, F, pk["tg2"], pk["tb2"], self.eps, True, hn, part)
+        _gemm_groupnorm(ctx, hn, pk["tw1"], h, dict(N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb1"],
+                                                    V=vt, vmode=1, vdiv=F * S),
+                        N, S, cout, F, pk["tg2"], pk["tb2"], self.eps, hn)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
         ops.gemm(hn, pk["tw2"], out, N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"],
                  s_acc=1.0 - pk["alpha"], R1=xs)

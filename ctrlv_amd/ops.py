@@ -120,11 +120,10 @@ def geglu_bwd(raw, du, draw):
     return draw
 
 
-def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
-         R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
-         act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0):
-    """out = epilogue(gather-GEMM(A[, A2], W)).  `conv` = (H, W, Ho, Wo, stride, up); `temporal` = (F, S)."""
-    _need_gpu(A, "A")
+def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
+               R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
+               act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0,
+               gn_partials=None):
     d = GemmDesc()
     d.A, d.A2, d.W, d.out = _p(A), _p(A2), _p(W), _p(out)
     d.bias, d.R1, d.R2, d.V = _p(bias), _p(R1), _p(R2), _p(V)
@@ -150,6 +149,24 @@ def gemm(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, co
     if raw_out is not None:
         d.raw_out, d.ld_raw = _p(raw_out), raw_out.stride(0)
     d.n_scale2, d.s_acc2 = n_scale2, s_acc2
+    d.gn_partials = _p(gn_partials)
+    return d
+
+
+def gemm_gn_partials_serves(A, W, out, **kw):
+    """Whether `gemm(A, W, out, **kw, gn_partials=...)` writes GroupNorm chunk partials of `out` (the launcher's own
+    predicate: a function of the layer's shape, never of the batch size)."""
+    return bool(_L(A, W).ctrlv_gemm_gn_partials_serves(ctypes.byref(_gemm_desc(A, W, out, **kw))))
+
+
+def gemm(A, W, out, **kw):
+    """out = epilogue(gather-GEMM(A[, A2], W)).  `conv` = (H, W, Ho, Wo, stride, up); `temporal` = (F, S).
+    Keywords: see `_gemm_desc` (the fields of ctrlv_gemm_desc)."""
+    _need_gpu(A, "A")
+    d = _gemm_desc(A, W, out, **kw)
+    cin, taps, mode, geglu = d.Cin, d.taps, d.mode, d.geglu
+    R1, R2, raw_out, act = kw.get("R1"), kw.get("R2"), kw.get("raw_out"), kw.get("act", 0)
+    out_f32 = kw.get("out_f32", False)
     ev = _prof.begin()
     check(_L(A, W).ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
     if ev is not None:
@@ -234,6 +251,22 @@ def groupnorm_chunks(n_img, S, C, imgs_per_stat):
 def groupnorm_scratch_floats(n_img, S, C, imgs_per_stat):
     """fp32 elements `groupnorm` needs in `partials`: chunk partials + the (mean, rstd) table behind them."""
     return (n_img * groupnorm_chunks(n_img, S, C, imgs_per_stat) + n_img // imgs_per_stat) * 64
+
+
+def groupnorm_fused_scratch_floats(n_img, S, imgs_per_stat):
+    """fp32 elements of `partials` for `gemm(..., gn_partials=)` + `groupnorm_from_partials` (64-row chunks)."""
+    return (n_img * (S // 64) + n_img // imgs_per_stat) * 64
+
+
+def groupnorm_from_partials(x, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
+    """GroupNorm(+SiLU) of a tensor whose producing `gemm` wrote the chunk partials: finalize + apply."""
+    _need_gpu(x, "x")
+    assert partials.numel() >= groupnorm_fused_scratch_floats(n_img, S, imgs_per_stat)
+    ev = _prof.begin()
+    check(_L(x).ctrlv_groupnorm_from_partials(_p(x), n_img, S, C, imgs_per_stat, eps, _p(partials), _p(gamma), _p(beta),
+                                              1 if silu else 0, _p(y), _stream()), "ctrlv_groupnorm_from_partials")
+    _prof.end(ev, "groupnorm", 0.0, 2.0 * 2 * n_img * S * C)
+    return y
 
 
 def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):

@@ -102,9 +102,18 @@ typedef struct ctrlv_gemm_desc {
   int32_t n_scale2;                   /* output columns [0, n_scale2) take s_acc2 in place of s_acc (multiple of 32; 0 = */
   float s_acc2;                       /* none).  The fused q|k|v projection scales its q block by (1/sqrt(64)) log2(e)
                                          here, in fp32 before the one bf16 rounding: ctrlv_attention_spatial_prescaled */
+  float* gn_partials;                 /* optional: GroupNorm(32) chunk partials of `out`, written by the same launch --
+                                         [M / 64][32 groups][mean, M2] fp32 over 64-row chunks (what the statistics pass
+                                         of ctrlv_groupnorm would compute by re-reading `out`); consumed by
+                                         ctrlv_groupnorm_from_partials.  Only where ctrlv_gemm_gn_partials_serves(d) */
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
+/* 1 if a launch of `d` can write gn_partials: a 3x3 conv (row-halo eligible geometry) with a {V} or {R1} epilogue or a
+ * temporal conv with a {V} epilogue (ResnetBlock2D.conv1 / conv2, TemporalResnetBlock.conv1: the producers of norm2,
+ * temporal norm1, temporal norm2), N = 320 / 640 / 1280, image size a multiple of 64 pixels.  Depends on the layer's
+ * shape only, never on the batch size. */
+int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * GroupNorm(32) (+SiLU), channels-last.  Replaces nn.GroupNorm + SiLU of ResnetBlock2D.norm1/norm2,
@@ -123,6 +132,11 @@ int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split, int n_img,
 int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img, int S, int C, int imgs_per_stat,
                           const float* partials, const float* gamma, const float* beta, int silu, void* y,
                           ctrlv_stream_t stream);
+/* GroupNorm(+SiLU) of a tensor whose producer wrote the chunk partials (ctrlv_gemm_desc.gn_partials): combines them
+ * into (mean, rstd) and streams y -- 1 read + 1 write of the tensor.  `partials` holds (n_img * S / 64 + n_img /
+ * imgs_per_stat) * 64 floats (the producer's part first); S must be a multiple of 64. */
+int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, int C, int imgs_per_stat, float eps, float* partials,
+                                  const float* gamma, const float* beta, int silu, void* y, ctrlv_stream_t stream);
 
 /* LayerNorm over the channel axis of [M, C] bf16 rows (BasicTransformerBlock.norm1/3,
  * TemporalBasicTransformerBlock.norm_in/1/3).  If V != NULL, normalises x[m,:] + V[(m / vdiv) % vmod, :]

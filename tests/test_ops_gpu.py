@@ -253,6 +253,60 @@ def test_gemm_conv3x3_row_halo(ops, H, W, n, cin, cout):
         assert all(torch.equal(first, o) for o in got.values()), name
 
 
+@pytest.mark.parametrize("kind,H,W,n,ips,cin,cout,shift", [
+    ("conv_v", 8, 32, 3, 1, 64, 320, 0.0), ("conv_r1", 4, 64, 6, 3, 128, 640, 0.0), ("conv_v", 2, 32, 4, 1, 64, 1280, 0.0),
+    ("temporal_v", 8, 16, 6, 3, 64, 320, 0.0), ("temporal_v", 8, 8, 4, 2, 128, 640, 0.0),
+    ("conv_v", 8, 32, 2, 1, 64, 320, 8.0), ("conv_r1", 9, 128, 2, 2, 64, 320, 0.0)])
+def test_gemm_writes_groupnorm_partials(ops, kind, H, W, n, ips, cin, cout, shift):
+    """Producer-side GroupNorm statistics (csrc/gemm_pp_kernel.h GNS): the conv1 / conv2 / temporal-conv1 launches of a res
+    block write the chunk partials of the GroupNorm that follows.  The GEMM output is BIT-IDENTICAL with and without the
+    partials; GroupNorm + SiLU from the partials against fp32 PyTorch on the stored output and against the two-pass kernel
+    (4-D and 5-D statistics, all three widths, a launch of several M tiles, |mean| = 8 std)."""
+    from ctrlv_amd import packing
+    S, M = H * W, n * H * W
+    x = bf(torch.randn(n, cin, H, W, generator=g(1)))
+    b = torch.randn(cout, generator=g(3)) + shift
+    if kind.startswith("conv"):
+        wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+        wd = packing.pack_conv3x3(wt).to(DEV)
+        kw = dict(N=cout, cin=cin, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=b.to(DEV))
+    else:
+        wt = torch.randn(cout, cin, 3, 1, 1, generator=g(2)) / math.sqrt(3 * cin)
+        wd = packing.pack_conv_temporal(wt).to(DEV)
+        kw = dict(N=cout, cin=cin, taps=3, mode=2, temporal=(ips, S), bias=b.to(DEV))
+    if kind.endswith("_v"):
+        kw.update(V=torch.randn(n, cout, generator=g(5)).to(DEV), vmode=1, vdiv=S)
+    else:
+        kw.update(R1=bf(torch.randn(M, cout, generator=g(4))).to(DEV), s1=0.5)
+    xd = rows_from_nchw(x).to(DEV)
+    plain = torch.empty(M, cout, dtype=EL, device=DEV)
+    assert ops.gemm_gn_partials_serves(xd, wd, plain, **kw)
+    ops.gemm(xd, wd, plain, tile=6, **kw)
+    out = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    part = torch.full((ops.groupnorm_fused_scratch_floats(n, S, ips),), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(xd, wd, out, gn_partials=part, **kw)
+    assert torch.equal(out, plain)
+    gamma, beta = torch.randn(cout, generator=g(6)), torch.randn(cout, generator=g(7))
+    y = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    ops.groupnorm_from_partials(out, n, S, cout, ips, gamma.to(DEV), beta.to(DEV), 1e-6, True, y, part)
+    xo = nchw_from_rows(out.float().cpu(), n, H, W)
+    if ips == 1:
+        ref = F.group_norm(xo, 32, gamma, beta, 1e-6)
+    else:
+        x5 = xo.reshape(n // ips, ips, cout, H, W).permute(0, 2, 1, 3, 4)
+        ref = F.group_norm(x5, 32, gamma, beta, 1e-6).permute(0, 2, 1, 3, 4).reshape(n, cout, H, W)
+    ref = F.silu(ref)
+    assert parity_err(nchw_from_rows(y.cpu(), n, H, W), ref) < tol(3e-3)
+    y2 = torch.empty_like(y)
+    p2 = torch.empty(ops.groupnorm_scratch_floats(n, S, cout, ips), dtype=torch.float32, device=DEV)
+    ops.groupnorm(out, None, n, S, cout, ips, gamma.to(DEV), beta.to(DEV), 1e-6, True, y2, p2)
+    # the two statistics paths agree far below the output rounding: most elements are bit-equal
+    assert rel_l2(y.float().cpu(), y2.float().cpu()) < tol(1e-3)
+    assert (y != y2).float().mean() < (0.05 if shift == 0.0 else 0.15)      # (differences are single output ulps)
+    # layers the epilogue does not serve say so (shape-only predicate)
+    assert not ops.gemm_gn_partials_serves(xd, wd, plain, **{k: v for k, v in kw.items() if k not in ("V", "vmode", "vdiv", "R1", "s1")})
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
