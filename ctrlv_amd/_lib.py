@@ -26,7 +26,7 @@ class GemmDesc(ctypes.Structure):
         ("act", c_int), ("geglu", c_int), ("out_f32", c_int), ("tile", c_int),
         ("ld_raw", c_int), ("raw_out", c_void_p),
         ("n_scale2", c_int), ("s_acc2", c_float),
-        ("gn_partials", c_void_p),
+        ("gn_partials", c_void_p), ("splitk_ws", c_void_p), ("ksplit", c_int), ("w_cin", c_int),
     ]
 
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "ctrlv_last_error": (c_int, [ctypes.c_char_p, c_size_t]),
     "ctrlv_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_gemm_gn_partials_serves": (c_int, [ctypes.POINTER(GemmDesc)]),
+    "ctrlv_gemm_splitk_ws_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
     "ctrlv_groupnorm_from_partials": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                               c_int, c_void_p, c_void_p]),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),

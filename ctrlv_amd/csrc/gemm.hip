@@ -206,6 +206,91 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel, smem + 2 * STAGE);
 }
 
+// ---- split contraction (small images, long K): sum of the K slices' raw accumulators + the launch's epilogue.
+// One thread per (row, 4 columns): slices in order, then exactly the operation sequence of gemm_epilogue above.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_desc d, const float* __restrict__ part, int slices) {
+  const int n4 = d.n_store >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)d.M * n4) return;
+  const int m = (int)(idx / n4), ncol = (int)(idx - (long)m * n4) * 4;
+  const long pstride = (long)d.M * d.N;
+  const float* p = part + (long)m * d.N + ncol;
+  float4 a = *(const float4*)p;
+  for (int s = 1; s < slices; ++s) {
+    const float4 b = *(const float4*)(p + s * pstride);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float o[4] = {a.x, a.y, a.z, a.w};
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = o[e] * d.s_acc;
+  }
+  if (d.R1) {
+    const uint2 rv = *(const uint2*)((const el_t*)d.R1 + (long)m * d.ldr1 + ncol);
+    o[0] = __builtin_fmaf(d.s1, el_lo_f32(rv.x), o[0]);
+    o[1] = __builtin_fmaf(d.s1, el_hi_f32(rv.x), o[1]);
+    o[2] = __builtin_fmaf(d.s1, el_lo_f32(rv.y), o[2]);
+    o[3] = __builtin_fmaf(d.s1, el_hi_f32(rv.y), o[3]);
+  }
+  if (d.R2) {
+    const uint2 rv = *(const uint2*)((const el_t*)d.R2 + (long)m * d.ldr2 + ncol);
+    o[0] = __builtin_fmaf(d.s2, el_lo_f32(rv.x), o[0]);
+    o[1] = __builtin_fmaf(d.s2, el_hi_f32(rv.x), o[1]);
+    o[2] = __builtin_fmaf(d.s2, el_lo_f32(rv.y), o[2]);
+    o[3] = __builtin_fmaf(d.s2, el_hi_f32(rv.y), o[3]);
+  }
+  if (d.vmode) {
+    const long vi = d.vmode == 1 ? (long)((m / d.vdiv) % d.vmod) : (((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod);
+    const float4 vv = *(const float4*)(d.V + vi * d.ldv + ncol);
+    o[0] += vv.x; o[1] += vv.y; o[2] += vv.z; o[3] += vv.w;
+  }
+  *(uint2*)((el_t*)d.out + (long)m * d.ldo + ncol) = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
+}
+
+// Split plan of a launch: number of K slices (1 = none) and the ping-pong tile that runs them.  The 3x3 / temporal convs
+// of the SMALL levels (<= 256 pixels per image: 9 x 16 at the benchmark's size; 10 x 16 and 5 x 8 at the reference's
+// default 320 x 512) have few output tiles -- 40-160 for a 50-image batch on 256 CUs -- and a contraction of 3840-23040:
+// the chip ran them at 0.10-0.38 of its rate.  K is cut into channel ranges (every tap of a range), all slices run in ONE
+// launch (gemm_pp_kernel.h, KS) and a streaming kernel adds them and applies the epilogue.  A function of the LAYER's shape
+// only (pixels per image, N, Cin, taps) -- priced for the 50 frame-images of a CFG'd 25-frame clip, never the actual batch:
+// a clip takes the same path, with the same summation order, alone and in any batch.
+static int splitk_plan(const ctrlv_gemm_desc& d, int* tile_out) {
+  static int on = -1;                    // A/B handle: CTRLV_SPLITK=0
+  if (on < 0) { const char* e = getenv("CTRLV_SPLITK"); on = e ? atoi(e) : 1; }
+  if (!on || d.mode == 0 || d.geglu || d.A2 || d.act || d.out_f32 || d.raw_out || d.gn_partials || d.n_scale2 || d.tile) return 1;
+  if (d.N % 32 || d.N < 256 || d.n_store != d.N || d.ldo % 8 || (d.R1 && d.ldr1 % 8) || (d.R2 && d.ldr2 % 8) ||
+      (d.vmode && d.ldv % 8) || d.Cin % 64)
+    return 1;
+  const long S = d.mode == 1 ? (long)d.Ho * d.Wo : (long)d.S;
+  if (S <= 0 || S > 256 || d.M % S != 0) return 1;
+  if (d.mode == 1 && ctrlv_conv_halo_order(d)) return 1;
+  const int nb = d.Cin / 64;
+  const long tiles_m = (50 * S + 255) / 256;
+  // one half-step of a 256-wide tile (measured: 222 us for the 360 half-steps of the 7200 x 1280 x 11520 conv, 0.74 us per
+  // half-step on the two-round 28800-row one); streaming rate of the partial sums (written once, read once)
+  const double us_unit = 0.65, bytes_per_us = 4.0e6;
+  auto cost = [&](int bn, int s) {
+    const long items = tiles_m * ((d.N + bn - 1) / bn) * s;
+    const long rounds = (items + 255) / 256;
+    const double gemm_us = (double)rounds * (d.taps * (d.Cin / s) / 32) * (bn / 256.0) * us_unit;
+    return gemm_us + (s > 1 ? (double)s * 50.0 * S * d.N * 8.0 / bytes_per_us : 0.0);
+  };
+  const double base = cost(d.N % 320 == 0 && 50 * S >= 16384 ? 320 : 256, 1);
+  double best = base * 0.85;             // a split has to be worth its second launch
+  int best_s = 1, best_tile = 0;
+  for (int bn = 256; bn <= 320; bn += 64) {
+    if (bn == 320 && d.N % 320 != 0) continue;
+    for (int sl = 2; sl <= nb && sl <= 16; ++sl) {
+      if (nb % sl != 0 || d.taps * (d.Cin / sl) / 32 < 24) continue;
+      const double c = cost(bn, sl);
+      if (c < best) { best = c; best_s = sl; best_tile = bn == 320 ? 6 : 5; }
+    }
+  }
+  *tile_out = best_tile;
+  return best_s;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128 + kGeluTabBytes;   // staging ring | Phi table (GEGLU launches)
@@ -223,6 +308,13 @@ int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" size_t ctrlv_gemm_splitk_ws_bytes(const ctrlv_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0) return 0;
+  int tile = 0;
+  const int s = splitk_plan(*d, &tile);
+  return s > 1 ? (size_t)s * d->M * d->N * sizeof(float) : 0;
+}
 
 extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
   CTRLV_CHECK_ARG(dp != nullptr, "ctrlv_gemm: null descriptor");
@@ -259,6 +351,25 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     CTRLV_CHECK_SHAPE(d.N % 32 == 0, "ctrlv_gemm: GEGLU needs N %% 32 == 0 (16 value + 16 gate columns per sub-tile)");
     CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !(d.out_f32 & 1) && d.mode == 0,
                     "ctrlv_gemm: GEGLU epilogue takes bias only (mode 0)");
+  }
+  if (d.splitk_ws) {      // split contraction where the layer's shape calls for it (splitk_plan)
+    int tile_s = 0;
+    const int slices = splitk_plan(d, &tile_s);
+    if (slices > 1) {
+      ctrlv_gemm_desc dd = d;
+      dd.Cin = d.Cin / slices; dd.w_cin = d.Cin; dd.ksplit = slices;
+      dd.out = d.splitk_ws; dd.ldo = d.N; dd.n_store = d.N;
+      dd.R1 = dd.R2 = nullptr; dd.V = nullptr; dd.vmode = 0; dd.s_acc = 1.0f; dd.splitk_ws = nullptr; dd.tile = 0;
+      if (ctrlv_gemm_pp_supports(dd) && (long)d.M * d.N * 4 < 0x7FFFFFF0L) {
+        int rc = ctrlv_gemm_launch_pp(dd, tile_s, stream);
+        if (rc != CTRLV_OK) return rc;
+        const long n_thr = (long)d.M * (d.n_store >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream, d,
+                           (const float*)d.splitk_ws, slices);
+        CTRLV_LAUNCH_CHECK();
+        return CTRLV_OK;
+      }
+    }
   }
   int tile = d.tile;
   if (tile == 0) {

@@ -108,10 +108,11 @@ __host__ __device__ inline long pp_vtable_rows(const ctrlv_gemm_desc& d) {
 // epilogue, so its latency hides behind the whole epilogue).  The K loop reads it once per tile as the C operand of
 // the tile's first MFMAs (bias_c in the kernel), so the accumulators already contain acc + bias when the epilogue runs.
 template <int WTN>
-__device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wbase_n, int lane) {
+__device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wbase_n, int lane, bool zero = false) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(d.bias ? (const void*)d.bias : d.W), 0, d.bias ? d.N * 4 : 0, 0x00020000);   // no bias: reads 0
-  return __builtin_amdgcn_raw_buffer_load_b128(rsB, lane < WTN / 4 ? (unsigned)((wbase_n + lane * 4) * 4) : 0xFFFFFFFFu,
+  // (zero: K slices after the first start from 0 -- the bias belongs to slice 0)
+  return __builtin_amdgcn_raw_buffer_load_b128(rsB, (lane < WTN / 4 && !zero) ? (unsigned)((wbase_n + lane * 4) * 4) : 0xFFFFFFFFu,
                                                0, 0);
 }
 // A/B handles of the epilogue's output stores (tools/ab_build.py): CTRLV_PP_STORE_AUX = cache-policy bits of the
@@ -581,8 +582,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   const int wr = wid / WN, wc = wid % WN;
   const int r32 = lane & 31, hsel = lane >> 5;
 
+  // KS (EPI 8: split contraction, ctrlv_gemm's K slices in ONE launch): the launch runs d.ksplit copies of the tile grid,
+  // copy s contracting over channels [s * Cin, (s + 1) * Cin) of every tap (d.Cin = channels per slice, d.w_cin = channels
+  // per tap of W) and storing its raw fp32 accumulators to out + s * M * ldo floats.  The slices are extra ROW BLOCKS of
+  // the tile order (row block mt -> slice mt / tiles_m_real): only the per-tile lane offsets know about them.
+  constexpr bool KS = EPI == 8;
   const int tiles_n = (d.N + BN - 1) / BN;
-  const int tiles_m = (d.M + BM - 1) / BM;
+  const int tiles_m_real = (d.M + BM - 1) / BM;
+  const int tiles_m = KS ? tiles_m_real * d.ksplit : tiles_m_real;
   const int ntiles = tiles_m * tiles_n;
   const int G = gridDim.x;
   // Tile order.  Tile numbers run over COLUMN GROUPS of `cgrp` column tiles: all row blocks of group 0 (row-major inside the
@@ -608,7 +615,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   const int my_first = xcd_remap(blockIdx.x, G);
   const int my_ntiles = (ntiles - my_first + G - 1) / G;       // >= 1 (grid <= ntiles)
   const int J = d.taps * (d.Cin >> 5);                       // half-steps per tile (>= 4: ctrlv_gemm_pp_supports)
-  const long ktot = (long)d.taps * d.Cin;
+  const int wcin = KS ? d.w_cin : d.Cin;                     // channels per tap in W
+  const long ktot = (long)d.taps * wcin;
 
   // ---- DMA addressing.  Sources go through buffer descriptors (buffer_load ... lds): address = base + voffset (per
   // lane) + soffset (scalar), and only the per-lane part is range-checked.  So a lane's offset is computed ONCE per
@@ -661,12 +669,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   auto setup = [&](int tile) {
     int mt_, nt_;
     tile_mn(tile, mt_, nt_);
-    const int bm = mt_ * BM, bn = nt_ * BN;
+    const int ksl = KS ? mt_ / tiles_m_real : 0;               // K slice (>= ksplit past the last tile: all rows invalid)
+    const int bm = (KS ? mt_ - ksl * tiles_m_real : mt_) * BM, bn = nt_ * BN;
+    const unsigned ks_off = KS ? (unsigned)(ksl * d.Cin * 2) : 0u;   // byte offset of the slice's first channel
     (void)bm;
 #pragma unroll
     for (int q = 0; q < (HALO ? 0 : A_Q); ++q) {
       const int m = bm + (q * NW + wid) * 16 + prow;
-      const bool ok = m < d.M;
+      const bool ok = m < d.M && (!KS || ksl < d.ksplit);
       int row = m;
       unsigned mask = 0;
       if (MODE == 1) {
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
         const int f = (m / d.S) % d.F;
         mask = ok ? ((f > 0 ? 1u : 0u) | 2u | (f < d.F - 1 ? 4u : 0u)) : 0u;
       }
-      a_voff[q] = ok ? (unsigned)row * (unsigned)(d.lda * 2) + coff : kOOB;
+      a_voff[q] = ok ? (unsigned)row * (unsigned)(d.lda * 2) + coff + ks_off : kOOB;
       a_voff2[q] = ok ? (unsigned)row * (unsigned)(d.lda2 * 2) + coff : kOOB;
       a_mask[q] = mask;
     }
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     for (int q = 0; q < B_Q; ++q) {
       const int ib = q * NW + wid;
       const int n = bn + ib * 16 + prow;
-      b_voff[q] = (ib < B_TOT && n < d.N) ? (unsigned)n * (unsigned)(ktot * 2) + coff : kOOB;
+      b_voff[q] = (ib < B_TOT && n < d.N) ? (unsigned)n * (unsigned)(ktot * 2) + coff + ks_off : kOOB;
     }
   };
 
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     // (readfirstlane: these are wave-uniform by construction; it keeps the compiler from wrapping the loads in a
     // waterfall loop when it has routed the arithmetic through vector registers)
     is_so_a = __builtin_amdgcn_readfirstlane((unsigned)(roff * is_ld2) + (unsigned)((is_second ? is_cc - d.c_split : is_cc) * 2));
-    is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((MODE == 0 ? 0 : is_tap * d.Cin) + is_cc) * 2));
+    is_so_w = __builtin_amdgcn_readfirstlane((unsigned)(((MODE == 0 ? 0 : is_tap * wcin) + is_cc) * 2));
   };
   auto issue_a = [&](int q) {
     unsigned voff = (HAS_A2 && is_second) ? a_voff2[q] : a_voff[q];
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     int mt0, nt0;
     tile_mn(my_first, mt0, nt0);
     const int bn0 = nt0 * BN;
-    const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane);
+    const u32x4_t b = pp_bias_load<WTN>(d, bn0 + wc * WTN, lane, KS && mt0 >= tiles_m_real);
     pp_bias_store<WTN>(bias_lds, b, lane);
   }
   // The first MFMAs of a tile start from the BIAS instead of zero: in the result layout a lane's 16 accumulators of a
@@ -902,7 +912,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   int g = 0;
   constexpr int HM = TM / 2;
   // buffer stores a wave issues in one epilogue (straight-line code: out-of-range ones are issued and counted too)
-  constexpr int NSTORE = GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * 2;
+  constexpr int NSTORE = EPI == 8 ? TM * TN * 4 : (GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * 2);
   static_assert(NPIECE + NPIECE + NSTORE <= 63, "vmcnt is a 6-bit counter");
   bool after_epi = false;                                    // this workgroup has run an epilogue (tile > first)
 #ifdef CTRLV_PP_STAMP
@@ -1015,7 +1025,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     const int tile = my_first + tr * G;
     int mt_, nt_;
     tile_mn(tile, mt_, nt_);
-    const int bm = mt_ * BM, bn = nt_ * BN;
+    const int ksl = KS ? mt_ / tiles_m_real : 0;
+    const int bm = (KS ? mt_ - ksl * tiles_m_real : mt_) * BM, bn = nt_ * BN;
     // The issue stream runs three half-steps ahead of the consuming one: it stays in this tile for J-3 half-steps and
     // then moves to the block's next tile (two K loops, so that the per-tile lane state is loop-invariant in each --
     // one loop with a conditional switch costs a dozen register copies per half-step).
@@ -1065,18 +1076,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       //  slot of the last triple, which is refilled two triples on, i.e. after this epilogue)
       char* sa0 = HALO ? smem + (((g - 1) / 3) % NA) * A_HSLOT : s0;
       // bias columns of the next tile: loaded now, parked in the LDS strip after this epilogue's last bias read
-      const bool refill = tiles_n > 1 && tr + 1 < my_ntiles;
+      const bool refill = (tiles_n > 1 || KS) && tr + 1 < my_ntiles;
       u32x4_t nb = {0, 0, 0, 0};
       if (refill) {
         int mtn, ntn;
         tile_mn(tile + G, mtn, ntn);
-        nb = pp_bias_load<WTN>(d, ntn * BN + wc * WTN, lane);
+        nb = pp_bias_load<WTN>(d, ntn * BN + wc * WTN, lane, KS && mtn >= tiles_m_real);
       }
       // The epilogue's lane constants (staging / read-back offsets, output column) do not depend on the tile: hipcc hoists
       // them out of the persistent loop and keeps them live (or spills them) around the K loop, which has no registers to
       // spare.  An opaque copy of the lane id makes them per-tile values: a dozen VALU instructions per tile instead.
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
+      if constexpr (KS) {
+        // raw fp32 accumulators of this slice, straight from the MFMA layout (lane: row r32 of a 32-row block, four quads
+        // of 4 consecutive columns): 16-byte stores, no staging
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((float*)d.out + (long)ksl * d.M * d.ldo), 0, (int)((long)d.M * d.ldo * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = bm + wr * WTM + i * 32 + r32;
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = bn + wc * WTN + n * 32 + 8 * q + 4 * hsel;
+              const u32x4_t pv = {__float_as_uint(acc[i][n][4 * q]), __float_as_uint(acc[i][n][4 * q + 1]),
+                                  __float_as_uint(acc[i][n][4 * q + 2]), __float_as_uint(acc[i][n][4 * q + 3])};
+              __builtin_amdgcn_raw_buffer_store_b128(pv, rsP, (m < d.M && col < d.N) ? (unsigned)((m * d.ldo + col) * 4) : kOOB, 0, 0);
+              store_data_hazard_guard(pv);
+            }
+        }
+      } else
       gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW, GNS>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024,
                                 OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds,
@@ -1138,7 +1169,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     if (cap < 0) { const char* e = getenv("CTRLV_PP_MAX_WG"); cap = e ? atoi(e) : 0; }
     if (cap > 0 && cap < num_cu) num_cu = cap;
   }
-  const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
+  const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN) * (EPI == 8 ? d.ksplit : 1);
   // persistent: one 512-thread workgroup per CU, every workgroup the same number of tiles.  1800 tiles (the N = 320 layers of
   // the 72 x 128 level) are 8 rounds on 256 CUs with 8 workgroups in the last one: 225 workgroups finish at the same time
   // and leave 31 CUs to the other stream's kernels (and their power to the clock) for the whole launch, not for its tail.
@@ -1185,6 +1216,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
 
 // epilogue operand set of a descriptor (see EPI above); -1 if the ping-pong kernels do not serve it
 inline int pp_epi_of(const ctrlv_gemm_desc& d) {
+  if (d.ksplit > 0) return (d.act || d.R1 || d.R2 || d.vmode || d.geglu || d.A2 || d.w_cin <= 0) ? -1 : 8;   // K slices: raw fp32
   if (d.act || (d.out_f32 & 1)) return -1;
   const int e = (d.vmode ? 1 : 0) | (d.R1 ? 2 : 0) | (d.R2 ? 4 : 0);
   if (e == 0 || e == 1 || e == 2 || e == 3 || e == 6) return e;
@@ -1205,6 +1237,13 @@ int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
         if (e == 1) return launch_one<BN, WM, WN, MODE, false, 1, false, false, false, true>(d, persistent, stream);
       }
       ctrlv_set_error("ctrlv_gemm: gn_partials not served for this launch");
+      return CTRLV_E_BAD_ARG;
+    }
+  }
+  if constexpr (MODE != 0 && BN >= 256) {
+    if (d.ksplit > 0) {
+      if (pp_epi_of(d) == 8) return launch_one<BN, WM, WN, MODE, false, 8>(d, persistent, stream);
+      ctrlv_set_error("ctrlv_gemm: K-slice launch with epilogue operands");
       return CTRLV_E_BAD_ARG;
     }
   }

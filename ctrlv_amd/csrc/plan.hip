@@ -494,13 +494,23 @@ ctrlv_gemm_desc gd(const void* A, int lda, const Linear& w, void* out, int ldo, 
   d.vdiv = 1; d.vmod = 1 << 30; d.vS = 1;
   return d;
 }
-int gemm(Ctx& c, const ctrlv_gemm_desc& d) {
-  if (c.dry) return CTRLV_OK;
-  if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
-  int fam; double fl, by;
-  gemm_work(d, &fam, &fl, &by);
-  ProfScope ps(c, fam, fl, by, d.M, d.N, d.taps * d.Cin, (d.geglu ? 1 : 0) | ((d.R1 ? 1 : 0) + (d.R2 ? 1 : 0)) << 1 | d.vmode << 3);
-  return ctrlv_gemm(&d, c.st);
+int gemm(Ctx& c, const ctrlv_gemm_desc& d0) {
+  // split contraction of the small-image long-K convs (gemm.hip splitk_plan): its scratch comes from the arena for the
+  // duration of the launch (the plan depends on the layer's shape only, so the measuring walk sees the same sizes)
+  ctrlv_gemm_desc d = d0;
+  const size_t mk = c.mark();
+  const size_t ws = ctrlv_gemm_splitk_ws_bytes(&d);
+  if (ws) d.splitk_ws = c.alloc(ws);
+  int rc = CTRLV_OK;
+  if (!c.dry) {
+    if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+    int fam; double fl, by;
+    gemm_work(d, &fam, &fl, &by);
+    ProfScope ps(c, fam, fl, by, d.M, d.N, d.taps * d.Cin, (d.geglu ? 1 : 0) | ((d.R1 ? 1 : 0) + (d.R2 ? 1 : 0)) << 1 | d.vmode << 3);
+    rc = ctrlv_gemm(&d, c.st);
+  }
+  c.release(mk);
+  return rc;
 }
 int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
               float eps, int silu, el_t* y) {

@@ -123,7 +123,7 @@ def geglu_bwd(raw, du, draw):
 def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
                R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
                act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0,
-               gn_partials=None):
+               gn_partials=None, splitk=True):
     d = GemmDesc()
     d.A, d.A2, d.W, d.out = _p(A), _p(A2), _p(W), _p(out)
     d.bias, d.R1, d.R2, d.V = _p(bias), _p(R1), _p(R2), _p(V)
@@ -153,6 +153,25 @@ def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split
     return d
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_scratch(device, nbytes):
+    """fp32 scratch of the split contractions, one per device, grown on demand (launches are stream-ordered: one buffer
+    serves them all)."""
+    buf = _SPLITK_WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _SPLITK_WS[device] = buf
+    return buf
+
+
+def gemm_splitk_slices(A, W, out, **kw):
+    """K slices `gemm(A, W, out, **kw)` runs this launch in (1 = not split): scratch bytes / (M * N * 4)."""
+    d = _gemm_desc(A, W, out, **kw)
+    return max(1, _L(A, W).ctrlv_gemm_splitk_ws_bytes(ctypes.byref(d)) // (d.M * d.N * 4))
+
+
 def gemm_gn_partials_serves(A, W, out, **kw):
     """Whether `gemm(A, W, out, **kw, gn_partials=...)` writes GroupNorm chunk partials of `out` (the launcher's own
     predicate: a function of the layer's shape, never of the batch size)."""
@@ -164,11 +183,19 @@ def gemm(A, W, out, **kw):
     Keywords: see `_gemm_desc` (the fields of ctrlv_gemm_desc)."""
     _need_gpu(A, "A")
     d = _gemm_desc(A, W, out, **kw)
+    lib = _L(A, W)
+    if kw.get("splitk", True):
+        # split contraction of the small-image long-K convs (csrc/gemm.hip splitk_plan): the scratch is what enables it, and
+        # it is offered to EVERY launch -- the plan is a function of the layer's shape, so a clip takes the same path alone
+        # and in a batch
+        need = lib.ctrlv_gemm_splitk_ws_bytes(ctypes.byref(d))
+        if need:
+            d.splitk_ws = _p(_splitk_scratch(A.device, need))
     cin, taps, mode, geglu = d.Cin, d.taps, d.mode, d.geglu
     R1, R2, raw_out, act = kw.get("R1"), kw.get("R2"), kw.get("raw_out"), kw.get("act", 0)
     out_f32 = kw.get("out_f32", False)
     ev = _prof.begin()
-    check(_L(A, W).ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
+    check(lib.ctrlv_gemm(ctypes.byref(d), _stream()), "ctrlv_gemm")
     if ev is not None:
         n_alg = d.N if geglu else min(d.N, d.n_store)
         fam = "gemm_conv3x3" if mode == 1 else ("gemm_conv_temporal" if mode == 2 else "gemm_linear")

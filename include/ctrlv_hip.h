@@ -106,9 +106,18 @@ typedef struct ctrlv_gemm_desc {
                                          [M / 64][32 groups][mean, M2] fp32 over 64-row chunks (what the statistics pass
                                          of ctrlv_groupnorm would compute by re-reading `out`); consumed by
                                          ctrlv_groupnorm_from_partials.  Only where ctrlv_gemm_gn_partials_serves(d) */
+  void* splitk_ws;                    /* optional scratch of ctrlv_gemm_splitk_ws_bytes(d) bytes: lets ctrlv_gemm split the
+                                         contraction of a small-image, long-K conv into K slices (one launch for all
+                                         slices + a streaming sum / epilogue kernel).  NULL = never split */
+  int32_t ksplit, w_cin;              /* internal (set by ctrlv_gemm for its slice launch; callers leave 0): number of K
+                                         slices; channels per tap of W when Cin is a slice's channel count */
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
+/* Bytes of splitk_ws a launch of `d` wants (0: the launch is not split).  A function of the layer's shape -- pixels per
+ * image, N, Cin, taps -- and of M only through the size of the scratch: a clip is computed with the same summation order
+ * alone and in a batch.  A caller that passes the scratch for one batch size must pass it for every batch size. */
+size_t ctrlv_gemm_splitk_ws_bytes(const ctrlv_gemm_desc* d);
 /* 1 if a launch of `d` can write gn_partials: a 3x3 conv (row-halo eligible geometry) with a {V} or {R1} epilogue or a
  * temporal conv with a {V} epilogue (ResnetBlock2D.conv1 / conv2, TemporalResnetBlock.conv1: the producers of norm2,
  * temporal norm1, temporal norm2), N = 320 / 640 / 1280, image size a multiple of 64 pixels.  Depends on the layer's

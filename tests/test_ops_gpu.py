@@ -307,6 +307,63 @@ def test_gemm_writes_groupnorm_partials(ops, kind, H, W, n, ips, cin, cout, shif
     assert not ops.gemm_gn_partials_serves(xd, wd, plain, **{k: v for k, v in kw.items() if k not in ("V", "vmode", "vdiv", "R1", "s1")})
 
 
+@pytest.mark.parametrize("kind,H,W,n,cin,cout", [
+    ("conv_r1", 5, 8, 6, 1280, 1280), ("conv_v", 9, 16, 4, 1280, 1280), ("conv_s2", 10, 16, 3, 1280, 1280),
+    ("temporal_v", 5, 8, 6, 1280, 1280), ("temporal_r1", 5, 8, 4, 2560, 1280), ("conv_bias", 10, 16, 2, 2560, 1280)])
+def test_gemm_split_contraction(ops, kind, H, W, n, cin, cout):
+    """Split contraction of the small-image long-K convs (csrc/gemm.hip splitk_plan; K slices in one launch of the ping-pong
+    kernel + the streaming sum / epilogue kernel): against fp32 PyTorch, against the unsplit launch, and BIT-IDENTICAL for
+    an image computed alone and inside a batch (the plan is a function of the layer's shape only)."""
+    from ctrlv_amd import packing
+    x = bf(torch.randn(n, cin, H, W, generator=g(1)))
+    b = torch.randn(cout, generator=g(3))
+    Ho, Wo = (H // 2, W // 2) if kind == "conv_s2" else (H, W)
+    S, M = Ho * Wo, n * Ho * Wo
+    if kind.startswith("conv"):
+        wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+        wd = packing.pack_conv3x3(wt).to(DEV)
+        stride = 2 if kind == "conv_s2" else 1
+        kw = dict(N=cout, cin=cin, taps=9, mode=1, conv=(H, W, Ho, Wo, stride, 0), bias=b.to(DEV))
+        ref = rows_from_nchw(F.conv2d(x.float(), bf(wt).float(), b, stride=stride, padding=1))
+    else:
+        wt = torch.randn(cout, cin, 3, 1, 1, generator=g(2)) / math.sqrt(3 * cin)
+        wd = packing.pack_conv_temporal(wt).to(DEV)
+        Fr = n // 2
+        kw = dict(N=cout, cin=cin, taps=3, mode=2, temporal=(Fr, S), bias=b.to(DEV))
+        x5 = x.float().reshape(2, Fr, cin, H, W).permute(0, 2, 1, 3, 4)
+        y5 = F.conv3d(x5, bf(wt).float(), b, padding=(1, 0, 0))
+        ref = rows_from_nchw(y5.permute(0, 2, 1, 3, 4).reshape(n, cout, H, W))
+    if kind.endswith("_v"):
+        V = torch.randn(n, cout, generator=g(5))
+        kw.update(V=V.to(DEV), vmode=1, vdiv=S)
+        ref = ref + V[torch.arange(M) // S]
+    elif kind.endswith("_r1"):
+        R1 = bf(torch.randn(M, cout, generator=g(4)))
+        kw.update(R1=R1.to(DEV), s1=0.5, s_acc=0.75)
+        ref = 0.75 * ref + 0.5 * R1.float()
+    xd = rows_from_nchw(x).to(DEV)
+    out = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    assert ops.gemm_splitk_slices(xd, wd, out, **kw) >= 2
+    ops.gemm(xd, wd, out, **kw)
+    assert parity_err(out, ref, kind) < tol(3e-3)
+    plain = torch.empty_like(out)
+    ops.gemm(xd, wd, plain, splitk=False, **kw)
+    assert rel_l2(out.float().cpu(), plain.float().cpu()) < tol(2e-3)
+    for _ in range(3):          # run to run
+        again = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+        ops.gemm(xd, wd, again, **kw)
+        assert torch.equal(again, out)
+    if kind.startswith("conv"):      # one image alone: the same bits as inside the batch
+        x1 = rows_from_nchw(x[:1]).to(DEV)
+        kw1 = dict(kw)
+        if "R1" in kw1:
+            kw1["R1"] = kw1["R1"][:S]
+        o1 = torch.full((S, cout), float("nan"), dtype=EL, device=DEV)
+        assert ops.gemm_splitk_slices(x1, wd, o1, **kw1) == ops.gemm_splitk_slices(xd, wd, out, **kw)
+        ops.gemm(x1, wd, o1, **kw1)
+        assert torch.equal(o1, out[:S])
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
