@@ -206,6 +206,52 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel, smem + 2 * STAGE);
 }
 
+// ---- M <= 8 (the per-clip GEMMs of the conditioning path: time / added-id embedding MLPs, the fused time_emb_proj, the
+// one-key cross-attention vectors -- ~25 launches per model and step with M = B).  On the 128 x 128 MFMA tile such a launch
+// is N / 128 workgroups walking K in 64-element steps behind a barrier each: ~30 us of latency for 3 MB of weights.  Here a
+// wave owns one output column: the weight row streams through its lanes in 16-byte pieces, the M activation rows come out
+// of L2, one wave reduction per row.  Same epilogue semantics as gemm_epilogue.
+__global__ __launch_bounds__(256) void gemv_small_kernel(const ctrlv_gemm_desc d) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= d.N) return;                                  // (whole waves: no barrier below)
+  const el_t* w = (const el_t*)d.W + (long)n * d.Cin;
+  const el_t* a = (const el_t*)d.A;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k8 = lane; k8 < (d.Cin >> 3); k8 += 64) {
+    float wf[8];
+    unpack_elx8(*(const uint4*)(w + k8 * 8), wf);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < d.M) {
+        float af[8];
+        unpack_elx8(*(const uint4*)(a + (long)m * d.lda + k8 * 8), af);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m] = __builtin_fmaf(af[e], wf[e], acc[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (m >= d.M) break;
+    float v = acc[m];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane != 0 || n >= d.n_store) continue;
+    v += d.bias ? d.bias[n] : 0.f;
+    {
+#pragma clang fp contract(off)
+      v = v * d.s_acc;
+    }
+    if (d.R1) v = __builtin_fmaf(d.s1, el_to_f32(((const el_t*)d.R1)[(long)m * d.ldr1 + n]), v);
+    if (d.R2) v = __builtin_fmaf(d.s2, el_to_f32(((const el_t*)d.R2)[(long)m * d.ldr2 + n]), v);
+    if (d.vmode == 1) v += d.V[(long)((m / d.vdiv) % d.vmod) * d.ldv + n];
+    else if (d.vmode == 2) v += d.V[(long)(((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod) * d.ldv + n];
+    if (d.act == 1) v = silu_f(v);
+    if (d.out_f32 & 1) ((float*)d.out)[(long)m * d.ldo + n] = v;
+    else ((el_t*)d.out)[(long)m * d.ldo + n] = f32_to_el(v);
+  }
+}
+
 // ---- split contraction (small images, long K): sum of the K slices' raw accumulators + the launch's epilogue.
 // One thread per (row, 4 columns): slices in order, then exactly the operation sequence of gemm_epilogue above.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_desc d, const float* __restrict__ part, int slices) {
@@ -369,6 +415,15 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
         CTRLV_LAUNCH_CHECK();
         return CTRLV_OK;
       }
+    }
+  }
+  if (d.tile == 0 && d.mode == 0 && d.M <= 8 && !d.geglu && !d.A2 && !d.raw_out && d.n_scale2 == 0 && (d.out_f32 & ~1) == 0) {
+    static int on = -1;                  // A/B handle: CTRLV_GEMV=0 -> the 128 x 128 MFMA tile
+    if (on < 0) { const char* e = getenv("CTRLV_GEMV"); on = e ? atoi(e) : 1; }
+    if (on) {
+      hipLaunchKernelGGL(gemv_small_kernel, dim3((unsigned)((d.N + 3) / 4)), dim3(256), 0, stream, d);
+      CTRLV_LAUNCH_CHECK();
+      return CTRLV_OK;
     }
   }
   int tile = d.tile;

@@ -364,6 +364,40 @@ def test_gemm_split_contraction(ops, kind, H, W, n, cin, cout):
         assert torch.equal(o1, out[:S])
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 320, 1280), (2, 1280, 1280), (5, 1024, 11520), (8, 64, 64)])
+def test_gemm_per_clip_rows(ops, M, K, N):
+    """M <= 8 (the conditioning path's per-clip GEMMs: csrc/gemm.hip gemv_small_kernel): every epilogue operand set the
+    plan uses there (SiLU, residual + SiLU, fp32 output, row vector) against fp32 PyTorch and the 128 x 128 MFMA tile;
+    a row's bits do not depend on the other rows."""
+    from ctrlv_amd import packing
+    A = bf(torch.randn(M, K, generator=g(1)))
+    wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    R1 = bf(torch.randn(M, N, generator=g(4)))
+    V = torch.randn(3, N, generator=g(5))
+    Wd, bd, Ad = packing.pack_linear(wt).to(DEV), b.to(DEV), A.to(DEV)
+    lin = A.float() @ bf(wt).float().T + b
+    vi = torch.arange(M) % 3
+    cases = {
+        "bias": (dict(), lin, EL),
+        "silu": (dict(act=1), F.silu(lin), EL),
+        "r1_silu": (dict(R1=R1.to(DEV), s1=0.5, s_acc=0.75, act=1), F.silu(0.75 * lin + 0.5 * R1.float()), EL),
+        "f32": (dict(out_f32=True), lin, torch.float32),
+        "v": (dict(V=V.to(DEV), vmode=1, vdiv=1, vmod=3), lin + V[vi], EL),
+    }
+    for name, (kw, ref, dt) in cases.items():
+        out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+        ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, **kw)
+        assert parity_err(out, ref, name) < (1e-4 if dt == torch.float32 else tol(3e-3))
+        mfma = torch.empty_like(out)
+        ops.gemm(Ad, Wd, mfma, N=N, cin=K, bias=bd, tile=1, **kw)
+        assert rel_l2(out.float().cpu(), mfma.float().cpu()) < (1e-5 if dt == torch.float32 else tol(2e-3))
+        if M > 1 and "R1" not in kw and "V" not in kw:
+            one = torch.empty((1, N), dtype=dt, device=DEV)
+            ops.gemm(Ad[M - 1:], Wd, one, N=N, cin=K, bias=bd, **kw)
+            assert torch.equal(one[0], out[M - 1])
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
