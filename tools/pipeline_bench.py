@@ -23,7 +23,7 @@ def main():
     from ctrlv_amd.pipelines import StableVideoControlPipeline
     from ctrlv_amd.schedulers import EulerDiscreteScheduler
     from tests.fakes import FakeCLIP, fake_feature_extractor
-    unet, ctrl = bench.build_models(torch.device(dev), "box2video", 25)
+    unet, ctrl = bench.build_models(torch.device(dev), "box2video", 25, torch.bfloat16)
     vae = AutoencoderKLTemporalDecoder().to(dev, torch.bfloat16).eval()
     clip = FakeCLIP(1024).to(dev, torch.bfloat16)
     pipe = StableVideoControlPipeline(vae, clip, unet, ctrl, EulerDiscreteScheduler(), fake_feature_extractor)

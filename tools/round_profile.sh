@@ -25,5 +25,6 @@ rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/prof/p_kernel_trace.csv
 python3 bench.py --steps 8 --warmup 2 --workload svd_unet --no-cpu-baseline > $OUT/bench_svd_unet.json 2>> $OUT/bench.err
 python3 bench.py --steps 12 --warmup 3 --height 320 --width 512 --no-cpu-baseline > $OUT/bench_320x512.json 2>> $OUT/bench.err
 python3 tools/train_bench.py --steps 4 --warmup 2 > $OUT/train_step.json 2>> $OUT/bench.err
+python3 tools/train_bench.py --steps 4 --warmup 2 --gradient-checkpointing 1 > $OUT/train_step_checkpointed.json 2>> $OUT/bench.err
 python3 tools/pipeline_bench.py > $OUT/pipeline_clip_latency.json 2>> $OUT/bench.err
 tail -1 $OUT/bench_svd_unet.json | cut -c1-160; tail -1 $OUT/bench_320x512.json | cut -c1-160; tail -1 $OUT/train_step.json | cut -c1-200; tail -2 $OUT/pipeline_clip_latency.json | cut -c1-300
