@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_des
 static int splitk_plan(const ctrlv_gemm_desc& d, int* tile_out) {
   static int on = -1;                    // A/B handle: CTRLV_SPLITK=0
   if (on < 0) { const char* e = getenv("CTRLV_SPLITK"); on = e ? atoi(e) : 1; }
-  if (!on || d.mode == 0 || d.geglu || d.A2 || d.act || d.out_f32 || d.raw_out || d.gn_partials || d.n_scale2 || d.tile) return 1;
+  if (!on || (d.mode == 0 && d.S <= 0) || d.geglu || d.A2 || d.act || d.out_f32 || d.raw_out || d.gn_partials || d.n_scale2 || d.tile) return 1;
   if (d.N % 32 || d.N < 256 || d.n_store != d.N || d.ldo % 8 || (d.R1 && d.ldr1 % 8) || (d.R2 && d.ldr2 % 8) ||
       (d.vmode && d.ldv % 8) || d.Cin % 64)
     return 1;

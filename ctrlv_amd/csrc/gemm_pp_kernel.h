@@ -1240,7 +1240,7 @@ int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
       return CTRLV_E_BAD_ARG;
     }
   }
-  if constexpr (MODE != 0 && BN >= 256) {
+  if constexpr (BN >= 256) {
     if (d.ksplit > 0) {
       if (pp_epi_of(d) == 8) return launch_one<BN, WM, WN, MODE, false, 8>(d, persistent, stream);
       ctrlv_set_error("ctrlv_gemm: K-slice launch with epilogue operands");

@@ -32,7 +32,7 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   if (d.geglu) return d.mode == 0;
   const int e = pp_epi_of(d);
   if (e < 0) return false;
-  if (e == 8) return d.mode != 0 && (long)d.ksplit * d.Cin == d.w_cin;     // K slices: the 3x3 / temporal gathers
+  if (e == 8) return (long)d.ksplit * d.Cin == d.w_cin;                   // K slices (any gather mode)
   return d.mode == 0 || e <= 2;
 }
 

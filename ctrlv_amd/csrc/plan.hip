@@ -756,7 +756,7 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     ctrlv_gemm_desc dp = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
-    d.R1 = h1; d.ldr1 = C;
+    d.R1 = h1; d.ldr1 = C; d.S = S;       // (S: rows per image, the split plan's shape key for a mode-0 launch)
     TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
@@ -765,7 +765,7 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0, C, (int)M, C, 4 * C, C);
-    d.R1 = h2; d.ldr1 = C;
+    d.R1 = h2; d.ldr1 = C; d.S = S;
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
     TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C, &u));
   }
@@ -791,7 +791,7 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     dp.geglu = 1;
     ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
     d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
-    d.s2 = (float)t.alpha;
+    d.s2 = (float)t.alpha; d.S = S;
     TRY(ln_ff(c, t.t_ff, t.t_ln3, g1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   {

@@ -139,7 +139,7 @@ def _ff_rows_per_chunk(M, C):
 _FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
 
 
-def _ff_pair(ws, x, ffp, ubox, out, C, **epi):
+def _ff_pair(ws, x, ffp, ubox, out, C, rows_per_image=0, **epi):
     """u = GEGLU(x); out = epilogue(u @ wout^T).  ffp = (wproj, bproj, wout, bout[, w1f, w2f]): at C = 320 one fused launch
     that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs, issued as
     M-chunked pairs (same arithmetic, same bits).  `ubox` = [u or None]: the 4C-wide intermediate of the two-launch path is
@@ -157,13 +157,13 @@ def _ff_pair(ws, x, ffp, ubox, out, C, **epi):
         m1 = min(M, m0 + rows)
         kw = {k: (v[m0:m1] if k in ("R1", "R2") else v) for k, v in epi.items()}
         ops.gemm(x[m0:m1], wproj, u[m0:m1], N=8 * C, cin=C, bias=bproj, geglu=1)
-        ops.gemm(u[m0:m1], wout, out[m0:m1], N=C, cin=4 * C, bias=bout, **kw)
+        ops.gemm(u[m0:m1], wout, out[m0:m1], N=C, cin=4 * C, bias=bout, rows_per_image=rows_per_image, **kw)
 
 
 _FF_LN = os.environ.get("CTRLV_FF_LN", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ln_ff)
 
 
-def _ln_ff(ws, xraw, ln, t, ffp, ubox, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, **epi):
+def _ln_ff(ws, xraw, ln, t, ffp, ubox, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, rows_per_image=0, **epi):
     """out = epilogue(FF(LayerNorm(xraw + ln_V))): with the fused kernel the norm is folded into its prologue, else
     ops.layernorm into `t` followed by _ff_pair (csrc/plan.hip ln_ff)."""
     if _FF_FUSED and _FF_LN and len(ffp) == 6 and ops.ff_fused_serves(xraw, out, **epi):
@@ -174,7 +174,7 @@ def _ln_ff(ws, xraw, ln, t, ffp, ubox, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 <
         ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, V=ln_V, vdiv=ln_vdiv, vmod=ln_vmod)
     else:
         ops.layernorm(xraw, ln[0], ln[1], 1e-5, t)
-    _ff_pair(ws, t, ffp, ubox, out, C, **epi)
+    _ff_pair(ws, t, ffp, ubox, out, C, rows_per_image=rows_per_image, **epi)
 
 
 def _gn_scratch(ctx, n_img, S, C, ips):
@@ -376,10 +376,10 @@ class TransformerSpatioTemporalModel(nn.Module):
         ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)
         u = [None]                                      # 4C-wide GEGLU output: allocated by _ff_pair on first need
         h2 = h0                                         # h0 is dead from here on
-        _ln_ff(ws, h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, R1=h1)
+        _ln_ff(ws, h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, rows_per_image=S, R1=h1)
         # ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
         g0 = h1                                         # h1 is dead
-        _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, R1=h2, V=emb, vmode=1, vdiv=S,
+        _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, rows_per_image=S, R1=h2, V=emb, vmode=1, vdiv=S,
                vmod=F)
         ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
         ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
@@ -394,7 +394,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
-        _ln_ff(ws, g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
+        _ln_ff(ws, g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, rows_per_image=S, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
         ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
         ws.release(mk)
         if ctx.trace is not None:

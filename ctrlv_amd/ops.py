@@ -123,7 +123,7 @@ def geglu_bwd(raw, du, draw):
 def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
                R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
                act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0,
-               gn_partials=None, splitk=True):
+               gn_partials=None, splitk=True, rows_per_image=0):
     d = GemmDesc()
     d.A, d.A2, d.W, d.out = _p(A), _p(A2), _p(W), _p(out)
     d.bias, d.R1, d.R2, d.V = _p(bias), _p(R1), _p(R2), _p(V)
@@ -137,6 +137,8 @@ def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split
         d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
     if temporal is not None:
         d.F, d.S = temporal
+    elif mode == 0 and rows_per_image:
+        d.S = rows_per_image          # mode 0: the split plan's shape key (rows per image)
     d.ldo = out.stride(0)
     d.n_store = out.shape[1] if n_store is None else n_store
     d.ldr1 = R1.stride(0) if R1 is not None else 0
@@ -157,12 +159,13 @@ _SPLITK_WS = {}
 
 
 def _splitk_scratch(device, nbytes):
-    """fp32 scratch of the split contractions, one per device, grown on demand (launches are stream-ordered: one buffer
-    serves them all)."""
-    buf = _SPLITK_WS.get(device)
+    """fp32 scratch of the split contractions, one per (device, stream), grown on demand: the launches of one stream are
+    ordered, two streams (ControlNet beside the UNet encoder) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLITK_WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _SPLITK_WS[device] = buf
+        _SPLITK_WS[key] = buf
     return buf
 
 

@@ -85,7 +85,8 @@ typedef struct ctrlv_gemm_desc {
   int32_t lda, lda2, c_split;
   int32_t mode;                       /* 0 plain, 1 conv2d 3x3, 2 temporal (3,1,1) */
   int32_t H, Wd, Ho, Wo, stride, up;  /* mode 1: input H x Wd (before upsample), output Ho x Wo */
-  int32_t F, S;                       /* mode 2: frames per clip, pixels per frame */
+  int32_t F, S;                       /* mode 2: frames per clip, pixels per frame.  mode 0: S = optional rows-per-image
+                                         hint (0 = unknown), the shape key of the split plan (ctrlv_gemm_splitk_ws_bytes) */
   int32_t ldo, n_store;               /* output leading dimension; columns >= n_store are not written */
   int32_t ldr1, ldr2;
   float s_acc, s1, s2;

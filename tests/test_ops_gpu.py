@@ -364,6 +364,42 @@ def test_gemm_split_contraction(ops, kind, H, W, n, cin, cout):
         assert torch.equal(o1, out[:S])
 
 
+@pytest.mark.parametrize("epi", ["r1", "r1r2", "r1v"])
+def test_gemm_split_contraction_linear(ops, epi):
+    """The same split for nn.Linear (the feed-forward output projection of the mid block's transformer at the 5 x 8 level of a
+    320 x 512 step: K = 5120, 40 pixels per image): mode 0 has no image size of its own, the caller's rows-per-image hint
+    is the plan's key."""
+    from ctrlv_amd import packing
+    S, n, K, N = 40, 12, 5120, 1280
+    M = n * S
+    A = bf(torch.randn(M, K, generator=g(1)))
+    wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    R1, R2 = bf(torch.randn(M, N, generator=g(4))), bf(torch.randn(M, N, generator=g(5)))
+    V = torch.randn(n, N, generator=g(6))
+    lin = A.float() @ bf(wt).float().T + b
+    kw, ref = dict(R1=R1.to(DEV)), lin + R1.float()
+    if epi == "r1r2":
+        kw.update(s_acc=0.4, s1=0.4, R2=R2.to(DEV), s2=0.6)
+        ref = 0.4 * lin + 0.4 * R1.float() + 0.6 * R2.float()
+    elif epi == "r1v":
+        kw.update(V=V.to(DEV), vmode=1, vdiv=S, vmod=n)
+        ref = ref + V[torch.arange(M) // S]
+    Ad, Wd, bd = A.to(DEV), packing.pack_linear(wt).to(DEV), b.to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=EL, device=DEV)
+    assert ops.gemm_splitk_slices(Ad, Wd, out, N=N, cin=K, bias=bd, **kw) == 1          # no hint, no split
+    assert ops.gemm_splitk_slices(Ad, Wd, out, N=N, cin=K, bias=bd, rows_per_image=S, **kw) >= 2
+    ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, rows_per_image=S, **kw)
+    assert parity_err(out, ref, epi) < tol(3e-3)
+    plain = torch.empty_like(out)
+    ops.gemm(Ad, Wd, plain, N=N, cin=K, bias=bd, **kw)
+    assert rel_l2(out.float().cpu(), plain.float().cpu()) < tol(2e-3)
+    kw1 = {k: (v[:S] if k in ("R1", "R2") else v) for k, v in kw.items()}
+    o1 = torch.full((S, N), float("nan"), dtype=EL, device=DEV)
+    ops.gemm(Ad[:S], Wd, o1, N=N, cin=K, bias=bd, rows_per_image=S, **kw1)
+    assert torch.equal(o1, out[:S])
+
+
 @pytest.mark.parametrize("M,K,N", [(1, 320, 1280), (2, 1280, 1280), (5, 1024, 11520), (8, 64, 64)])
 def test_gemm_per_clip_rows(ops, M, K, N):
     """M <= 8 (the conditioning path's per-clip GEMMs: csrc/gemm.hip gemv_small_kernel): every epilogue operand set the
