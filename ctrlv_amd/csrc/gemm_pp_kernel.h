@@ -1227,7 +1227,9 @@ template <int BN, int WM, int WN, int MODE>
 int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   if constexpr (BN == 320 && MODE != 0) {
     // producer-side GroupNorm statistics (gemm_epilogue_lds, GNS): the conv1 / conv2 / temporal conv1 launches of a res
-    // block, whose outputs go straight into a GroupNorm.  ctrlv_gemm has checked ctrlv_gemm_gn_partials_serves(d).
+    // block, whose outputs go straight into a GroupNorm, and its temporal conv2 (AlphaBlender epilogue, {R1}) when the
+    // block is followed by a transformer (whose first op is a GroupNorm).  ctrlv_gemm has checked
+    // ctrlv_gemm_gn_partials_serves(d).
     if (d.gn_partials) {
       const int e = pp_epi_of(d);
       if constexpr (MODE == 1) {
@@ -1235,6 +1237,7 @@ int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
         if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, true, true>(d, persistent, stream);
       } else {
         if (e == 1) return launch_one<BN, WM, WN, MODE, false, 1, false, false, false, true>(d, persistent, stream);
+        if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, true>(d, persistent, stream);
       }
       ctrlv_set_error("ctrlv_gemm: gn_partials not served for this launch");
       return CTRLV_E_BAD_ARG;

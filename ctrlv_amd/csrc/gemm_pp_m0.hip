@@ -55,7 +55,9 @@ extern "C" int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* dp) {
     if (!(e == 1 || e == 2) || !ctrlv_conv_halo_order(d)) return 0;
     S = (long)d.Ho * d.Wo;
   } else if (d.mode == 2) {
-    if (e != 1) return 0;
+    static int cross = -1;               // A/B handle: CTRLV_GN_CROSS=0 -> the {R1} temporal conv (a res block's last GEMM,
+    if (cross < 0) { const char* e2 = getenv("CTRLV_GN_CROSS"); cross = e2 ? atoi(e2) : 1; }   // feeding the transformer's norm) does not serve
+    if (!(e == 1 || (e == 2 && cross))) return 0;
     S = d.S;
   } else {
     return 0;

@@ -439,6 +439,9 @@ struct Ctx {
   float* temb = nullptr; int ldtemb = 0;
   float* xattn = nullptr; int ldx = 0;
   bool quirk = false;
+  // GroupNorm chunk partials that cross a block boundary: written by the last GEMM of a res block (temporal conv2) for
+  // the GroupNorm that opens the transformer behind it (one buffer per forward, used in stream order)
+  float* gn_cross = nullptr; size_t gn_cross_floats = 0; bool gn_cross_valid = false;
 
   void* alloc(size_t bytes) {
     const size_t a = (bytes + 255) & ~(size_t)255;
@@ -562,10 +565,16 @@ int layernorm(Ctx& c, const el_t* x, int M, int C, const Norm& nm, el_t* y, cons
 }
 
 // ---- SpatioTemporalResBlock (blocks.py::SpatioTemporalResBlock.run)
-int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, int H, int W, el_t** out_) {
+int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, int H, int W, el_t** out_,
+            bool feeds_norm = false) {
   const int N = c.B * c.F, S = H * W, F = c.F;
   const long M = (long)N * S;
   const int cin = r.cin, cout = r.cout;
+  c.gn_cross_valid = false;
+  if (feeds_norm && S % 64 == 0) {      // (sized from the shape alone, outside this block's scratch region)
+    const size_t need = ((size_t)N * (S / 64) + N) * 64;
+    if (c.gn_cross_floats < need) { c.gn_cross = (float*)c.alloc(need * 4); c.gn_cross_floats = need; }
+  }
   el_t* out = c.rows(M, cout);
   const size_t mk = c.mark();
   const int lda_x = x2 ? c1 : cin;
@@ -607,6 +616,10 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
     ctrlv_gemm_desc d = gd(hn, cout, r.tc2, out, cout, (int)M, cout, cout, cout);
     d.taps = 3; d.mode = 2; d.F = F; d.S = S;
     d.s_acc = (float)(1.0 - r.alpha); d.R1 = xs; d.ldr1 = cout;
+    if (feeds_norm && S % 64 == 0 && !c.dry && ctrlv_gemm_gn_partials_serves(&d)) {
+      d.gn_partials = c.gn_cross;       // the transformer behind this block opens with a GroupNorm of `out`
+      c.gn_cross_valid = true;
+    }
     TRY(gemm(c, d));
   }
   c.release(mk);
@@ -727,7 +740,13 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     emb = e;
   }
   el_t* tt = c.rows(M, C);
-  TRY(groupnorm(c, x, nullptr, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
+  if (c.gn_cross_valid && !c.dry) {     // statistics from the res block's last GEMM (run_res, feeds_norm)
+    c.gn_cross_valid = false;
+    ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * N * (double)S * C, N * S, C, 1);
+    TRY(ctrlv_groupnorm_from_partials(x, N, S, C, 1, 1e-6f, c.gn_cross, t.gn.g, t.gn.b, 0, tt, c.st));
+  } else {
+    TRY(groupnorm(c, x, nullptr, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
+  }
   el_t* h0 = c.rows(M, C);
   TRY(gemm(c, gd(tt, C, t.pin, h0, C, (int)M, C, C, C)));
   // ---- spatial BasicTransformerBlock
@@ -918,7 +937,7 @@ int run_down_mid(Ctx& c, el_t* x, int h, int w, std::vector<Tap>& taps, el_t** m
   for (auto& b : p->down) {
     for (size_t j = 0; j < b.res.size(); ++j) {
       el_t* y;
-      TRY(run_res(c, b.res[j], x, nullptr, 0, H, W, &y));
+      TRY(run_res(c, b.res[j], x, nullptr, 0, H, W, &y, !b.attn.empty()));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
       taps.push_back({x, H, W, b.res[j].cout});
@@ -931,7 +950,7 @@ int run_down_mid(Ctx& c, el_t* x, int h, int w, std::vector<Tap>& taps, el_t** m
     }
   }
   el_t* y;
-  TRY(run_res(c, p->mid_r0, x, nullptr, 0, H, W, &y)); x = y;
+  TRY(run_res(c, p->mid_r0, x, nullptr, 0, H, W, &y, true)); x = y;
   TRY(run_tr(c, p->mid_attn, x, H, W, &y)); x = y;
   TRY(run_res(c, p->mid_r1, x, nullptr, 0, H, W, &y)); x = y;
   *mid_ = x; *H_ = H; *W_ = W;
@@ -976,7 +995,7 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
       const Tap skip = taps.back();
       taps.pop_back();
       el_t* y;
-      TRY(run_res(c, b.res[j], x, skip.x, b.res[j].cin - skip.C, H, W, &y));
+      TRY(run_res(c, b.res[j], x, skip.x, b.res[j].cin - skip.C, H, W, &y, !b.attn.empty()));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
     }

@@ -32,6 +32,8 @@ class FwdCtx:
         self.xattn = xattn                # fp32 [B, sum C];   attentions hold their column offset
         self.quirk = time_context_order == "sb"
         self.gn_part = None               # shared fp32 scratch for GroupNorm partial sums
+        self.gn_cross = None              # chunk partials a res block's last GEMM wrote for the transformer behind it
+        self.gn_cross_valid = False       # (plan.hip Ctx::gn_cross)
         self.trace = None                 # debugging aid: list collecting (block, output rows clone, H, W)
 
 
@@ -230,8 +232,9 @@ class SpatioTemporalResBlock(nn.Module):
             pk["bsc"] = _f32(s.conv_shortcut.bias)
         self._pk = pk
 
-    def run(self, ctx, x, H, W, x2=None):
-        """x (| x2 on channels): rows [B*F*H*W, cin] -> rows [.., cout]."""
+    def run(self, ctx, x, H, W, x2=None, feeds_norm=False):
+        """x (| x2 on channels): rows [B*F*H*W, cin] -> rows [.., cout].  feeds_norm: the next op is a transformer, whose
+        opening GroupNorm takes its statistics from this block's last GEMM where that launch serves them."""
         pk, ws = self._pk, ctx.ws
         B, F = ctx.B, ctx.F
         N, S = B * F, H * W
@@ -264,8 +267,15 @@ class SpatioTemporalResBlock(nn.Module):
                                                     V=vt, vmode=1, vdiv=F * S),
                         N, S, cout, F, pk["tg2"], pk["tb2"], self.eps, hn)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
-        ops.gemm(hn, pk["tw2"], out, N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"],
-                 s_acc=1.0 - pk["alpha"], R1=xs)
+        kw2 = dict(N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"], s_acc=1.0 - pk["alpha"], R1=xs)
+        ctx.gn_cross_valid = False
+        if feeds_norm and S % 64 == 0 and ops.gemm_gn_partials_serves(hn, pk["tw2"], out, **kw2):
+            need = ops.groupnorm_fused_scratch_floats(N, S, 1)
+            if ctx.gn_cross is None or ctx.gn_cross.numel() < need:
+                ctx.gn_cross = torch.empty(need, dtype=torch.float32, device=ws.device)
+            kw2["gn_partials"] = ctx.gn_cross
+            ctx.gn_cross_valid = True
+        ops.gemm(hn, pk["tw2"], out, **kw2)
         ws.release(mk)
         if ctx.trace is not None:
             ctx.trace.append((self, out.clone(), H, W))
@@ -362,7 +372,11 @@ class TransformerSpatioTemporalModel(nn.Module):
         mk = ws.mark()
         part = _gn_scratch(ctx, N, S, C, 1)
         t = ws.alloc((M, C))
-        ops.groupnorm(x, None, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, part)
+        if ctx.gn_cross_valid:       # statistics from the res block's last GEMM (SpatioTemporalResBlock.run, feeds_norm)
+            ctx.gn_cross_valid = False
+            ops.groupnorm_from_partials(x, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, ctx.gn_cross)
+        else:
+            ops.groupnorm(x, None, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, part)
         h0 = ws.alloc((M, C))
         ops.gemm(t, pk["pin"][0], h0, N=C, cin=C, bias=pk["pin"][1])
         # ---- spatial BasicTransformerBlock
@@ -458,7 +472,7 @@ class CrossAttnDownBlockSpatioTemporal(nn.Module):
     def run(self, ctx, x, H, W):
         taps = []
         for resnet, attn in zip(self.resnets, self.attentions):
-            x = resnet.run(ctx, x, H, W)
+            x = resnet.run(ctx, x, H, W, feeds_norm=True)
             x = attn.run(ctx, x, H, W)
             taps.append((x, H, W))
         if self.downsamplers is not None:
@@ -500,10 +514,10 @@ class UNetMidBlockSpatioTemporal(nn.Module):
             self.resnets.append(SpatioTemporalResBlock(in_channels, in_channels, temb_channels, eps=1e-5))
 
     def run(self, ctx, x, H, W):
-        x = self.resnets[0].run(ctx, x, H, W)
-        for attn, resnet in zip(self.attentions, self.resnets[1:]):
+        x = self.resnets[0].run(ctx, x, H, W, feeds_norm=len(self.attentions) > 0)
+        for i, (attn, resnet) in enumerate(zip(self.attentions, self.resnets[1:])):
             x = attn.run(ctx, x, H, W)
-            x = resnet.run(ctx, x, H, W)
+            x = resnet.run(ctx, x, H, W, feeds_norm=i + 1 < len(self.attentions))
         return x
 
 
@@ -548,7 +562,7 @@ class CrossAttnUpBlockSpatioTemporal(_UpBase):
     def run(self, ctx, x, H, W, skips):
         for resnet, attn in zip(self.resnets, self.attentions):
             skip = skips.pop()
-            x = resnet.run(ctx, x, H, W, x2=skip)
+            x = resnet.run(ctx, x, H, W, x2=skip, feeds_norm=True)
             x = attn.run(ctx, x, H, W)
         if self.upsamplers is not None:
             x, H, W = self.upsamplers[0].run(ctx, x, H, W)

@@ -255,7 +255,7 @@ def test_gemm_conv3x3_row_halo(ops, H, W, n, cin, cout):
 
 @pytest.mark.parametrize("kind,H,W,n,ips,cin,cout,shift", [
     ("conv_v", 8, 32, 3, 1, 64, 320, 0.0), ("conv_r1", 4, 64, 6, 3, 128, 640, 0.0), ("conv_v", 2, 32, 4, 1, 64, 1280, 0.0),
-    ("temporal_v", 8, 16, 6, 3, 64, 320, 0.0), ("temporal_v", 8, 8, 4, 2, 128, 640, 0.0),
+    ("temporal_v", 8, 16, 6, 3, 64, 320, 0.0), ("temporal_v", 8, 8, 4, 2, 128, 640, 0.0), ("temporal_r1", 8, 16, 6, 3, 64, 320, 0.0),
     ("conv_v", 8, 32, 2, 1, 64, 320, 8.0), ("conv_r1", 9, 128, 2, 2, 64, 320, 0.0)])
 def test_gemm_writes_groupnorm_partials(ops, kind, H, W, n, ips, cin, cout, shift):
     """Producer-side GroupNorm statistics (csrc/gemm_pp_kernel.h GNS): the conv1 / conv2 / temporal-conv1 launches of a res
