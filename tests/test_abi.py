@@ -88,3 +88,53 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(import|from)\s+(oracle|ctrlv_ref)", s, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def _conv_desc(_lib, M, N, cin, H, W, taps=9, mode=1, F=25, R1=False, V=False):
+    d = _lib.GemmDesc()
+    d.A, d.W, d.out = 0x1000, 0x2000, 0x3000            # (host logic only: never dereferenced)
+    d.M, d.N, d.Cin, d.taps, d.mode = M, N, cin, taps, mode
+    d.lda, d.ldo, d.n_store = cin, N, N
+    d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = H, W, H, W, 1, 0
+    d.F, d.S = F, H * W
+    d.s_acc = d.s1 = d.s2 = 1.0
+    d.vdiv, d.vmod, d.vS = F * H * W, 1 << 30, 1
+    if R1:
+        d.R1, d.ldr1 = 0x4000, N
+    if V:
+        d.V, d.ldv, d.vmode = 0x5000, N, 1
+    return d
+
+
+def test_launch_plans_depend_on_the_layer_shape_not_on_the_batch():
+    """The two optional side channels of ctrlv_gemm are decided on the host from the LAYER's shape -- pixels per image, N,
+    Cin, taps, epilogue operands -- and never from the number of images: a clip is computed with the same kernels and the
+    same summation order alone and inside a batch (clip independence is bit-exact; the GPU suite checks the bits)."""
+    import ctypes
+    from ctrlv_amd import _lib
+    lib = _lib.load()
+
+    def slices(d):
+        return max(1, lib.ctrlv_gemm_splitk_ws_bytes(ctypes.byref(d)) // (d.M * d.N * 4))
+
+    # split contraction: the 9x16 / 10x16 / 5x8 levels split, the larger ones never do; same plan for 1, 25, 50, 400 images
+    for (H, W, cin, want_split) in ((9, 16, 1280, True), (5, 8, 1280, True), (5, 8, 2560, True), (18, 32, 1280, False),
+                                    (72, 128, 320, False)):
+        got = {n: slices(_conv_desc(_lib, n * H * W, 1280 if cin >= 1280 else 320, cin, H, W, R1=True)) for n in (1, 25, 50, 400)}
+        assert len(set(got.values())) == 1, (H, W, got)
+        assert (got[50] > 1) == want_split, (H, W, cin, got)
+    d = _conv_desc(_lib, 50 * 40, 1280, 1280, 5, 8, taps=3, mode=2, V=True)
+    assert slices(d) > 1
+    d.tile = 6                                                           # a forced tile is never split
+    assert slices(d) == 1
+    # producer-side GroupNorm statistics: row-halo 3x3 convs with {V} or {R1}, temporal convs with {V} or {R1}; N = 320 / 640
+    # / 1280; images of a multiple of 64 pixels; not the plain epilogue, not N = 960, not 9x16
+    serves = lambda d: lib.ctrlv_gemm_gn_partials_serves(ctypes.byref(d))   # noqa: E731
+    for n in (1, 2, 50):
+        assert serves(_conv_desc(_lib, n * 72 * 128, 320, 320, 72, 128, V=True))
+        assert serves(_conv_desc(_lib, n * 36 * 64, 640, 1280, 36, 64, R1=True))
+        assert serves(_conv_desc(_lib, n * 18 * 32, 1280, 1280, 18, 32, taps=3, mode=2, R1=True))
+        assert not serves(_conv_desc(_lib, n * 72 * 128, 320, 320, 72, 128))
+        assert not serves(_conv_desc(_lib, n * 72 * 128, 960, 320, 72, 128, V=True))
+        assert not serves(_conv_desc(_lib, n * 9 * 16, 1280, 1280, 9, 16, V=True))
+        assert not serves(_conv_desc(_lib, n * 16 * 16, 320, 320, 16, 16, V=True))     # W < 32: no row-halo kernel
