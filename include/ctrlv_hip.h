@@ -119,10 +119,11 @@ int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
  * image, N, Cin, taps -- and of M only through the size of the scratch: a clip is computed with the same summation order
  * alone and in a batch.  A caller that passes the scratch for one batch size must pass it for every batch size. */
 size_t ctrlv_gemm_splitk_ws_bytes(const ctrlv_gemm_desc* d);
-/* 1 if a launch of `d` can write gn_partials: a 3x3 conv (row-halo eligible geometry) with a {V} or {R1} epilogue or a
- * temporal conv with a {V} epilogue (ResnetBlock2D.conv1 / conv2, TemporalResnetBlock.conv1: the producers of norm2,
- * temporal norm1, temporal norm2), N = 320 / 640 / 1280, image size a multiple of 64 pixels.  Depends on the layer's
- * shape only, never on the batch size. */
+/* 1 if a launch of `d` can write gn_partials: a 3x3 conv (row-halo eligible geometry) or a temporal conv with a {V} or
+ * {R1} epilogue (ResnetBlock2D.conv1 / conv2, TemporalResnetBlock.conv1 / conv2: the producers of norm2, temporal norm1,
+ * temporal norm2 and -- conv2 with the AlphaBlender epilogue -- of the GroupNorm that opens the transformer behind the
+ * block), N = 320 / 640 / 1280, image size a multiple of 64 pixels.  Depends on the layer's shape only, never on the
+ * batch size. */
 int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------------------------
