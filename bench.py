@@ -70,7 +70,11 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="element type of activations / packed weights: bf16 (BASELINE.json's dtype, libctrlv_hip.so) or "
-                         "fp16 (the reference's autocast dtype, libctrlv_hip_f16.so: model-level parity 1e-3 instead of 1e-2)")
+                         "fp16 (the reference's autocast dtype, libctrlv_hip_f16.so: model-level rel-L2 1.3e-3 measured instead of 1.0e-2, "
+                         "gate 2e-3; below north_star's 1e-3 with --trunk fp16x2)")
+    ap.add_argument("--trunk", choices=["same", "fp16x2"], default="same",
+                    help="storage of the residual trunk (with --dtype fp16): same = one fp16 element per value; fp16x2 = split "
+                         "hi + lo fp16 planes (fp32's bytes, 21+ significant bits) -- north_star's 1e-3 model-level tolerance")
     ap.add_argument("--no-profile-step", action="store_true",
                     help="skip the extra instrumented eager step (no `roofline` in the output): for runs under rocprofv3 --pmc")
     ap.add_argument("--no-fp16-leg", action="store_true",
@@ -291,7 +295,11 @@ def cpu_baseline(args, unet, ctrl, device):
     return cpu, parity, ref
 
 
-PARITY_TOL = {"bf16": 1.5e-2, "fp16": 3e-3}
+# Bounds this bench asserts per storage mode (measured on the complete 25-frame step: bf16 1.03e-2, fp16 1.28e-3, fp16 with
+# the split trunk < 1e-3) and the number north_star itself states.  `parity.ok` is against `tolerance`;
+# `parity.meets_north_star` against NORTH_STAR_TOL.
+PARITY_TOL = {"bf16": 1.5e-2, "fp16": 2e-3, "fp16+fp16x2": 1e-3}
+NORTH_STAR_TOL = 1e-3
 
 
 def hip_parity(unet, ctrl, ref, F, h, w, device):
@@ -300,6 +308,8 @@ def hip_parity(unet, ctrl, ref, F, h, w, device):
     from tests.parity_utils import max_err, rel_l2
     inp = cpu_sample_inputs(F, h, w)
     el = "fp16" if unet.dtype == torch.float16 else "bf16"
+    if getattr(unet, "trunk_dtype", "same") != "same":
+        el += "+" + unet.trunk_dtype
     dv = lambda x: x.to(device, unet.dtype)   # noqa: E731
     with torch.no_grad():
         down = mid = None
@@ -313,17 +323,21 @@ def hip_parity(unet, ctrl, ref, F, h, w, device):
     # tol * (6 rms(ref) + 2 |ref|)
     parity = {"rel_l2": round(rel_l2(got, ref), 6), "max_elem": round(max_err(got, ref), 6),
               "max_abs": round((got - ref).abs().max().item(), 6), "ref_rms": round(rms, 6),
-              "tolerance": PARITY_TOL[el],
+              "tolerance": PARITY_TOL[el], "north_star_tolerance": NORTH_STAR_TOL,
               "what": f"HIP UNet output ({el} storage) vs the fp32 CPU oracle, same weights / inputs, {F} frames at {h}x{w}; "
-                      "ok = rel-L2 < tolerance and |a - ref| < tolerance * (6 rms(ref) + 2 |ref|) for every element"}
+                      "ok = rel-L2 < tolerance and |a - ref| < tolerance * (6 rms(ref) + 2 |ref|) for every element with "
+                      "this storage mode's own bound; meets_north_star = rel-L2 < north_star_tolerance (BASELINE.json: "
+                      "'within 1e-3 relative')"}
     parity["ok"] = bool(parity["rel_l2"] < parity["tolerance"] and parity["max_elem"] < parity["tolerance"])
+    parity["meets_north_star"] = bool(parity["rel_l2"] < NORTH_STAR_TOL)
     return parity
 
 
-def fp16_leg(args, unet, ctrl, ref, device):
+def fp16_leg(args, unet, ctrl, ref, device, trunk="same"):
     """bf16 runs only: the SAME weights and the SAME sample through the fp16 element build (libctrlv_hip_f16.so) -- its
     parity against the oracle output `ref` (north_star's 1e-3 needs fp16 storage: DESIGN.md 4) and its step time,
-    reported beside the bf16 headline.  Not part of `value`."""
+    reported beside the bf16 headline; trunk = "fp16x2": the same with the residual trunk split into hi + lo planes.  Not
+    part of `value`."""
     import torch
     from ctrlv_amd.utils import build_on_device
 
@@ -335,6 +349,9 @@ def fp16_leg(args, unet, ctrl, ref, device):
         m2.load_state_dict(m.state_dict())
         return m2.to(torch.float16)
     u16, c16 = clone16(unet), clone16(ctrl)
+    for m in (u16, c16):
+        if m is not None:
+            m.trunk_dtype = trunk
     F = args.frames if (args.cpu_full_step or args.cpu_frames <= 0 or args.cpu_frames >= args.frames) else args.cpu_frames
     out = {"parity": hip_parity(u16, c16, ref, F, args.height // 8, args.width // 8, device)}
     st = make_stepper(u16, c16, device, args, clip_index=0)
@@ -349,7 +366,11 @@ def fp16_leg(args, unet, ctrl, ref, device):
     dt = time.perf_counter() - t0
     out.update(value=round(args.steps / dt, 4), unit="steps/s", ms_per_step=round(dt / args.steps * 1e3, 2), steps=args.steps,
                finite=bool(torch.isfinite(st.latents).all()),
-               what="the same weights, workload and HIP-graph step with fp16 elements (bench.py --dtype fp16 is the full line)")
+               what="the same weights, workload and HIP-graph step with fp16 elements"
+                    + (" and the split (fp16x2) residual trunk" if trunk != "same" else "")
+                    + f" (bench.py --dtype fp16{' --trunk fp16x2' if trunk != 'same' else ''} is the full line)")
+    del st, u16, c16
+    torch.cuda.empty_cache()
     return out
 
 
@@ -403,6 +424,12 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     unet, ctrl = build_models(device, args.workload, args.frames, torch_dtype(args.dtype))
+    if args.trunk != "same":
+        if args.dtype != "fp16":
+            raise SystemExit("bench.py: --trunk fp16x2 needs --dtype fp16 (the split planes are fp16 elements)")
+        for m in (unet, ctrl):
+            if m is not None:
+                m.trunk_dtype = args.trunk
     clip = D.shard_clips(world, rank, world)[0]                        # one clip per rank (weak scaling)
     st = make_stepper(unet, ctrl, device, args, clip_index=clip)
     lib = _lib.load(unet.el_dtype)
@@ -471,11 +498,16 @@ def main():
                 for fam, keys in alias.items():
                     keys = [k for k in keys if k in raw]
                     if keys:
-                        pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
-                        # launches per step of the kernels the PMC figure covers (the ping-pong + fused GEMM kernels of a
-                        # family, not its tiny 2-stage launches): traffic x traffic_launches = the family's bytes per step
+                        # `traffic` x `traffic_launches` = the family's PMC bytes per step.  traffic_launches = launches per
+                        # step of the kernels the figure covers (the ping-pong + fused GEMM kernels of a family, not its tiny
+                        # 2-stage launches); a family of several kernels with DIFFERENT launch counts (GroupNorm: apply x 152,
+                        # statistics x 68, finalize x 152) is summed per step first and divided by the largest count
                         if all("launches_per_step" in raw[k] for k in keys):
                             pmc_launches[fam] = max(raw[k]["launches_per_step"] for k in keys)
+                            per_step = sum(raw[k]["traffic_bytes_per_launch"] * raw[k]["launches_per_step"] for k in keys)
+                            pmc[fam] = per_step / pmc_launches[fam]
+                        else:
+                            pmc[fam] = sum(raw[k]["traffic_bytes_per_launch"] for k in keys)
                 pmc["_source"] = os.path.relpath(cands[-1], ROOT)
     except Exception as ex:       # noqa: BLE001
         pmc_note = f"PMC summary unreadable: {ex}"
@@ -509,7 +541,7 @@ def main():
                    else f"denoising steps/sec, SVD UNet-only {shape}"),
         "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "trunk": args.trunk, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {'ControlNet + ' if ctrl is not None else ''}UNet forward, CFG batch 2, "
                                f"{args.frames} frames, latent {args.height // 8}x{args.width // 8}, 25-step Karras Euler "
                                "schedule, random-init SVD-XT weights", "clips_per_gpu": 1, "parallelism": f"clip-shard x{world}",
@@ -536,6 +568,8 @@ def main():
         if args.dtype == "bf16" and ref is not None and not args.no_fp16_leg:
             log("fp16 leg: the same weights / sample through libctrlv_hip_f16.so ...")
             line["fp16_build"] = fp16_leg(args, unet, ctrl, ref, device)
+            log("fp16 leg with the split (fp16x2) residual trunk ...")
+            line["fp16_split_trunk_build"] = fp16_leg(args, unet, ctrl, ref, device, trunk="fp16x2")
     print(json.dumps(line))
 
 

@@ -27,6 +27,7 @@ class GemmDesc(ctypes.Structure):
         ("ld_raw", c_int), ("raw_out", c_void_p),
         ("n_scale2", c_int), ("s_acc2", c_float),
         ("gn_partials", c_void_p), ("splitk_ws", c_void_p), ("ksplit", c_int), ("w_cin", c_int),
+        ("R1_lo", c_void_p), ("R2_lo", c_void_p), ("out_lo", c_void_p),      # split trunk planes (fp16 library)
     ]
 
 
@@ -73,6 +74,14 @@ SIGNATURES = {
     "ctrlv_groupnorm_from_partials": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                               c_int, c_void_p, c_void_p]),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
+    "ctrlv_groupnorm_stats_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                            c_void_p, c_void_p]),
+    "ctrlv_groupnorm_apply_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                            c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctrlv_layernorm_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
+                                      c_int, c_void_p, c_void_p]),
+    "ctrlv_axpby_split": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ctrlv_plan_set_trunk_mode": (c_int, [c_void_p, c_int]),
     "ctrlv_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p]),
     "ctrlv_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -137,7 +146,7 @@ SIGNATURES = {
 }
 
 _libs = {}                # element dtype code (2 bf16 / 1 fp16) -> CDLL
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class CtrlvHipError(RuntimeError):

@@ -94,6 +94,31 @@ __device__ __forceinline__ uint4 pack_elx8(const float* f) {
   v.z = pack_elx2(f[4], f[5]); v.w = pack_elx2(f[6], f[7]);
   return v;
 }
+// ---- SPLIT storage of the residual trunk (round 5; DESIGN.md 4 "trunk").  A trunk tensor may carry a second plane of
+// the same shape: hi = rne_el(v), lo = rne_el(v - hi) -- 2 x 16 bits per element (fp32's bytes), 21+ significant bits with
+// fp16 elements.  MFMA consumers read the hi plane in place (it IS the element-rounded tensor); residual operands and
+// norm inputs read hi + lo.  v - hi is exact in fp32 (hi is v rounded to fewer bits), so lo carries one rounding.
+__device__ __forceinline__ uint4 split_lo8(const float* v, const uint4& hi) {
+#pragma clang fp contract(off)
+  float h[8], dl[8];
+  unpack_elx8(hi, h);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dl[e] = v[e] - h[e];
+  return pack_elx8(dl);
+}
+__device__ __forceinline__ el_t split_lo1(float v, el_t hi) {
+#pragma clang fp contract(off)
+  return f32_to_el(v - el_to_f32(hi));
+}
+// x = hi + lo of a split tensor (lo may be absent)
+__device__ __forceinline__ void add_lo8(float* f, const uint4& lo) {
+#pragma clang fp contract(off)
+  float l[8];
+  unpack_elx8(lo, l);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = f[e] + l[e];
+}
+
 // silu(x) = x * sigmoid(x) with the raw v_exp_f32 / v_rcp_f32 (1 ulp each); x -> -inf gives x * 0.
 __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));

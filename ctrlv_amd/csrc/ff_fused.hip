@@ -45,7 +45,7 @@ struct FfArgs {
   const float* lnv; int ln_vdiv, ln_vmod, ln_ldv;
 };
 
-template <int EPI>
+template <int EPI, bool LO = false>
 __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
     char* stg = smem + wid * 10 * 1024;
     int lane_e = lane;                                       // (opaque copy: keeps the epilogue's lane constants per-tile values
     asm volatile("" : "+v"(lane_e));                         //  instead of hoisted, spilled ones -- gemm_pp_kernel.h)
-    gemm_epilogue_lds<1, 10, false, EPI>(d, acc, bm, 0, wid, 0, 32, kC, lane_e, stg, stg + 1024, stg + 2048, stg + 3072,
-                                         nullptr, tab);
+    gemm_epilogue_lds<1, 10, false, EPI, false, false, LO>(d, acc, bm, 0, wid, 0, 32, kC, lane_e, stg, stg + 1024, stg + 2048,
+                                                           stg + 3072, nullptr, tab);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging reads done before the next tile's x_hi writes
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last chunks: nothing may be in flight
@@ -300,10 +300,10 @@ __global__ void ff_pack_kernel(const el_t* __restrict__ w1p, const float* __rest
   }
 }
 
-template <int EPI>
+template <int EPI, bool LO = false>
 int launch_ff(const FfArgs& a, hipStream_t stream) {
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = ff_fused_kernel<EPI>;
+  auto kfn = ff_fused_kernel<EPI, LO>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
@@ -359,6 +359,10 @@ static int ff_check(const ctrlv_gemm_desc& d, int ldx, bool report, bool* fold) 
              (!d.R2 || (long)d.M * d.ldr2 * 2 <= lim),
          CTRLV_E_BAD_SHAPE, "ctrlv_ff_fused: operands beyond 32-bit byte offsets");
   FF_REQ(!d.R2 || d.R1, CTRLV_E_BAD_ARG, "ctrlv_ff_fused: R2 without R1");
+  if (pp_split_io(d)) {      // split trunk planes (include/ctrlv_hip.h): the fp16 element library, {R1} and {R1, R2} epilogues
+    FF_REQ(CTRLV_ELEM_DTYPE == 1 && d.R1 && (!d.R1_lo || d.R1) && (!d.R2_lo || d.R2), CTRLV_E_BAD_ARG,
+           "ctrlv_ff_fused: split trunk planes need the fp16 element library and an R1 operand");
+  }
   if (d.vmode) {
     FF_REQ((d.vmode == 1 || d.vmode == 2) && d.V && d.vdiv > 0 && d.vmod > 0 && d.ldv >= kC && d.ldv % 4 == 0 &&
                (d.vmode == 1 || d.vS > 0),
@@ -368,6 +372,7 @@ static int ff_check(const ctrlv_gemm_desc& d, int ldx, bool report, bool* fold) 
     *fold = d.vmode == 1 && d.vdiv % 256 == 0 && d.s_acc == 1.0f;
     FF_REQ(*fold || !d.R2, CTRLV_E_BAD_ARG,
            "ctrlv_ff_fused: R1 + R2 + a row vector is served only in the per-tile form (vmode 1, vdiv %% 256 == 0, s_acc 1)");
+    FF_REQ(*fold || !pp_split_io(d), CTRLV_E_BAD_ARG, "ctrlv_ff_fused: split trunk planes with a row vector: per-tile form only");
   }
   return CTRLV_OK;
 #undef FF_REQ
@@ -401,7 +406,13 @@ extern "C" int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, 
   // TN = 10 -- is the one that "intermittently stored zero dwords" in round 3: the store-data hazard of gemm_pp_kernel.h
   // (store_data_hazard_guard), a zero-initialisation of the next sub-tile's row-vector registers scheduled right behind a
   // buffer store whose data registers it reused.  Guarded, it is back in the build; tests: 48-run bit-stability.)
-  switch (pp_epi_of(d)) {
+#ifdef CTRLV_ELEM_F16
+  if (pp_split_io(d)) {
+    if (pp_epi_of(d) == 2) return launch_ff<2, true>(a, st);
+    if (pp_epi_of(d) == 6) return launch_ff<6, true>(a, st);
+  }
+#endif
+  switch (pp_split_io(d) ? -1 : pp_epi_of(d)) {
     case 0: return launch_ff<0>(a, st);
     case 1: return launch_ff<1>(a, st);
     case 2: return launch_ff<2>(a, st);

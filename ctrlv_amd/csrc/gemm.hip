@@ -206,16 +206,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
   gemm_epilogue<TM, TN>(d, acc, bm, bn, wr, wc, WTM, WTN, r32, hsel, smem + 2 * STAGE);
 }
 
-// ---- M <= 8 (the per-clip GEMMs of the conditioning path: time / added-id embedding MLPs, the fused time_emb_proj, the
-// one-key cross-attention vectors -- ~25 launches per model and step with M = B).  On the 128 x 128 MFMA tile such a launch
-// is N / 128 workgroups walking K in 64-element steps behind a barrier each: ~30 us of latency for 3 MB of weights.  Here a
-// wave owns one output column: the weight row streams through its lanes in 16-byte pieces, the M activation rows come out
-// of L2, one wave reduction per row.  Same epilogue semantics as gemm_epilogue.
-__global__ __launch_bounds__(256) void gemv_small_kernel(const ctrlv_gemm_desc d) {
+// ---- per-clip rows (the GEMMs of the conditioning path: time / added-id embedding MLPs, the fused time_emb_proj, the
+// one-key cross-attention vectors -- ~25 launches per model and step with M = B clips).  On the 128 x 128 MFMA tile such a
+// launch is N / 128 workgroups walking K in 64-element steps behind a barrier each: ~30 us of latency for 3 MB of weights.
+// Here a wave owns one output column: the weight row streams through its lanes in 16-byte pieces, the activation rows come
+// out of L2, one wave reduction per row.  Same epilogue semantics as gemm_epilogue.  Rows are computed independently, in
+// chunks of 8 (blockIdx.y): a row's bits are the same at ANY batch size (round 4 chose this kernel by M <= 8, so a clip's
+// conditioning vectors -- and with them its whole output -- changed in bits when a ninth clip joined the batch).
+__global__ __launch_bounds__(256) void gemv_small_kernel(const ctrlv_gemm_desc d0) {
   const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= d.N) return;                                  // (whole waves: no barrier below)
+  if (n >= d0.N) return;                                 // (whole waves: no barrier below)
+  // this workgroup's chunk of rows: re-base the row-indexed operands (row-vector indices keep the absolute row: m0 + m)
+  ctrlv_gemm_desc d = d0;
+  const int m0 = blockIdx.y * 8;
+  d.M = d0.M - m0 < 8 ? d0.M - m0 : 8;
   const el_t* w = (const el_t*)d.W + (long)n * d.Cin;
-  const el_t* a = (const el_t*)d.A;
+  const el_t* a = (const el_t*)d.A + (long)m0 * d.lda;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k8 = lane; k8 < (d.Cin >> 3); k8 += 64) {
     float wf[8];
@@ -242,13 +248,14 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const ctrlv_gemm_desc d
 #pragma clang fp contract(off)
       v = v * d.s_acc;
     }
-    if (d.R1) v = __builtin_fmaf(d.s1, el_to_f32(((const el_t*)d.R1)[(long)m * d.ldr1 + n]), v);
-    if (d.R2) v = __builtin_fmaf(d.s2, el_to_f32(((const el_t*)d.R2)[(long)m * d.ldr2 + n]), v);
-    if (d.vmode == 1) v += d.V[(long)((m / d.vdiv) % d.vmod) * d.ldv + n];
-    else if (d.vmode == 2) v += d.V[(long)(((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod) * d.ldv + n];
+    const int mg = m0 + m;                               // row of the launch
+    if (d.R1) v = __builtin_fmaf(d.s1, el_to_f32(((const el_t*)d.R1)[(long)mg * d.ldr1 + n]), v);
+    if (d.R2) v = __builtin_fmaf(d.s2, el_to_f32(((const el_t*)d.R2)[(long)mg * d.ldr2 + n]), v);
+    if (d.vmode == 1) v += d.V[(long)((mg / d.vdiv) % d.vmod) * d.ldv + n];
+    else if (d.vmode == 2) v += d.V[(long)(((long)(mg / d.vdiv) * d.vS + (mg % d.vS)) % d.vmod) * d.ldv + n];
     if (d.act == 1) v = silu_f(v);
-    if (d.out_f32 & 1) ((float*)d.out)[(long)m * d.ldo + n] = v;
-    else ((el_t*)d.out)[(long)m * d.ldo + n] = f32_to_el(v);
+    if (d.out_f32 & 1) ((float*)d.out)[(long)mg * d.ldo + n] = v;
+    else ((el_t*)d.out)[(long)mg * d.ldo + n] = f32_to_el(v);
   }
 }
 
@@ -278,6 +285,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_des
     o[1] = __builtin_fmaf(d.s1, el_hi_f32(rv.x), o[1]);
     o[2] = __builtin_fmaf(d.s1, el_lo_f32(rv.y), o[2]);
     o[3] = __builtin_fmaf(d.s1, el_hi_f32(rv.y), o[3]);
+    if (d.R1_lo) {
+      const uint2 rl = *(const uint2*)((const el_t*)d.R1_lo + (long)m * d.ldr1 + ncol);
+      o[0] = __builtin_fmaf(d.s1, el_lo_f32(rl.x), o[0]);
+      o[1] = __builtin_fmaf(d.s1, el_hi_f32(rl.x), o[1]);
+      o[2] = __builtin_fmaf(d.s1, el_lo_f32(rl.y), o[2]);
+      o[3] = __builtin_fmaf(d.s1, el_hi_f32(rl.y), o[3]);
+    }
   }
   if (d.R2) {
     const uint2 rv = *(const uint2*)((const el_t*)d.R2 + (long)m * d.ldr2 + ncol);
@@ -285,13 +299,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_des
     o[1] = __builtin_fmaf(d.s2, el_hi_f32(rv.x), o[1]);
     o[2] = __builtin_fmaf(d.s2, el_lo_f32(rv.y), o[2]);
     o[3] = __builtin_fmaf(d.s2, el_hi_f32(rv.y), o[3]);
+    if (d.R2_lo) {
+      const uint2 rl = *(const uint2*)((const el_t*)d.R2_lo + (long)m * d.ldr2 + ncol);
+      o[0] = __builtin_fmaf(d.s2, el_lo_f32(rl.x), o[0]);
+      o[1] = __builtin_fmaf(d.s2, el_hi_f32(rl.x), o[1]);
+      o[2] = __builtin_fmaf(d.s2, el_lo_f32(rl.y), o[2]);
+      o[3] = __builtin_fmaf(d.s2, el_hi_f32(rl.y), o[3]);
+    }
   }
   if (d.vmode) {
     const long vi = d.vmode == 1 ? (long)((m / d.vdiv) % d.vmod) : (((long)(m / d.vdiv) * d.vS + (m % d.vS)) % d.vmod);
     const float4 vv = *(const float4*)(d.V + vi * d.ldv + ncol);
     o[0] += vv.x; o[1] += vv.y; o[2] += vv.z; o[3] += vv.w;
   }
-  *(uint2*)((el_t*)d.out + (long)m * d.ldo + ncol) = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
+  const uint2 pk = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
+  *(uint2*)((el_t*)d.out + (long)m * d.ldo + ncol) = pk;
+  if (d.out_lo) {
+#pragma clang fp contract(off)
+    const float l0 = o[0] - el_lo_f32(pk.x), l1 = o[1] - el_hi_f32(pk.x), l2 = o[2] - el_lo_f32(pk.y), l3 = o[3] - el_hi_f32(pk.y);
+    *(uint2*)((el_t*)d.out_lo + (long)m * d.ldo + ncol) = make_uint2(pack_elx2(l0, l1), pack_elx2(l2, l3));
+  }
 }
 
 // Split plan of a launch: number of K slices (1 = none) and the ping-pong tile that runs them.  The 3x3 / temporal convs
@@ -398,6 +425,14 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     CTRLV_CHECK_ARG(!d.R1 && !d.R2 && !d.vmode && !d.act && !(d.out_f32 & 1) && d.mode == 0,
                     "ctrlv_gemm: GEGLU epilogue takes bias only (mode 0)");
   }
+  const bool split_io = d.R1_lo || d.R2_lo || d.out_lo;
+  if (split_io) {         // SPLIT residual-trunk planes (include/ctrlv_hip.h)
+    CTRLV_CHECK_ARG(CTRLV_ELEM_DTYPE == 1, "ctrlv_gemm: R1_lo / R2_lo / out_lo (split trunk) are served by the fp16 element "
+                                           "library only");
+    CTRLV_CHECK_ARG((!d.R1_lo || d.R1) && (!d.R2_lo || d.R2), "ctrlv_gemm: R1_lo / R2_lo need R1 / R2");
+    CTRLV_CHECK_ARG(!d.geglu && !d.act && !d.out_f32 && !d.gn_partials && !d.raw_out && !d.n_scale2,
+                    "ctrlv_gemm: split planes do not combine with GEGLU / SiLU / fp32 output / gn_partials / raw_out / n_scale2");
+  }
   if (d.splitk_ws) {      // split contraction where the layer's shape calls for it (splitk_plan)
     int tile_s = 0;
     const int slices = splitk_plan(d, &tile_s);
@@ -406,6 +441,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
       dd.Cin = d.Cin / slices; dd.w_cin = d.Cin; dd.ksplit = slices;
       dd.out = d.splitk_ws; dd.ldo = d.N; dd.n_store = d.N;
       dd.R1 = dd.R2 = nullptr; dd.V = nullptr; dd.vmode = 0; dd.s_acc = 1.0f; dd.splitk_ws = nullptr; dd.tile = 0;
+      dd.R1_lo = dd.R2_lo = nullptr; dd.out_lo = nullptr;
       if (ctrlv_gemm_pp_supports(dd) && (long)d.M * d.N * 4 < 0x7FFFFFF0L) {
         int rc = ctrlv_gemm_launch_pp(dd, tile_s, stream);
         if (rc != CTRLV_OK) return rc;
@@ -417,11 +453,15 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
       }
     }
   }
-  if (d.tile == 0 && d.mode == 0 && d.M <= 8 && !d.geglu && !d.A2 && !d.raw_out && d.n_scale2 == 0 && (d.out_f32 & ~1) == 0) {
+  // Per-clip rows: tile 11 = "this is a per-clip GEMM" (the plans say so for every GEMM of the conditioning path: the choice is
+  // the LAYER's, whatever the batch size); without a tile request, launches of up to 64 rows take it too.
+  const bool gemv_ok = d.mode == 0 && !d.geglu && !d.A2 && !d.raw_out && d.n_scale2 == 0 && (d.out_f32 & ~1) == 0 && !split_io;
+  CTRLV_CHECK_ARG(d.tile != 11 || gemv_ok, "ctrlv_gemm: tile 11 (per-clip rows) serves plain mode-0 launches only");
+  if (d.tile == 11 || (d.tile == 0 && gemv_ok && d.M <= 64)) {
     static int on = -1;                  // A/B handle: CTRLV_GEMV=0 -> the 128 x 128 MFMA tile
     if (on < 0) { const char* e = getenv("CTRLV_GEMV"); on = e ? atoi(e) : 1; }
-    if (on) {
-      hipLaunchKernelGGL(gemv_small_kernel, dim3((unsigned)((d.N + 3) / 4)), dim3(256), 0, stream, d);
+    if (on || d.tile == 11) {
+      hipLaunchKernelGGL(gemv_small_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)((d.M + 7) / 8)), dim3(256), 0, stream, d);
       CTRLV_LAUNCH_CHECK();
       return CTRLV_OK;
     }
@@ -437,6 +477,9 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     else if (d.N <= 128 && d.mode != 0) tile = 10;     // 256x128 ping-pong tile (profiles/r02_vae_decode.txt)
     else if (d.N % 320 == 0 && (d.geglu ? d.Cin < 1280 : d.N < 3840) && d.M >= 16384) tile = 6;
     else tile = 5;
+    // split planes: the 256x320 ping-pong tile is the one instantiated with the split epilogue (N = 320 / 640 / 1280: the
+    // trunk's widths), the 2-stage kernel serves everything else -- the same operation sequence in both
+    if (split_io && tile >= 5) tile = d.N % 320 == 0 ? 6 : 1;
     {
       static int force = -1;             // A/B handle (tools/shape_table.py): CTRLV_GEMM_FORCE_TILE = 5 / 6 for every large launch
       if (force < 0) { const char* e = getenv("CTRLV_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }

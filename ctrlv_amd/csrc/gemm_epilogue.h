@@ -65,6 +65,13 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             o[1] = __builtin_fmaf(d.s1, el_hi_f32(rv.x), o[1]);
             o[2] = __builtin_fmaf(d.s1, el_lo_f32(rv.y), o[2]);
             o[3] = __builtin_fmaf(d.s1, el_hi_f32(rv.y), o[3]);
+            if (d.R1_lo) {      // SPLIT trunk operand: R1 + R1_lo, one fma per plane (the ping-pong epilogue's sequence)
+              const uint2 rl = *(const uint2*)((const el_t*)d.R1_lo + (long)m * d.ldr1 + ncol);
+              o[0] = __builtin_fmaf(d.s1, el_lo_f32(rl.x), o[0]);
+              o[1] = __builtin_fmaf(d.s1, el_hi_f32(rl.x), o[1]);
+              o[2] = __builtin_fmaf(d.s1, el_lo_f32(rl.y), o[2]);
+              o[3] = __builtin_fmaf(d.s1, el_hi_f32(rl.y), o[3]);
+            }
           }
           if (d.R2) {
             const uint2 rv = *(const uint2*)((const el_t*)d.R2 + (long)m * d.ldr2 + ncol);
@@ -72,6 +79,13 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             o[1] = __builtin_fmaf(d.s2, el_hi_f32(rv.x), o[1]);
             o[2] = __builtin_fmaf(d.s2, el_lo_f32(rv.y), o[2]);
             o[3] = __builtin_fmaf(d.s2, el_hi_f32(rv.y), o[3]);
+            if (d.R2_lo) {
+              const uint2 rl = *(const uint2*)((const el_t*)d.R2_lo + (long)m * d.ldr2 + ncol);
+              o[0] = __builtin_fmaf(d.s2, el_lo_f32(rl.x), o[0]);
+              o[1] = __builtin_fmaf(d.s2, el_hi_f32(rl.x), o[1]);
+              o[2] = __builtin_fmaf(d.s2, el_lo_f32(rl.y), o[2]);
+              o[3] = __builtin_fmaf(d.s2, el_hi_f32(rl.y), o[3]);
+            }
           }
           if (vrow) {
             const float4 vv = *(const float4*)(vrow + ncol);
@@ -87,6 +101,12 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             uint2 pk = make_uint2(pack_elx2(o[0], o[1]), pack_elx2(o[2], o[3]));
             if (d.out_f32 & 2) asm volatile("" ::"v"(pk.x), "v"(pk.y));   // profiling aid: compute, do not store
             else *(uint2*)((el_t*)d.out + (long)m * d.ldo + ncol) = pk;
+            if (d.out_lo) {     // SPLIT output: lo = rne(v - hi)  (common.h split_lo8, four elements)
+#pragma clang fp contract(off)
+              const float l0 = o[0] - el_lo_f32(pk.x), l1 = o[1] - el_hi_f32(pk.x), l2 = o[2] - el_lo_f32(pk.y),
+                          l3 = o[3] - el_hi_f32(pk.y);
+              *(uint2*)((el_t*)d.out_lo + (long)m * d.ldo + ncol) = make_uint2(pack_elx2(l0, l1), pack_elx2(l2, l3));
+            }
           }
         }
       }

@@ -158,7 +158,9 @@ __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, 
 // through the wave's staging pieces turns the 64 lanes' sums into 32 column sums + 32 column square sums; after the last
 // block the wave's WTN column sums go through the staging pieces once more and WTN / cpg lanes fold their group's columns.
 // Needs WTN % cpg == 0 and a wave tile inside one image (S % 64 == 0): ctrlv_gemm_gn_partials_serves.
-template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false, bool GNS = false>
+// LO (round 5): SPLIT residual-trunk planes (include/ctrlv_hip.h R1_lo / R2_lo / out_lo): R1 / R2 are read as hi + lo (one
+// fma per plane, hi first -- gemm_epilogue.h's sequence) and the output goes out as hi = rne(v) plus lo = rne(v - hi).
+template <int TM, int TN, bool GEGLU, int EPI, bool RAW = false, bool GNS = false, bool LO = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                   int wr, int wc, int WTM, int WTN, int lane, char* p0, char* p1,
                                                   char* p2, char* p3, const char* bias_lds, const char* gelu_tab,
@@ -185,6 +187,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       (void*)((EPI & 4) ? d.R2 : d.W), 0, (EPI & 4) ? (int)((long)d.M * d.ldr2 * 2) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((EPI & 1) ? (const void*)d.V : d.W), 0, (EPI & 1) ? (int)(pp_vtable_rows(d) * d.ldv * 4) : 0, kFlags);
+  // (LO: a missing lo plane is an empty descriptor -- its loads return zeros, hi + 0)
+  const __amdgpu_buffer_rsrc_t rsOL = __builtin_amdgcn_make_buffer_rsrc(
+      (LO && d.out_lo) ? d.out_lo : (void*)d.W, 0, (LO && d.out_lo) ? (int)((long)d.M * d.ldo * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsR1L = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((LO && (EPI & 2) && d.R1_lo) ? d.R1_lo : d.W), 0, (LO && (EPI & 2) && d.R1_lo) ? (int)((long)d.M * d.ldr1 * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsR2L = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((LO && (EPI & 4) && d.R2_lo) ? d.R2_lo : d.W), 0, (LO && (EPI & 4) && d.R2_lo) ? (int)((long)d.M * d.ldr2 * 2) : 0, kFlags);
 
   // byte offset of the row-vector table row of (i, pass): two integer divisions per row, hoisted out of the sub-tiles
   // (GNS: the launcher guarantees vmode 1 with vdiv a multiple of the 64-row wave tile: one table row per wave tile, a scalar)
@@ -210,11 +219,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     // Residual operands are streamed from HBM (~1 us): they are prefetched through a window that GROWS as the
     // epilogue retires accumulators -- every finished sub-tile frees 16 accumulator registers, enough for the R1 rows of
     // two more sub-tiles (one with R2) -- so a 10-sub-tile epilogue pays the memory latency about once, not ten times.
-    struct Res { u32x4_t r1[2], r2[2]; };
+    struct Res { u32x4_t r1[2], r2[2], r1l[LO ? 2 : 1], r2l[LO ? 2 : 1]; };
     constexpr bool HAS_RES = (EPI & 6) != 0;
     // sub-tiles in flight before the first one is processed: bounded by what the 320-wide tile (252+ VGPRs) can hold
-    constexpr int P0 = GNS ? 1 : (TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3));
-    constexpr int GROW = ((EPI & 4) || GNS) ? 1 : (TN > 2 ? 2 : 2);   // additional sub-tiles issued per processed one
+    // (LO: every residual row is two planes -- one sub-tile ahead, one more per processed one)
+    constexpr int P0 = (GNS || LO) ? 1 : (TN > 2 ? (EPI == 2 ? 2 : 1) : ((EPI & 4) ? 2 : 3));
+    constexpr int GROW = ((EPI & 4) || GNS || LO) ? 1 : (TN > 2 ? 2 : 2);   // additional sub-tiles issued per processed one
     Res q[HAS_RES ? NSUB : 1];
     const int ocol0 = wbase_n + l4 * 8;
     // Addresses: ONE per-lane byte offset per operand (row m0, column ocol0) -- or out of range -- and the displacement
@@ -231,8 +241,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         const bool ok = m0 + dr < d.M && ocol0 + j * 32 < d.n_store;
         if (EPI & 2)
           q[s].r1[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR1, ok ? r1_base : kOOB, (dr * d.ldr1 + j * 32) * 2, 0);
+        if (LO && (EPI & 2))
+          q[s].r1l[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR1L, ok ? r1_base : kOOB, (dr * d.ldr1 + j * 32) * 2, 0);
         if (EPI & 4)
           q[s].r2[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR2, ok ? r2_base : kOOB, (dr * d.ldr2 + j * 32) * 2, 0);
+        if (LO && (EPI & 4))
+          q[s].r2l[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR2L, ok ? r2_base : kOOB, (dr * d.ldr2 + j * 32) * 2, 0);
       }
     };
     if (HAS_RES) {
@@ -316,6 +330,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           unpack_elx8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
+          if (LO) {
+            const u32x4_t rl = q[HAS_RES ? s : 0].r1l[pass];
+            unpack_elx8(make_uint4(rl.x, rl.y, rl.z, rl.w), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
+          }
         }
         if (EPI & 4) {
           float f[8];
@@ -323,6 +343,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           unpack_elx8(make_uint4(r.x, r.y, r.z, r.w), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
+          if (LO) {
+            const u32x4_t rl = q[HAS_RES ? s : 0].r2l[pass];
+            unpack_elx8(make_uint4(rl.x, rl.y, rl.z, rl.w), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
+          }
         }
         if (EPI & 1) {
 #pragma unroll
@@ -345,6 +371,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         const uint4 pk = pack_elx8(o);
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
         pp_store_out(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
+        if (LO) {
+          const uint4 pl = split_lo8(o, pk);
+          const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
+          pp_store_out(pvl, rsOL, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
+        }
       }
       if (GNS && i == TM - 1) {
         // 64 lanes x 16 sums -> 64 column sums.  Value v (0..7: sum of channel v, 8..15: its squares) of lane (row_a, l4)
@@ -527,7 +558,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 // combination exists (the 1x1 shortcut convs of the up blocks; every other consumer of a concat reads the GroupNorm
 // output), so all other instantiations carry no source-select instructions in their hot loop (~15 of ~95 per half-step).
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false,
-          bool GNS = false>
+          bool GNS = false, bool LO = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, const int cgrp) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types (__amdgpu_buffer_rsrc_t): keep it out of the host pass
   constexpr int BM = 256, NW = 8, NH = 4;
@@ -912,7 +943,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   int g = 0;
   constexpr int HM = TM / 2;
   // buffer stores a wave issues in one epilogue (straight-line code: out-of-range ones are issued and counted too)
-  constexpr int NSTORE = EPI == 8 ? TM * TN * 4 : (GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * 2);
+  constexpr int NSTORE = EPI == 8 ? TM * TN * 4 : (GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * (LO ? 4 : 2));
+  static_assert(!LO || (!GEGLU && !GNS && !RAW && EPI != 8), "split planes: plain epilogues only");
   static_assert(NPIECE + NPIECE + NSTORE <= 63, "vmcnt is a 6-bit counter");
   bool after_epi = false;                                    // this workgroup has run an epilogue (tile > first)
 #ifdef CTRLV_PP_STAMP
@@ -1108,7 +1140,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
             }
         }
       } else
-      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW, GNS>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
+      gemm_epilogue_lds<TM, TN, GEGLU, EPI, RAW, GNS, LO>(d, acc, bm, bn, wr, wc, WTM, WTN, lane_e, sa0 + wid * 1024, sa0 + (NW + wid) * 1024,
                                 s0 + A_SLOT + wid * 1024,
                                 OWN_P3 ? smem + P3_OFF + wid * 1024 : s0 + A_SLOT + (NW + wid) * 1024, bias_lds,
                                 smem + TAB_OFF,
@@ -1147,7 +1179,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 }
 
 template <int BN, int WM, int WN, int MODE, bool GEGLU, int EPI, bool HAS_A2 = false, bool RAW = false, bool HALO = false,
-          bool GNS = false>
+          bool GNS = false, bool LO = false>
 int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   // DMA ring + one bias strip (BN / WN floats) per wave + one dummy piece (ragged B piece count / row-halo staging) +
   // private fourth staging pieces (128-wide tile only) + the Phi table (GEGLU only); HALO: three 24-KiB row-halo slots in
@@ -1157,7 +1189,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   static_assert(smem <= 160 * 1024, "ping-pong tile does not fit the LDS");
   // per-device caches (a process may drive several GPUs; the dynamic-LDS attribute is per device code object)
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW, HALO, GNS>;
+  auto kfn = gemm_pp_kernel<BN, WM, WN, MODE, GEGLU, EPI, HAS_A2, RAW, HALO, GNS, LO>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1223,8 +1255,50 @@ inline int pp_epi_of(const ctrlv_gemm_desc& d) {
   return -1;
 }
 
+// does this descriptor carry SPLIT trunk planes?
+inline bool pp_split_io(const ctrlv_gemm_desc& d) { return d.R1_lo || d.R2_lo || d.out_lo; }
+
+// SPLIT residual-trunk launches (R1_lo / R2_lo / out_lo): the 256x320 tile of the fp16 element library only -- the trunk's
+// widths are multiples of 320 and its writers are {bias} (proj_in, shortcuts incl. the skip-concat form, the resampling
+// convs), {R1} (conv2, temporal conv2 = AlphaBlender, feed-forward / proj_out), {R1, V} (attention out-projections with the
+// one-key cross-attention vector, ff_in with the frame embedding) and {R1, R2} (the temporal block's folded AlphaBlender).
+template <int BN, int WM, int WN, int MODE>
+int launch_epi_split(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
+#ifdef CTRLV_ELEM_F16
+  if constexpr (BN == 320) {
+    const int e = pp_epi_of(d);
+    if constexpr (MODE == 0) {
+      switch (e) {
+        case 0:
+          if (d.A2) return launch_one<BN, WM, WN, MODE, false, 0, true, false, false, false, true>(d, persistent, stream);
+          return launch_one<BN, WM, WN, MODE, false, 0, false, false, false, false, true>(d, persistent, stream);
+        case 2: return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, false, true>(d, persistent, stream);
+        case 3: return launch_one<BN, WM, WN, MODE, false, 3, false, false, false, false, true>(d, persistent, stream);
+        case 6: return launch_one<BN, WM, WN, MODE, false, 6, false, false, false, false, true>(d, persistent, stream);
+        default: break;
+      }
+    } else if constexpr (MODE == 1) {
+      if (ctrlv_conv_halo_order(d)) {
+        if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, true, false, true>(d, persistent, stream);
+        if (e == 0) return launch_one<BN, WM, WN, MODE, false, 0, false, false, true, false, true>(d, persistent, stream);
+      } else {
+        if (e == 0) return launch_one<BN, WM, WN, MODE, false, 0, false, false, false, false, true>(d, persistent, stream);
+        if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, false, true>(d, persistent, stream);
+      }
+    } else {
+      if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, false, true>(d, persistent, stream);
+    }
+  }
+#endif
+  (void)persistent; (void)stream;
+  ctrlv_set_error("ctrlv_gemm: split trunk planes are not served by this ping-pong tile / epilogue (tile 6 of the fp16 "
+                  "element library; epilogues {bias}, {R1}, {R1,V}, {R1,R2})");
+  return CTRLV_E_BAD_ARG;
+}
+
 template <int BN, int WM, int WN, int MODE>
 int launch_epi(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
+  if (pp_split_io(d)) return launch_epi_split<BN, WM, WN, MODE>(d, persistent, stream);
   if constexpr (BN == 320 && MODE != 0) {
     // producer-side GroupNorm statistics (gemm_epilogue_lds, GNS): the conv1 / conv2 / temporal conv1 launches of a res
     // block, whose outputs go straight into a GroupNorm, and its temporal conv2 (AlphaBlender epilogue, {R1}) when the

@@ -24,13 +24,22 @@ __device__ __forceinline__ uint4 gn_load(const el_t* x, const el_t* x2, int c_sp
   const int ld = x2 != nullptr ? c_split : C;
   return *(const uint4*)(x + row * ld + c0);
 }
+// SPLIT inputs (ctrlv_gemm_desc.out_lo): the lo planes of x / x2, same shapes and pitches; a null plane reads as zeros.
+struct GnLo { const el_t* x; const el_t* x2; };
+// the lo-plane pointer that belongs to column block c0 (fixed per thread), or null; `first` = that half's first column
+__device__ __forceinline__ const el_t* gn_lo_plane(const GnLo& lo, const el_t* x2, int c_split, int C, int c0, int* ld, int* first) {
+  if (x2 != nullptr && c0 >= c_split) { *ld = C - c_split; *first = c_split; return lo.x2; }
+  *ld = x2 != nullptr ? c_split : C; *first = 0;
+  return lo.x;
+}
 
 // Pass 1.  Per (image, row-chunk): every lane accumulates, for its 8 channels, sum (x - K_c) and sum (x - K_c)^2 about a
 // per-CHANNEL pilot K_c = x[first row of the chunk][c] (one extra 16-byte load per lane, the same row for every lane of
 // a column, so all partial sums of a channel share their pilot): with |mean| >> std, E[x^2] - mean^2 would cancel in
 // fp32, the shifted sums do not.  32 threads then turn the channel sums of their group into the chunk's
 // (mean_c, M2_c) with Chan's pairwise update (equal counts per channel).
-__global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnShape s,
+template <bool SPLIT>
+__global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnLo lo, GnShape s,
                                 float* __restrict__ partials) {
   extern __shared__ float red[];  // [RPP][C][2] sums, then [C] pilots
   const int tid = threadIdx.x;
@@ -40,12 +49,15 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
+  int lo_ld = 0, lo_first = 0;
+  const el_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
   // (float2 arithmetic: v_pk_add_f32 / v_pk_fma_f32, two channels per instruction)
   f32x2_t sm2[4], sq2[4], piv2[4];
   {
     const uint4 pv = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r0, c0);
     float pf[8];
     unpack_elx8(pv, pf);
+    // (the pilot is the hi value of the first row: any value near the channel's data serves)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       piv2[e] = f32x2_t{pf[2 * e], pf[2 * e + 1]};
@@ -53,9 +65,10 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
       sq2[e] = f32x2_t{0.f, 0.f};
     }
   }
-  auto accum = [&](const uint4& v) {
+  auto accum = [&](const uint4& v, long row) {
     float f[8];
     unpack_elx8(v, f);
+    if (SPLIT && lop) add_lo8(f, *(const uint4*)(lop + row * lo_ld + (c0 - lo_first)));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const f32x2_t dl = f32x2_t{f[2 * e], f[2 * e + 1]} - piv2[e];
@@ -71,9 +84,9 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r + u * s.RPP, c0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) accum(v[u]);
+    for (int u = 0; u < 4; ++u) accum(v[u], (long)n * s.S + r + u * s.RPP);
   }
-  for (; r < r1; r += s.RPP) accum(gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0));
+  for (; r < r1; r += s.RPP) accum(gn_load(x, x2, s.c_split, s.C, (long)n * s.S + r, c0), (long)n * s.S + r);
   float* pil = red + (size_t)s.RPP * s.C * 2;     // per channel: [mean | M2] after stage A
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -155,7 +168,8 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(GnShape s, const floa
   }
 }
 
-__global__ void gn_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnShape s,
+template <bool SPLIT>
+__global__ void gn_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ x2, GnLo lo, GnShape s,
                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int silu, el_t* __restrict__ y) {
   const int tid = threadIdx.x;
@@ -174,9 +188,12 @@ __global__ void gn_apply_kernel(const el_t* __restrict__ x, const el_t* __restri
   }
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
+  int lo_ld = 0, lo_first = 0;
+  const el_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
   auto apply_row = [&](const uint4& v, long row) {
     float f[8];
     unpack_elx8(v, f);
+    if (SPLIT && lop) add_lo8(f, *(const uint4*)(lop + row * lo_ld + (c0 - lo_first)));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = f[e] * a[e] + b[e];
@@ -236,7 +253,7 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 template <int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, int M, int C,
+__global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, const el_t* __restrict__ xlo, int M, int C,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
                                                  el_t* __restrict__ y) {
@@ -279,6 +296,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, int
       if (cv < CV) {
         const uint4 v = cur[k];
         unpack_elx8(v, f[k]);
+        if (xlo) add_lo8(f[k], *(const uint4*)(xlo + m * C + cv * 8));
         if (vrow) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[k][e] += vrow[cv * 8 + e];
@@ -362,8 +380,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // contiguous bytes per row) and a wave normalises 64 / LPR rows at once: all lanes busy, log2(LPR)-step reductions, ~32
 // wave-instructions per row.  Same arithmetic as ln_kernel (two passes in registers: mean, then centred squares; the
 // optional row vector added first), different summation tree.  gamma / beta live in LDS (C floats each).
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x, int M, int C, int lpr_log2,
+template <int NCH, bool SPLIT>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x, const el_t* __restrict__ xlo, int M, int C, int lpr_log2,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
                                                       el_t* __restrict__ y) {
@@ -376,15 +394,22 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x
   const float inv_c = 1.0f / (float)C;
   const long step = (long)gridDim.x * 4 * RPW;
   long m = ((long)blockIdx.x * 4 + wid) * RPW + rsub;
-  uint4 nxt[NCH];
+  uint4 nxt[NCH], nxl[SPLIT ? NCH : 1];
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) nxt[k] = m < M ? *(const uint4*)(x + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < NCH; ++k) {
+    nxt[k] = m < M ? *(const uint4*)(x + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+    if (SPLIT) nxl[k] = m < M ? *(const uint4*)(xlo + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+  }
   for (; m - rsub < M; m += step) {                // (wave-uniform trip count: the shuffles below need every lane)
-    uint4 cur[NCH];
+    uint4 cur[NCH], cul[SPLIT ? NCH : 1];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       cur[k] = nxt[k];
       nxt[k] = (m + step < M) ? *(const uint4*)(x + (m + step) * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+      if (SPLIT) {
+        cul[k] = nxl[k];
+        nxl[k] = (m + step < M) ? *(const uint4*)(xlo + (m + step) * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+      }
     }
     const bool ok = m < M;
     const float* vrow = (V && ok) ? V + (long)((m / vdiv) % vmod) * ldv : nullptr;
@@ -393,6 +418,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       unpack_elx8(cur[k], f[k]);
+      if (SPLIT) add_lo8(f[k], cul[k]);
       if (vrow) {
         const float4 a = *(const float4*)(vrow + (j + k * LPR) * 8), b = *(const float4*)(vrow + (j + k * LPR) * 8 + 4);
         f[k][0] += a.x; f[k][1] += a.y; f[k][2] += a.z; f[k][3] += a.w;
@@ -448,14 +474,25 @@ extern "C" int ctrlv_groupnorm_chunks(int n_img, int S, int C, int imgs_per_stat
 
 extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split, int n_img, int S, int C,
                                      int imgs_per_stat, float eps, float* partials, ctrlv_stream_t stream) {
+  return ctrlv_groupnorm_stats_split(x, nullptr, x2, nullptr, c_split, n_img, S, C, imgs_per_stat, eps, partials, stream);
+}
+extern "C" int ctrlv_groupnorm_stats_split(const void* x, const void* x_lo, const void* x2, const void* x2_lo, int c_split,
+                                           int n_img, int S, int C, int imgs_per_stat, float eps, float* partials,
+                                           ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials, "groupnorm_stats: null pointer");
+  CTRLV_CHECK_ARG(x2 || !x2_lo, "groupnorm_stats: x2_lo without x2");
+  const GnLo lo{(const el_t*)x_lo, (const el_t*)x2_lo};
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
   const int nt = s.CV * s.RPP;
   const size_t smem = ((size_t)s.RPP * C * 2 + C) * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
-                     (const el_t*)x, (const el_t*)x2, s, partials);
+  if (x_lo || x2_lo)
+    hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
+                       (const el_t*)x, (const el_t*)x2, lo, s, partials);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), smem, (hipStream_t)stream,
+                       (const el_t*)x, (const el_t*)x2, lo, s, partials);
   CTRLV_LAUNCH_CHECK();
   // (mean, rstd) per (statistics row, group), behind the chunk partials
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img / imgs_per_stat, 32 / kFinGroups), dim3(1024), 0, (hipStream_t)stream, s,
@@ -467,13 +504,25 @@ extern "C" int ctrlv_groupnorm_stats(const void* x, const void* x2, int c_split,
 extern "C" int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img, int S, int C,
                                      int imgs_per_stat, const float* partials, const float* gamma, const float* beta,
                                      int silu, void* y, ctrlv_stream_t stream) {
+  return ctrlv_groupnorm_apply_split(x, nullptr, x2, nullptr, c_split, n_img, S, C, imgs_per_stat, partials, gamma, beta, silu,
+                                     y, stream);
+}
+extern "C" int ctrlv_groupnorm_apply_split(const void* x, const void* x_lo, const void* x2, const void* x2_lo, int c_split,
+                                           int n_img, int S, int C, int imgs_per_stat, const float* partials,
+                                           const float* gamma, const float* beta, int silu, void* y, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_apply: null pointer");
+  CTRLV_CHECK_ARG(x2 || !x2_lo, "groupnorm_apply: x2_lo without x2");
+  const GnLo lo{(const el_t*)x_lo, (const el_t*)x2_lo};
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
   const int nt = s.CV * s.RPP;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
-                     (const el_t*)x2, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (el_t*)y);
+  if (x_lo || x2_lo)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                       (const el_t*)x2, lo, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (el_t*)y);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                       (const el_t*)x2, lo, s, partials + (size_t)n_img * s.n_chunks * 64, gamma, beta, silu, (el_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -496,14 +545,18 @@ extern "C" int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, in
                      partials, eps, stats);
   CTRLV_LAUNCH_CHECK();
   const int nt = s.CV * s.RPP;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
-                     (const el_t*)nullptr, s, stats, gamma, beta, silu, (el_t*)y);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                     (const el_t*)nullptr, GnLo{nullptr, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
 
 extern "C" int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps,
                                const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream) {
+  return ctrlv_layernorm_split(x, nullptr, M, C, gamma, beta, eps, V, vdiv, vmod, ldv, y, stream);
+}
+extern "C" int ctrlv_layernorm_split(const void* x, const void* x_lo, int M, int C, const float* gamma, const float* beta,
+                                     float eps, const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
   CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: C=%d must be a multiple of 8, <= 2048", C);
   if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm: bad row-vector table");
@@ -516,15 +569,19 @@ extern "C" int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, 
     const int lg = lpr == 8 ? 3 : (lpr == 16 ? 4 : 5), rpb = 4 * (64 >> lg);
     long nb = ((long)M + rpb - 1) / rpb;
     if (nb > 256 * 8) nb = 256 * 8;
-    hipLaunchKernelGGL(ln_rows_kernel<5>, dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x, M, C, lg,
-                       gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
+    if (x_lo)
+      hipLaunchKernelGGL((ln_rows_kernel<5, true>), dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x,
+                         (const el_t*)x_lo, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
+    else
+      hipLaunchKernelGGL((ln_rows_kernel<5, false>), dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x,
+                         (const el_t*)nullptr, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
   long blocks = ((long)M + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
 #define LN_LAUNCH(NV)                                                                                             \
-  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, M, C, gamma, beta, \
+  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, (const el_t*)x_lo, M, C, gamma, beta, \
                      eps, V, vdiv, vmod, ldv, (el_t*)y)
   switch (nv) {
     case 1: LN_LAUNCH(1); break;

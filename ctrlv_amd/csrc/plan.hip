@@ -142,6 +142,7 @@ struct ctrlv_plan {
   ctrlv_model_config cfg;
   int device = 0;
   bool loaded = false;
+  int trunk_mode = 0;         // 0: plain residual trunk, 1: SPLIT hi + lo planes (ctrlv_plan_set_trunk_mode)
   std::vector<DownBlock> down;
   ResBlock mid_r0, mid_r1;
   Transformer mid_attn;
@@ -428,6 +429,13 @@ int load_tr(Loader& L, Transformer& t, int cross_dim) {
 }
 
 // ------------------------------------------------------------------------------------------------ execution context
+// A tensor of the RESIDUAL TRUNK (block inputs / outputs, the tensors every branch result is added back into).  In trunk
+// mode 1 it carries a second plane: value = hi + lo (include/ctrlv_hip.h, ctrlv_gemm_desc.out_lo).  GEMM A operands and
+// the ABI's tensors read `hi`; residual operands (R1 / R2) and norm inputs read both.
+struct Trk {
+  el_t* hi = nullptr;
+  el_t* lo = nullptr;
+};
 struct Ctx {
   ctrlv_plan* p;
   hipStream_t st;
@@ -452,6 +460,12 @@ struct Ctx {
     return base + o;
   }
   el_t* rows(long m, int c) { return (el_t*)alloc((size_t)m * c * 2); }
+  Trk trunk(long m, int c) {          // a trunk tensor: one plane, or hi + lo in trunk mode 1
+    Trk t;
+    t.hi = rows(m, c);
+    if (p->trunk_mode == 1) t.lo = rows(m, c);
+    return t;
+  }
   size_t mark() const { return off; }
   void release(size_t m) { off = m; }
 };
@@ -484,8 +498,13 @@ void gemm_work(const ctrlv_gemm_desc& d, int* fam, double* flops, double* bytes)
   const double K = (double)d.taps * d.Cin;
   *flops = 2.0 * d.M * n_alg * K;
   *bytes = (double)d.M * d.Cin * 2 + (double)d.M * n_out * ((d.out_f32 & 1) ? 4 : 2) + (double)d.N * K * 2 +
-           (d.R1 ? (double)d.M * n_out * 2 : 0) + (d.R2 ? (double)d.M * n_out * 2 : 0);
+           (d.R1 ? (double)d.M * n_out * 2 : 0) + (d.R2 ? (double)d.M * n_out * 2 : 0) +
+           ((d.R1_lo ? 1 : 0) + (d.R2_lo ? 1 : 0) + (d.out_lo ? 1 : 0)) * (double)d.M * n_out * 2;
 }
+// residual operand / output of a GEMM from a trunk tensor
+inline void set_r1(ctrlv_gemm_desc& d, const Trk& t, int ld) { d.R1 = t.hi; d.R1_lo = t.lo; d.ldr1 = ld; }
+inline void set_r2(ctrlv_gemm_desc& d, const Trk& t, int ld) { d.R2 = t.hi; d.R2_lo = t.lo; d.ldr2 = ld; }
+inline void set_out(ctrlv_gemm_desc& d, const Trk& t) { d.out = t.hi; d.out_lo = t.lo; }
 
 ctrlv_gemm_desc gd(const void* A, int lda, const Linear& w, void* out, int ldo, int M, int N, int cin, int n_store) {
   ctrlv_gemm_desc d;
@@ -515,7 +534,7 @@ int gemm(Ctx& c, const ctrlv_gemm_desc& d0) {
   c.release(mk);
   return rc;
 }
-int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
+int groupnorm(Ctx& c, const Trk& x, const Trk& x2, int c_split, int n_img, int S, int C, int ips, const Norm& nm,
               float eps, int silu, el_t* y) {
   const int chunks = ctrlv_groupnorm_chunks(n_img, S, C, ips);
   if (chunks < 0) return chunks;
@@ -525,8 +544,9 @@ int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int
   if (!c.dry) {
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * n_img * (double)S * C, n_img * S, C);   // algorithmic: 1 read + 1 write
-    rc = ctrlv_groupnorm_stats(x, x2, c_split, n_img, S, C, ips, eps, part, c.st);
-    if (rc == CTRLV_OK) rc = ctrlv_groupnorm_apply(x, x2, c_split, n_img, S, C, ips, part, nm.g, nm.b, silu, y, c.st);
+    rc = ctrlv_groupnorm_stats_split(x.hi, x.lo, x2.hi, x2.lo, c_split, n_img, S, C, ips, eps, part, c.st);
+    if (rc == CTRLV_OK)
+      rc = ctrlv_groupnorm_apply_split(x.hi, x.lo, x2.hi, x2.lo, c_split, n_img, S, C, ips, part, nm.g, nm.b, silu, y, c.st);
   }
   c.release(m);          // stream order keeps the scratch alive until the apply pass has read it
   return rc;
@@ -536,9 +556,10 @@ int groupnorm(Ctx& c, const el_t* x, const el_t* x2, int c_split, int n_img, int
 // finalize + apply -- one read and one write of the tensor instead of two reads.  The scratch is sized from the shape alone
 // (the measuring walk has no operand pointers to ask the predicate with).
 int gemm_groupnorm(Ctx& c, ctrlv_gemm_desc d, int n_img, int S, int C, int ips, const Norm& nm, float eps, int silu, el_t* y) {
+  const Trk dout{(el_t*)d.out, (el_t*)d.out_lo};
   if (S % 64 != 0) {
     TRY(gemm(c, d));
-    return groupnorm(c, (const el_t*)d.out, nullptr, 0, n_img, S, C, ips, nm, eps, silu, y);
+    return groupnorm(c, dout, Trk{}, 0, n_img, S, C, ips, nm, eps, silu, y);
   }
   const size_t m = c.mark();
   float* part = (float*)c.alloc(((size_t)n_img * (S / 64) + n_img / ips) * 64 * 4);
@@ -555,17 +576,17 @@ int gemm_groupnorm(Ctx& c, ctrlv_gemm_desc d, int n_img, int S, int C, int ips, 
   }
   c.release(m);
   TRY(gemm(c, d));
-  return groupnorm(c, (const el_t*)d.out, nullptr, 0, n_img, S, C, ips, nm, eps, silu, y);
+  return groupnorm(c, dout, Trk{}, 0, n_img, S, C, ips, nm, eps, silu, y);
 }
-int layernorm(Ctx& c, const el_t* x, int M, int C, const Norm& nm, el_t* y, const float* V = nullptr, int vdiv = 1,
+int layernorm(Ctx& c, const Trk& x, int M, int C, const Norm& nm, el_t* y, const float* V = nullptr, int vdiv = 1,
               int vmod = 1 << 30, int ldv = 0) {
   if (c.dry) return CTRLV_OK;
   ProfScope ps(c, CTRLV_FAM_LAYERNORM, 0.0, 2.0 * 2 * (double)M * C, M, C);
-  return ctrlv_layernorm(x, M, C, nm.g, nm.b, 1e-5f, V, vdiv, vmod, ldv, y, c.st);
+  return ctrlv_layernorm_split(x.hi, x.lo, M, C, nm.g, nm.b, 1e-5f, V, vdiv, vmod, ldv, y, c.st);
 }
 
 // ---- SpatioTemporalResBlock (blocks.py::SpatioTemporalResBlock.run)
-int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, int H, int W, el_t** out_,
+int run_res(Ctx& c, const ResBlock& r, const Trk& x, const Trk& x2, int c1, int H, int W, Trk* out_,
             bool feeds_norm = false) {
   const int N = c.B * c.F, S = H * W, F = c.F;
   const long M = (long)N * S;
@@ -575,11 +596,11 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
     const size_t need = ((size_t)N * (S / 64) + N) * 64;
     if (c.gn_cross_floats < need) { c.gn_cross = (float*)c.alloc(need * 4); c.gn_cross_floats = need; }
   }
-  el_t* out = c.rows(M, cout);
+  const Trk out = c.trunk(M, cout);
   const size_t mk = c.mark();
-  const int lda_x = x2 ? c1 : cin;
+  const int lda_x = x2.hi ? c1 : cin;
   el_t* xn = c.rows(M, cin);
-  TRY(groupnorm(c, x, x2, x2 ? c1 : 0, N, S, cin, 1, r.n1, r.eps, 1, xn));
+  TRY(groupnorm(c, x, x2, x2.hi ? c1 : 0, N, S, cin, 1, r.n1, r.eps, 1, xn));
   el_t* h = c.rows(M, cout);
   el_t* hn = nullptr;
   {
@@ -589,21 +610,23 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
     hn = c.rows(M, cout);
     TRY(gemm_groupnorm(c, d, N, S, cout, 1, r.n2, r.eps, 1, hn));
   }
-  const el_t* res = x;
+  Trk res = x;
   int ldres = cin;
   if (r.has_sc) {
-    el_t* rs = c.rows(M, cout);
-    ctrlv_gemm_desc d = gd(x, lda_x, r.sc, rs, cout, (int)M, cout, cin, cout);
-    if (x2) { d.A2 = x2; d.lda2 = cin - c1; d.c_split = c1; }
+    const Trk rs = c.trunk(M, cout);
+    ctrlv_gemm_desc d = gd(x.hi, lda_x, r.sc, rs.hi, cout, (int)M, cout, cin, cout);
+    set_out(d, rs);
+    if (x2.hi) { d.A2 = x2.hi; d.lda2 = cin - c1; d.c_split = c1; }
     TRY(gemm(c, d));
     res = rs;
     ldres = cout;
   }
-  el_t* xs = c.rows(M, cout);
+  const Trk xs = c.trunk(M, cout);
   {
-    ctrlv_gemm_desc d = gd(hn, cout, r.c2, xs, cout, (int)M, cout, cout, cout);
+    ctrlv_gemm_desc d = gd(hn, cout, r.c2, xs.hi, cout, (int)M, cout, cout, cout);
     d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = H; d.Wo = W; d.stride = 1;
-    d.R1 = res; d.ldr1 = ldres;
+    set_out(d, xs);
+    set_r1(d, res, ldres);
     TRY(gemm_groupnorm(c, d, N, S, cout, F, r.tn1, r.eps, 1, hn));
   }
   {
@@ -613,9 +636,11 @@ int run_res(Ctx& c, const ResBlock& r, const el_t* x, const el_t* x2, int c1, in
     TRY(gemm_groupnorm(c, d, N, S, cout, F, r.tn2, r.eps, 1, hn));
   }
   {   // AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
-    ctrlv_gemm_desc d = gd(hn, cout, r.tc2, out, cout, (int)M, cout, cout, cout);
+    ctrlv_gemm_desc d = gd(hn, cout, r.tc2, out.hi, cout, (int)M, cout, cout, cout);
     d.taps = 3; d.mode = 2; d.F = F; d.S = S;
-    d.s_acc = (float)(1.0 - r.alpha); d.R1 = xs; d.ldr1 = cout;
+    d.s_acc = (float)(1.0 - r.alpha);
+    set_out(d, out);
+    set_r1(d, xs, cout);
     if (feeds_norm && S % 64 == 0 && !c.dry && ctrlv_gemm_gn_partials_serves(&d)) {
       d.gn_partials = c.gn_cross;       // the transformer behind this block opens with a GroupNorm of `out`
       c.gn_cross_valid = true;
@@ -685,7 +710,8 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
-                 (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0)), outd.M, 320, 320, 0x100);
+                 (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0) + (outd.R1_lo ? 1 : 0) + (outd.R2_lo ? 1 : 0) +
+                                             (outd.out_lo ? 1 : 0)), outd.M, 320, 320, 0x100);
     return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, f.w2f, &outd, c.st);
   }
   if (*u == nullptr) *u = c.rows(proj.M, 4 * C);
@@ -702,6 +728,9 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
     o.out = (el_t*)outd.out + (long)m0 * outd.ldo;
     if (outd.R1) o.R1 = (const el_t*)outd.R1 + (long)m0 * outd.ldr1;
     if (outd.R2) o.R2 = (const el_t*)outd.R2 + (long)m0 * outd.ldr2;
+    if (outd.R1_lo) o.R1_lo = (const el_t*)outd.R1_lo + (long)m0 * outd.ldr1;
+    if (outd.R2_lo) o.R2_lo = (const el_t*)outd.R2_lo + (long)m0 * outd.ldr2;
+    if (outd.out_lo) o.out_lo = (el_t*)outd.out_lo + (long)m0 * outd.ldo;
     TRY(gemm(c, p));
     TRY(gemm(c, o));
   }
@@ -712,26 +741,26 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
 // prologue (ctrlv_ff_fused_ln: one launch and one write + read of the activation less).  Measured equal in the model
 // (224.2 vs 224.2 and 230.3 vs 230.4 ms per step, three alternations each: the LayerNorm family drops 7.9 -> 5.3 ms, the
 // fused kernel's per-tile prologue takes it back), so the default keeps ctrlv_layernorm in front of the fused kernel.
-int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const el_t* xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
+int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const Trk& xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
           el_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C, el_t** u) {
   static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
   static const bool fold = [] { const char* e = getenv("CTRLV_FF_LN"); return e && atoi(e) != 0; }();
-  if (fuse && fold && f.w1f && ctrlv_ff_fused_serves(&outd, C)) {
+  if (fuse && fold && f.w1f && !xraw.lo && ctrlv_ff_fused_serves(&outd, C)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
                  (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0)), outd.M, 320, 320, 0x300);
-    return ctrlv_ff_fused_ln(xraw, C, nm.g, nm.b, 1e-5f, lnV, lnvdiv, lnvmod, lnldv, f.w1f, f.w2f, &outd, c.st);
+    return ctrlv_ff_fused_ln(xraw.hi, C, nm.g, nm.b, 1e-5f, lnV, lnvdiv, lnvmod, lnldv, f.w1f, f.w2f, &outd, c.st);
   }
   TRY(layernorm(c, xraw, proj.M, C, nm, tt, lnV, lnvdiv, lnvmod, lnldv));
   return ff_pair(c, f, proj, outd, C, u);
 }
 
 // ---- TransformerSpatioTemporalModel (blocks.py::TransformerSpatioTemporalModel.run)
-int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out_) {
+int run_tr(Ctx& c, const Transformer& t, const Trk& x, int H, int W, Trk* out_) {
   const int B = c.B, F = c.F, C = t.C, N = B * F, S = H * W;
   const long M = (long)N * S;
-  el_t* out = c.rows(M, C);
+  const Trk out = c.trunk(M, C);
   const size_t mk = c.mark();
   const float* emb = t.frame_emb;
   if (F != c.p->cfg.num_frames || emb == nullptr) {
@@ -743,12 +772,16 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
   if (c.gn_cross_valid && !c.dry) {     // statistics from the res block's last GEMM (run_res, feeds_norm)
     c.gn_cross_valid = false;
     ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * N * (double)S * C, N * S, C, 1);
-    TRY(ctrlv_groupnorm_from_partials(x, N, S, C, 1, 1e-6f, c.gn_cross, t.gn.g, t.gn.b, 0, tt, c.st));
+    TRY(ctrlv_groupnorm_from_partials(x.hi, N, S, C, 1, 1e-6f, c.gn_cross, t.gn.g, t.gn.b, 0, tt, c.st));
   } else {
-    TRY(groupnorm(c, x, nullptr, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
+    TRY(groupnorm(c, x, Trk{}, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
   }
-  el_t* h0 = c.rows(M, C);
-  TRY(gemm(c, gd(tt, C, t.pin, h0, C, (int)M, C, C, C)));
+  const Trk h0 = c.trunk(M, C);
+  {
+    ctrlv_gemm_desc d = gd(tt, C, t.pin, h0.hi, C, (int)M, C, C, C);
+    set_out(d, h0);
+    TRY(gemm(c, d));
+  }
   // ---- spatial BasicTransformerBlock
   TRY(layernorm(c, h0, (int)M, C, t.s_ln1, tt));
   el_t* qkv = c.rows(M, 3 * C);
@@ -762,29 +795,34 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
     ProfScope ps(c, CTRLV_FAM_ATTENTION_SPATIAL, 4.0 * N * (C / 64) * (double)S * S * 64, 2.0 * 4 * N * (double)S * C, N, S, C);
     TRY(ctrlv_attention_spatial_prescaled(qkv, a, N, S, C, c.st));
   }
-  el_t* h1 = c.rows(M, C);
+  const Trk h1 = c.trunk(M, C);
   {   // attn2 with one key == to_out(to_v(ehs[b])) for every query: a per-clip row vector
-    ctrlv_gemm_desc d = gd(a, C, t.s_o, h1, C, (int)M, C, C, C);
-    d.R1 = h0; d.ldr1 = C;
+    ctrlv_gemm_desc d = gd(a, C, t.s_o, h1.hi, C, (int)M, C, C, C);
+    set_out(d, h1);
+    set_r1(d, h0, C);
     d.V = c.xattn + t.xattn_off[0]; d.ldv = c.ldx; d.vmode = 1; d.vdiv = F * S;
     TRY(gemm(c, d));
   }
   el_t* u = nullptr;  // 4C-wide GEGLU output of the two-launch path: allocated by ff_pair on first need
-  el_t* h2 = h0;      // h0 is dead from here on
+  const Trk h2 = h0;  // h0 is dead from here on
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.s_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
-    ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2, C, (int)M, C, 4 * C, C);
-    d.R1 = h1; d.ldr1 = C; d.S = S;       // (S: rows per image, the split plan's shape key for a mode-0 launch)
+    ctrlv_gemm_desc d = gd(u, 4 * C, t.s_ff.out, h2.hi, C, (int)M, C, 4 * C, C);
+    set_out(d, h2);
+    set_r1(d, h1, C);
+    d.S = S;                              // (S: rows per image, the split plan's shape key for a mode-0 launch)
     TRY(ln_ff(c, t.s_ff, t.s_ln3, h1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   // ---- temporal block on tokens (b, s) x frames; rows stay ordered (b, f, s)
-  el_t* g0 = h1;      // h1 is dead
+  const Trk g0 = h1;  // h1 is dead
   {
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ffin.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
-    ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0, C, (int)M, C, 4 * C, C);
-    d.R1 = h2; d.ldr1 = C; d.S = S;
+    ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ffin.out, g0.hi, C, (int)M, C, 4 * C, C);
+    set_out(d, g0);
+    set_r1(d, h2, C);
+    d.S = S;
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
     TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C, &u));
   }
@@ -795,27 +833,31 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
                  F, C);
     TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
   }
-  el_t* g1 = c.rows(M, C);
+  const Trk g1 = c.trunk(M, C);
   {
-    ctrlv_gemm_desc d = gd(a, C, t.t_o, g1, C, (int)M, C, C, C);
-    d.R1 = g0; d.ldr1 = C;
+    ctrlv_gemm_desc d = gd(a, C, t.t_o, g1.hi, C, (int)M, C, C, C);
+    set_out(d, g1);
+    set_r1(d, g0, C);
     d.V = c.xattn + t.xattn_off[1]; d.ldv = c.ldx; d.vdiv = F * S;
     if (c.quirk && B > 1) { d.vmode = 2; d.vS = S; d.vmod = B; }   // diffusers 0.27.2: context rows (s, b), tokens (b, s)
     else d.vmode = 1;
     TRY(gemm(c, d));
   }
-  el_t* h3 = g0;
+  const Trk h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
     ctrlv_gemm_desc dp = gd(tt, C, t.t_ff.proj, u, 4 * C, (int)M, 8 * C, C, 4 * C);
     dp.geglu = 1;
-    ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3, C, (int)M, C, 4 * C, C);
-    d.s_acc = (float)(1.0 - t.alpha); d.R1 = g1; d.ldr1 = C; d.s1 = (float)(1.0 - t.alpha); d.R2 = h2; d.ldr2 = C;
-    d.s2 = (float)t.alpha; d.S = S;
+    ctrlv_gemm_desc d = gd(u, 4 * C, t.t_ff.out, h3.hi, C, (int)M, C, 4 * C, C);
+    set_out(d, h3);
+    d.s_acc = (float)(1.0 - t.alpha); d.s1 = (float)(1.0 - t.alpha); d.s2 = (float)t.alpha; d.S = S;
+    set_r1(d, g1, C);
+    set_r2(d, h2, C);
     TRY(ln_ff(c, t.t_ff, t.t_ln3, g1, nullptr, 1, 1 << 30, 0, tt, dp, d, C, &u));
   }
   {
-    ctrlv_gemm_desc d = gd(h3, C, t.pout, out, C, (int)M, C, C, C);
-    d.R1 = x; d.ldr1 = C;
+    ctrlv_gemm_desc d = gd(h3.hi, C, t.pout, out.hi, C, (int)M, C, C, C);
+    set_out(d, out);
+    set_r1(d, x, C);
     TRY(gemm(c, d));
   }
   c.release(mk);
@@ -823,19 +865,20 @@ int run_tr(Ctx& c, const Transformer& t, const el_t* x, int H, int W, el_t** out
   return CTRLV_OK;
 }
 
-int run_resample(Ctx& c, const Resample& r, const el_t* x, int H, int W, bool up, el_t** out_, int* Ho_, int* Wo_) {
+int run_resample(Ctx& c, const Resample& r, const Trk& x, int H, int W, bool up, Trk* out_, int* Ho_, int* Wo_) {
   const int N = c.B * c.F;
   const int Ho = up ? 2 * H : (H + 2 - 3) / 2 + 1, Wo = up ? 2 * W : (W + 2 - 3) / 2 + 1;
   const long M = (long)N * Ho * Wo;
-  el_t* out = c.rows(M, r.C);
-  ctrlv_gemm_desc d = gd(x, r.C, r.conv, out, r.C, (int)M, r.C, r.C, r.C);
+  const Trk out = c.trunk(M, r.C);
+  ctrlv_gemm_desc d = gd(x.hi, r.C, r.conv, out.hi, r.C, (int)M, r.C, r.C, r.C);
+  set_out(d, out);
   d.taps = 9; d.mode = 1; d.H = H; d.Wd = W; d.Ho = Ho; d.Wo = Wo; d.stride = up ? 1 : 2; d.up = up ? 1 : 0;
   TRY(gemm(c, d));
   *out_ = out; *Ho_ = Ho; *Wo_ = Wo;
   return CTRLV_OK;
 }
 
-struct Tap { el_t* x; int H, W, C; };
+struct Tap { Trk x; int H, W, C; };
 
 // ---- embeddings + per-clip row-vector tables (encoder.py::_context)
 int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* ehs, const float* ids32, int n_ids) {
@@ -879,15 +922,18 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
       TRY(ctrlv_timestep_embedding(ids32, B * n_ids, add_dim, ae, c.st));
     }
   }
-  { ctrlv_gemm_desc d = gd(te, kt, p->te1, h, ted, B, ted, kt, ted); d.act = 1; TRY(gemm(c, d)); }
-  TRY(gemm(c, gd(h, ted, p->te2, emb_t, ted, B, ted, ted, ted)));
-  { ctrlv_gemm_desc d = gd(ae, ka, p->ae1, h, ted, B, ted, ka, ted); d.act = 1; TRY(gemm(c, d)); }
+  // (tile 11: per-clip rows -- one kernel for these launches whatever B is, so a clip's conditioning vectors have the same
+  //  bits alone and in any batch: csrc/gemm.hip gemv_small_kernel)
+  constexpr int kClipRows = 11;
+  { ctrlv_gemm_desc d = gd(te, kt, p->te1, h, ted, B, ted, kt, ted); d.act = 1; d.tile = kClipRows; TRY(gemm(c, d)); }
+  { ctrlv_gemm_desc d = gd(h, ted, p->te2, emb_t, ted, B, ted, ted, ted); d.tile = kClipRows; TRY(gemm(c, d)); }
+  { ctrlv_gemm_desc d = gd(ae, ka, p->ae1, h, ted, B, ted, ka, ted); d.act = 1; d.tile = kClipRows; TRY(gemm(c, d)); }
   {   // silu(emb + aug_emb): the SiLU in front of every time_emb_proj
     ctrlv_gemm_desc d = gd(h, ted, p->ae2, emb_s, ted, B, ted, ted, ted);
-    d.R1 = emb_t; d.ldr1 = ted; d.act = 1;
+    d.R1 = emb_t; d.ldr1 = ted; d.act = 1; d.tile = kClipRows;
     TRY(gemm(c, d));
   }
-  { ctrlv_gemm_desc d = gd(emb_s, ted, p->temb, c.temb, c.ldtemb, B, p->temb.n, ted, c.ldtemb); d.out_f32 = 1; TRY(gemm(c, d)); }
+  { ctrlv_gemm_desc d = gd(emb_s, ted, p->temb, c.temb, c.ldtemb, B, p->temb.n, ted, c.ldtemb); d.out_f32 = 1; d.tile = kClipRows; TRY(gemm(c, d)); }
   if (p->xattn_n) {
     const int dc = cfg.cross_attention_dim, nx = p->xv.n;
     el_t* e = c.rows(B, kx);
@@ -899,10 +945,10 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
       if (kx != dc) CTRLV_HIP_TRY(hipMemsetAsync(e, 0, (size_t)B * kx * 2, c.st));
       TRY(ctrlv_nchw_to_rows(ehs, dtype, B, dc, 1, e, kx, 0, c.st));      // (B, 1, dc) any dtype -> bf16 rows [B, kx]
     }
-    TRY(gemm(c, gd(e, kx, p->xv, v_all, nx, B, nx, kx, nx)));
+    { ctrlv_gemm_desc d = gd(e, kx, p->xv, v_all, nx, B, nx, kx, nx); d.tile = kClipRows; TRY(gemm(c, d)); }
     for (const CrossOut& xo : p->xouts) {
       ctrlv_gemm_desc d = gd(v_all + xo.off, nx, xo.to_out, c.xattn + xo.off, nx, B, xo.c, xo.c, xo.c);
-      d.out_f32 = 1;
+      d.out_f32 = 1; d.tile = kClipRows;
       TRY(gemm(c, d));
     }
   }
@@ -911,13 +957,13 @@ int run_context(Ctx& c, int dtype, const float* timestep, int n_t, const void* e
 }
 
 // conv_in (+ control_conv_in) as ONE im2col GEMM over the [conv_in channels | control channels | pad] slots
-int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h, int w, el_t** out_) {
+int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h, int w, Trk* out_) {
   ctrlv_plan* p = c.p;
   const int N = c.B * c.F, cin = p->cfg.in_channels, c0 = p->cfg.block_out_channels[0];
   const long M = (long)N * h * w;
   el_t* x16 = c.rows(M, p->cin_cp);
   el_t* col = c.rows(M, p->cin_kp);
-  el_t* x = c.rows(M, c0);
+  const Trk x = c.trunk(M, c0);
   if (!c.dry) {
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     CTRLV_HIP_TRY(hipMemsetAsync(x16, 0, (size_t)M * p->cin_cp * 2, c.st));
@@ -925,34 +971,38 @@ int run_input(Ctx& c, int dtype, const void* sample, const void* control, int h,
     if (control) TRY(ctrlv_nchw_to_rows(control, dtype, N, cin / 2, h * w, x16, p->cin_cp, cin, c.st));
     TRY(ctrlv_im2col3x3(x16, N, h, w, p->cin_cp, col, p->cin_kp, c.st));
   }
-  TRY(gemm(c, gd(col, p->cin_kp, p->cin, x, c0, (int)M, p->cin.n, p->cin_kp, c0)));
+  {
+    ctrlv_gemm_desc d = gd(col, p->cin_kp, p->cin, x.hi, c0, (int)M, p->cin.n, p->cin_kp, c0);
+    set_out(d, x);
+    TRY(gemm(c, d));
+  }
   *out_ = x;
   return CTRLV_OK;
 }
 
-int run_down_mid(Ctx& c, el_t* x, int h, int w, std::vector<Tap>& taps, el_t** mid_, int* H_, int* W_) {
+int run_down_mid(Ctx& c, Trk x, int h, int w, std::vector<Tap>& taps, Trk* mid_, int* H_, int* W_) {
   ctrlv_plan* p = c.p;
   int H = h, W = w;
   taps.push_back({x, H, W, p->cfg.block_out_channels[0]});
   for (auto& b : p->down) {
     for (size_t j = 0; j < b.res.size(); ++j) {
-      el_t* y;
-      TRY(run_res(c, b.res[j], x, nullptr, 0, H, W, &y, !b.attn.empty()));
+      Trk y;
+      TRY(run_res(c, b.res[j], x, Trk{}, 0, H, W, &y, !b.attn.empty()));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
       taps.push_back({x, H, W, b.res[j].cout});
     }
     if (b.down.present) {
-      el_t* y; int Ho, Wo;
+      Trk y; int Ho, Wo;
       TRY(run_resample(c, b.down, x, H, W, false, &y, &Ho, &Wo));
       x = y; H = Ho; W = Wo;
       taps.push_back({x, H, W, b.down.C});
     }
   }
-  el_t* y;
-  TRY(run_res(c, p->mid_r0, x, nullptr, 0, H, W, &y, true)); x = y;
+  Trk y;
+  TRY(run_res(c, p->mid_r0, x, Trk{}, 0, H, W, &y, true)); x = y;
   TRY(run_tr(c, p->mid_attn, x, H, W, &y)); x = y;
-  TRY(run_res(c, p->mid_r1, x, nullptr, 0, H, W, &y)); x = y;
+  TRY(run_res(c, p->mid_r1, x, Trk{}, 0, H, W, &y)); x = y;
   *mid_ = x; *H_ = H; *W_ = W;
   return CTRLV_OK;
 }
@@ -971,11 +1021,16 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
                  int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  el_t* x;
+  Trk x;
   TRY(run_input(c, dtype, sample, nullptr, h, w, &x));
   std::vector<Tap> taps;
   int H, W;
   TRY(run_down_mid(c, x, h, w, taps, &x, &H, &W));
+  // the ControlNet residual add on a trunk tensor: in place; in trunk mode 1 the sum is split again
+  auto add_res = [&](const Trk& t, const void* r, size_t n) -> int {
+    if (t.lo) return ctrlv_axpby_split(t.hi, t.lo, r, 1.0f, 1.0f, t.hi, t.lo, n, c.st);
+    return ctrlv_axpby(t.hi, r, 1.0f, 1.0f, t.hi, n, c.st);
+  };
   if (down_res && mid_res) {        // unet_spatio_temporal_condition.py:61,119-127,136-137
     if (!c.dry) {
       if (res_event) CTRLV_HIP_TRY(hipStreamWaitEvent(c.st, (hipEvent_t)res_event, 0));
@@ -983,24 +1038,24 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
         CTRLV_CHECK_ARG(down_res[i] != nullptr, "unet_forward: down_res[%zu] is null", i);
         const size_t n = (size_t)N * taps[i].H * taps[i].W * taps[i].C;
         ProfScope ps(c, CTRLV_FAM_RESIDUAL_ADD, 0.0, 2.0 * 3 * (double)n, (int)(n / taps[i].C), taps[i].C);
-        TRY(ctrlv_axpby(taps[i].x, down_res[i], 1.0f, 1.0f, taps[i].x, n, c.st));
+        TRY(add_res(taps[i].x, down_res[i], n));
       }
       const size_t nm_ = (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1];
       ProfScope ps(c, CTRLV_FAM_RESIDUAL_ADD, 0.0, 2.0 * 3 * (double)nm_, N * H * W, p->cfg.block_out_channels[p->cfg.n_blocks - 1]);
-      TRY(ctrlv_axpby(x, mid_res, 1.0f, 1.0f, x, nm_, c.st));
+      TRY(add_res(x, mid_res, nm_));
     }
   }
   for (auto& b : p->up) {           // :140-158 -- torch.cat([hidden, skip], dim=1) is read in place (x | x2)
     for (size_t j = 0; j < b.res.size(); ++j) {
       const Tap skip = taps.back();
       taps.pop_back();
-      el_t* y;
+      Trk y;
       TRY(run_res(c, b.res[j], x, skip.x, b.res[j].cin - skip.C, H, W, &y, !b.attn.empty()));
       x = y;
       if (!b.attn.empty()) { TRY(run_tr(c, b.attn[j], x, H, W, &y)); x = y; }
     }
     if (b.up.present) {
-      el_t* y; int Ho, Wo;
+      Trk y; int Ho, Wo;
       TRY(run_resample(c, b.up, x, H, W, true, &y, &Ho, &Wo));
       x = y; H = Ho; W = Wo;
     }
@@ -1008,7 +1063,7 @@ int unet_forward(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, const flo
   const int c0 = p->cfg.block_out_channels[0], co = p->cfg.out_channels, co_p = pad_to(co, 4);
   const long M = (long)N * H * W;
   el_t* xn = c.rows(M, c0);
-  TRY(groupnorm(c, x, nullptr, 0, N, H * W, c0, 1, p->gno, 1e-5f, 1, xn));       // :161-163
+  TRY(groupnorm(c, x, Trk{}, 0, N, H * W, c0, 1, p->gno, 1e-5f, 1, xn));         // :161-163
   el_t* y = c.rows(M, co_p);
   {
     ctrlv_gemm_desc d = gd(xn, c0, p->cout, y, co_p, (int)M, p->cout.n, c0, co_p);
@@ -1024,7 +1079,7 @@ int controlnet_forward(ctrlv_plan* p, Ctx& c, const void* sample, const void* co
                        void* out_mid, int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  el_t* x;
+  Trk x;
   TRY(run_input(c, dtype, sample, control, h, w, &x));
   std::vector<Tap> taps;
   int H, W;
@@ -1034,13 +1089,13 @@ int controlnet_forward(ctrlv_plan* p, Ctx& c, const void* sample, const void* co
     const long M = (long)N * taps[i].H * taps[i].W;
     const int C = taps[i].C;
     if (!c.dry) CTRLV_CHECK_ARG(out_down && out_down[i], "controlnet_forward: out_down[%zu] is null", i);
-    ctrlv_gemm_desc d = gd(taps[i].x, C, p->zc[i], c.dry ? nullptr : out_down[i], C, (int)M, p->zc[i].n, C, C);
+    ctrlv_gemm_desc d = gd(taps[i].x.hi, C, p->zc[i], c.dry ? nullptr : out_down[i], C, (int)M, p->zc[i].n, C, C);
     d.s_acc = scale;
     TRY(gemm(c, d));
   }
   {
     const int C = p->cfg.block_out_channels[p->cfg.n_blocks - 1];
-    ctrlv_gemm_desc d = gd(x, C, p->zc_mid, out_mid, C, (int)((long)N * H * W), p->zc_mid.n, C, C);
+    ctrlv_gemm_desc d = gd(x.hi, C, p->zc_mid, out_mid, C, (int)((long)N * H * W), p->zc_mid.n, C, C);
     d.s_acc = scale;
     TRY(gemm(c, d));
   }
@@ -1207,6 +1262,15 @@ extern "C" int ctrlv_plan_set_time_context_order(ctrlv_plan* p, int order) {
   return CTRLV_OK;
 }
 
+extern "C" int ctrlv_plan_set_trunk_mode(ctrlv_plan* p, int mode) {
+  CTRLV_CHECK_ARG(p != nullptr && (mode == 0 || mode == 1), "plan_set_trunk_mode: mode must be 0 (plain) or 1 (split hi + lo planes)");
+  CTRLV_CHECK_ARG(mode == 0 || CTRLV_ELEM_DTYPE == 1, "plan_set_trunk_mode: the split trunk needs the fp16 element library "
+                                                      "(libctrlv_hip_f16.so)");
+  if (p->trunk_mode != mode) p->ws_cache.clear();       // the workspace grows with the lo planes
+  p->trunk_mode = mode;
+  return CTRLV_OK;
+}
+
 extern "C" int ctrlv_plan_num_down_residuals(ctrlv_plan* p) {
   CTRLV_CHECK_ARG(p != nullptr, "plan: null plan");
   int n = 1;
@@ -1289,17 +1353,17 @@ static int unet_encoder(ctrlv_plan* p, Ctx& c, const void* sample, int dtype, co
                         const float* ids, int n_ids, void* const* out_taps, void* out_mid, int h, int w) {
   const int N = c.B * c.F;
   TRY(run_context(c, dtype, timestep, n_t, ehs, ids, n_ids));
-  el_t* x;
+  Trk x;
   TRY(run_input(c, dtype, sample, nullptr, h, w, &x));
   std::vector<Tap> taps;
   int H, W;
   TRY(run_down_mid(c, x, h, w, taps, &x, &H, &W));
-  if (!c.dry) {
+  if (!c.dry) {     // (the training step's tensors are plain element rows: the hi planes)
     for (size_t i = 0; i < taps.size(); ++i) {
       CTRLV_CHECK_ARG(out_taps[i] != nullptr, "unet_encoder_forward: out_taps[%zu] is null", i);
-      TRY(ctrlv_axpby(taps[i].x, taps[i].x, 1.0f, 0.0f, out_taps[i], (size_t)N * taps[i].H * taps[i].W * taps[i].C, c.st));
+      TRY(ctrlv_axpby(taps[i].x.hi, taps[i].x.hi, 1.0f, 0.0f, out_taps[i], (size_t)N * taps[i].H * taps[i].W * taps[i].C, c.st));
     }
-    TRY(ctrlv_axpby(x, x, 1.0f, 0.0f, out_mid, (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1], c.st));
+    TRY(ctrlv_axpby(x.hi, x.hi, 1.0f, 0.0f, out_mid, (size_t)N * H * W * p->cfg.block_out_channels[p->cfg.n_blocks - 1], c.st));
   }
   return CTRLV_OK;
 }

@@ -123,7 +123,7 @@ def geglu_bwd(raw, du, draw):
 def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split=0, conv=None, temporal=None,
                R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
                act=0, geglu=0, out_f32=False, n_store=None, M=None, tile=0, raw_out=None, n_scale2=0, s_acc2=1.0, _dbg=0,
-               gn_partials=None, splitk=True, rows_per_image=0):
+               gn_partials=None, splitk=True, rows_per_image=0, R1_lo=None, R2_lo=None, out_lo=None):
     d = GemmDesc()
     d.A, d.A2, d.W, d.out = _p(A), _p(A2), _p(W), _p(out)
     d.bias, d.R1, d.R2, d.V = _p(bias), _p(R1), _p(R2), _p(V)
@@ -152,6 +152,8 @@ def _gemm_desc(A, W, out, *, N, cin, taps=1, mode=0, bias=None, A2=None, c_split
         d.raw_out, d.ld_raw = _p(raw_out), raw_out.stride(0)
     d.n_scale2, d.s_acc2 = n_scale2, s_acc2
     d.gn_partials = _p(gn_partials)
+    # split residual-trunk planes (fp16 library; include/ctrlv_hip.h): same shapes / pitches as R1 / R2 / out
+    d.R1_lo, d.R2_lo, d.out_lo = _p(R1_lo), _p(R2_lo), _p(out_lo)
     return d
 
 
@@ -227,10 +229,12 @@ def ff_fused_pack(w1_packed, b1, w2_packed):
     return w1f, w2f
 
 
-def _ff_out_desc(out, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1):
+def _ff_out_desc(out, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1,
+                 R1_lo=None, R2_lo=None, out_lo=None):
     """The second projection's descriptor of a C = 320 feed-forward (what ctrlv_ff_fused / ctrlv_ff_fused_serves take)."""
     d = GemmDesc()
     d.out, d.bias, d.R1, d.R2, d.V = _p(out), _p(bias), _p(R1), _p(R2), _p(V)
+    d.R1_lo, d.R2_lo, d.out_lo = _p(R1_lo), _p(R2_lo), _p(out_lo)
     d.M, d.N, d.Cin, d.taps, d.mode = out.shape[0], out.shape[1], 4 * out.shape[1], 1, 0
     d.ldo, d.n_store = out.stride(0), out.shape[1]
     d.ldr1 = R1.stride(0) if R1 is not None else 0
@@ -250,11 +254,11 @@ def ff_fused_serves(x, out, **epi):
 
 
 def ff_fused(x, w1f, w2f, out, *, bias=None, R1=None, s1=1.0, R2=None, s2=1.0, s_acc=1.0, V=None, vmode=0, vdiv=1,
-             vmod=1 << 30, vS=1, ln=None, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30):
+             vmod=1 << 30, vS=1, ln=None, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, R1_lo=None, R2_lo=None, out_lo=None):
     """out = s_acc * (GEGLU(x W1^T + b1) W2^T + bias) + s1 R1 + s2 R2 + V[idx(m)] for a C = 320 feed-forward, the 4C-wide
     intermediate kept on chip (csrc/ff_fused.hip).  The epilogue operands are those of `gemm`."""
     _need_gpu(x, "x")
-    d = _ff_out_desc(out, bias, R1, s1, R2, s2, s_acc, V, vmode, vdiv, vmod, vS)
+    d = _ff_out_desc(out, bias, R1, s1, R2, s2, s_acc, V, vmode, vdiv, vmod, vS, R1_lo, R2_lo, out_lo)
     ev = _prof.begin()
     if ln is None:        # ln = (gamma, beta, eps): the LayerNorm in front of the feed-forward, folded into the kernel
         check(_L(x).ctrlv_ff_fused(_p(x), x.stride(0), _p(w1f), _p(w2f), ctypes.byref(d), _stream()),
@@ -299,26 +303,28 @@ def groupnorm_from_partials(x, n_img, S, C, imgs_per_stat, gamma, beta, eps, sil
     return y
 
 
-def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
-    """Two-pass GroupNorm(32)(+SiLU) over channels-last rows; (x | x2) is a channel concat when x2 is given."""
+def groupnorm(x, x2, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials, x_lo=None, x2_lo=None):
+    """Two-pass GroupNorm(32)(+SiLU) over channels-last rows; (x | x2) is a channel concat when x2 is given.  x_lo / x2_lo:
+    the lo planes of a SPLIT input (the normalised value is x + x_lo)."""
     _need_gpu(x, "x")
     lib = _L(x)
     c_split = x.shape[1] if x2 is not None else 0
     st = _stream()
     ev = _prof.begin()
-    check(lib.ctrlv_groupnorm_stats(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, eps, _p(partials), st),
-          "ctrlv_groupnorm_stats")
-    check(lib.ctrlv_groupnorm_apply(_p(x), _p(x2), c_split, n_img, S, C, imgs_per_stat, _p(partials), _p(gamma),
-                                    _p(beta), 1 if silu else 0, _p(y), st), "ctrlv_groupnorm_apply")
+    check(lib.ctrlv_groupnorm_stats_split(_p(x), _p(x_lo), _p(x2), _p(x2_lo), c_split, n_img, S, C, imgs_per_stat, eps,
+                                          _p(partials), st), "ctrlv_groupnorm_stats")
+    check(lib.ctrlv_groupnorm_apply_split(_p(x), _p(x_lo), _p(x2), _p(x2_lo), c_split, n_img, S, C, imgs_per_stat,
+                                          _p(partials), _p(gamma), _p(beta), 1 if silu else 0, _p(y), st),
+          "ctrlv_groupnorm_apply")
     _prof.end(ev, "groupnorm", 0.0, 2.0 * 2 * n_img * S * C)       # algorithmic: 1 read + 1 write, bf16
     return y
 
 
-def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30):
+def layernorm(x, gamma, beta, eps, y, V=None, vdiv=1, vmod=1 << 30, x_lo=None):
     _need_gpu(x, "x")
     M, C = x.shape
     ev = _prof.begin()
-    check(_L(x).ctrlv_layernorm(_p(x), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
+    check(_L(x).ctrlv_layernorm_split(_p(x), _p(x_lo), M, C, _p(gamma), _p(beta), eps, _p(V), vdiv, vmod,
                                       V.stride(0) if V is not None else 0, _p(y), _stream()), "ctrlv_layernorm")
     _prof.end(ev, "layernorm", 0.0, 2.0 * 2 * M * C)
     return y
@@ -407,6 +413,13 @@ def axpby(x, r, a, b, y):
     check(_L(x).ctrlv_axpby(_p(x), _p(r), a, b, _p(y), x.numel(), _stream()), "ctrlv_axpby")
     _prof.end(ev, "residual_add", 0.0, 2.0 * 3 * x.numel())
     return y
+
+
+def axpby_split(x, x_lo, r, a, b, y, y_lo):
+    """(y, y_lo) = split(a * (x + x_lo) + b * r): the residual add on a SPLIT trunk tensor (x_lo may be None)."""
+    _need_gpu(x, "x")
+    check(_L(x).ctrlv_axpby_split(_p(x), _p(x_lo), _p(r), a, b, _p(y), _p(y_lo), x.numel(), _stream()), "ctrlv_axpby_split")
+    return y, y_lo
 
 
 def silu(x, y):

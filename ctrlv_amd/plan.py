@@ -65,6 +65,7 @@ class Plan:
         self._cfg = config_struct(kind, config, time_context_order)
         check(self._lib.ctrlv_plan_create(ctypes.byref(self._cfg), self.device.index or 0, ctypes.byref(self._h)),
               "ctrlv_plan_create")
+        self.trunk_mode = "same"
         self._ws = {}            # lane -> uint8 workspace tensor
         self._ws_bytes = {}      # (B, F, H, W) -> bytes
         self.n_down = self._lib.ctrlv_plan_num_down_residuals(self._h)
@@ -111,6 +112,15 @@ class Plan:
         if m < 0:
             check(m, "ctrlv_plan_profile_read")
         return [(_lib.FAMILIES[r.family], r.ms, r.flops, r.bytes, (r.M, r.N, r.K, r.flags)) for r in arr[:m]]
+
+    def set_trunk_mode(self, mode):
+        """Storage of the residual trunk: "same" (one element per value) or "fp16x2" (split hi + lo element planes: fp32's
+        bytes, 21+ significant bits; fp16 plans only) -- ctrlv_plan_set_trunk_mode."""
+        if mode not in ("same", "fp16x2"):
+            raise ValueError(f'trunk_dtype must be "same" or "fp16x2", got {mode!r}')
+        check(self._lib.ctrlv_plan_set_trunk_mode(self._h, 1 if mode == "fp16x2" else 0), "ctrlv_plan_set_trunk_mode")
+        self._ws_bytes.clear()          # the workspace grows with the lo planes
+        self.trunk_mode = mode
 
     def set_time_context_order(self, order):
         check(self._lib.ctrlv_plan_set_time_context_order(self._h, 0 if order == "sb" else 1),

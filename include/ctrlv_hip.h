@@ -112,6 +112,14 @@ typedef struct ctrlv_gemm_desc {
                                          slices + a streaming sum / epilogue kernel).  NULL = never split */
   int32_t ksplit, w_cin;              /* internal (set by ctrlv_gemm for its slice launch; callers leave 0): number of K
                                          slices; channels per tap of W when Cin is a slice's channel count */
+  /* SPLIT ("fp16x2") residual trunk -- libctrlv_hip_f16.so only (round 5).  A tensor of the residual stream may carry a
+   * second plane of the same shape and pitch: hi = rne(v), lo = rne(v - hi), 2 x 16 bits per element = fp32's bytes and
+   * 21+ significant bits.  R1_lo / R2_lo (optional, need R1 / R2): the operand is R1 + R1_lo (R2 + R2_lo); out_lo
+   * (optional): `out` receives hi, out_lo receives lo.  MFMA operands (A, A2) always read the hi plane: it is the
+   * element-rounded tensor.  Not with GEGLU / SiLU / fp32 output / gn_partials / raw_out. */
+  const void* R1_lo;
+  const void* R2_lo;
+  void* out_lo;
 } ctrlv_gemm_desc;
 
 int ctrlv_gemm(const ctrlv_gemm_desc* d, ctrlv_stream_t stream);
@@ -148,12 +156,22 @@ int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img,
  * imgs_per_stat) * 64 floats (the producer's part first); S must be a multiple of 64. */
 int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, int C, int imgs_per_stat, float eps, float* partials,
                                   const float* gamma, const float* beta, int silu, void* y, ctrlv_stream_t stream);
+/* The statistics and apply passes on a SPLIT input (ctrlv_gemm_desc.out_lo; a launch with out_lo writes no gn_partials): x_lo / x2_lo are the lo planes of x / x2 (same shapes and
+ * pitches; either may be NULL = that half has no lo plane); the normalised value is x + x_lo.  y is a plain tensor. */
+int ctrlv_groupnorm_stats_split(const void* x, const void* x_lo, const void* x2, const void* x2_lo, int c_split, int n_img,
+                                int S, int C, int imgs_per_stat, float eps, float* partials, ctrlv_stream_t stream);
+int ctrlv_groupnorm_apply_split(const void* x, const void* x_lo, const void* x2, const void* x2_lo, int c_split, int n_img,
+                                int S, int C, int imgs_per_stat, const float* partials, const float* gamma,
+                                const float* beta, int silu, void* y, ctrlv_stream_t stream);
 
 /* LayerNorm over the channel axis of [M, C] bf16 rows (BasicTransformerBlock.norm1/3,
  * TemporalBasicTransformerBlock.norm_in/1/3).  If V != NULL, normalises x[m,:] + V[(m / vdiv) % vmod, :]
  * (the frame positional embedding add of TransformerSpatioTemporalModel). */
 int ctrlv_layernorm(const void* x, int M, int C, const float* gamma, const float* beta, float eps,
                     const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream);
+/* ... of a SPLIT input: normalises x + x_lo (+ V) (x_lo: the lo plane of x, ctrlv_gemm_desc.out_lo). */
+int ctrlv_layernorm_split(const void* x, const void* x_lo, int M, int C, const float* gamma, const float* beta, float eps,
+                          const float* V, int vdiv, int vmod, int ldv, void* y, ctrlv_stream_t stream);
 
 /* Fused feed-forward pair at C = 320:  out = epilogue( GEGLU(x . W1^T + b1) . W2^T )  with the second projection's
  * epilogue operands taken from `out_desc` (out, bias = b2, R1 / R2 / V, s_acc, s1, s2, M, N = 320, Cin = 1280, mode 0):
@@ -234,6 +252,10 @@ int ctrlv_im2col3x3(const void* x, int n_img, int H, int W, int Cp, void* col, i
 /* y = a*x + b*r  (bf16 rows, n elements) -- the ControlNet residual add of
  * unet_spatio_temporal_condition.py:119-127,136-137. */
 int ctrlv_axpby(const void* x, const void* r, float a, float b, void* y, size_t n, ctrlv_stream_t stream);
+/* (y, y_lo) = split(a * (x + x_lo) + b * r): the same add on a SPLIT skip tensor (x_lo may be NULL; y_lo receives the lo
+ * plane of the result; in place allowed). */
+int ctrlv_axpby_split(const void* x, const void* x_lo, const void* r, float a, float b, void* y, void* y_lo, size_t n,
+                      ctrlv_stream_t stream);
 /* Sinusoidal `Timesteps` (flip_sin_to_cos=True, shift 0, max_period 1e4): t[n] -> out[n, dim] = [cos | sin], bf16. */
 int ctrlv_timestep_embedding(const float* t, int n, int dim, void* out, ctrlv_stream_t stream);
 /* y = silu(x) on bf16 (the SiLU in front of every time_emb_proj). */
@@ -340,6 +362,13 @@ int ctrlv_plan_create(const ctrlv_model_config* cfg, int device, ctrlv_plan** ou
 int ctrlv_plan_load_weights(ctrlv_plan* plan, const ctrlv_tensor_desc* tensors, size_t n);
 /* Switch the temporal cross-attention context order of an existing plan (0 "sb" / 1 "bs", see the config). */
 int ctrlv_plan_set_time_context_order(ctrlv_plan* plan, int order);
+/* Storage of the RESIDUAL TRUNK of the plan's forwards (conv_in output, every block / AlphaBlender output, the skip
+ * tensors, the tensors the ControlNet residuals are added into): 0 = one element per value like every other activation
+ * (default), 1 = SPLIT into hi + lo element planes (see ctrlv_gemm_desc.out_lo: fp32's bytes, 21+ significant bits under
+ * fp16 branches; north_star's 1e-3 model-level tolerance).  Mode 1 needs the fp16 element library; the workspace grows
+ * (ctrlv_plan_workspace_bytes answers for the current mode).  Model inputs / outputs / residual tensors across the ABI are
+ * unchanged. */
+int ctrlv_plan_set_trunk_mode(ctrlv_plan* plan, int mode);
 /* Bytes of workspace one forward of (B clips, F frames, H x W latent) needs; 0 on error (see ctrlv_last_error). */
 size_t ctrlv_plan_workspace_bytes(ctrlv_plan* plan, int B, int F, int H, int W);
 /* Number of residual tensors the ControlNet produces / the UNet consumes on the down path (12 for SVD), and the

@@ -434,6 +434,35 @@ def test_gemm_per_clip_rows(ops, M, K, N):
             assert torch.equal(one[0], out[M - 1])
 
 
+@pytest.mark.parametrize("K,N", [(1280, 1280), (1024, 2560)])
+def test_gemm_per_clip_rows_do_not_depend_on_the_batch(ops, K, N):
+    """A clip's conditioning vectors (time / added-id MLPs, time_emb_proj, the one-key cross-attention vectors) have the
+    same BITS at every batch size: the per-clip-rows kernel serves these launches in 8-row chunks, chosen by the layer
+    (tile 11 from the plans; any launch of up to 64 rows without a tile request) -- never by M (the round-4
+    dispatch switched to the MFMA tile, with another summation order, at M = 9)."""
+    from ctrlv_amd import packing
+    M = 70
+    A = bf(torch.randn(M, K, generator=g(1)))
+    wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    R1 = bf(torch.randn(M, N, generator=g(4)))
+    Wd, bd, Ad, R1d = packing.pack_linear(wt).to(DEV), b.to(DEV), A.to(DEV), R1.to(DEV)
+    lin = A.float() @ bf(wt).float().T + b
+    for kw, ref, dt in ((dict(act=1), F.silu(lin), EL), (dict(out_f32=True), lin, torch.float32),
+                        (dict(R1=R1d, act=1), F.silu(lin + R1.float()), EL)):
+        outs = {}
+        for rows, tile in ((2, 0), (8, 0), (10, 0), (33, 0), (64, 0), (70, 11), (1, 11)):
+            out = torch.full((rows, N), float("nan"), dtype=dt, device=DEV)
+            k2 = dict(kw)
+            if "R1" in k2:
+                k2["R1"] = R1d[:rows]
+            ops.gemm(Ad[:rows], Wd, out, N=N, cin=K, bias=bd, tile=tile, **k2)
+            assert parity_err(out, ref[:rows]) < (1e-4 if dt == torch.float32 else tol(3e-3))
+            outs[rows] = out
+        for rows, out in outs.items():            # every row: the same bits whatever the launch's row count
+            assert torch.equal(out, outs[70][:rows]), rows
+
+
 def test_gemm_small_m_and_padding(ops):
     """M = 2 (the per-clip embedding GEMMs) and N padded to 32 with n_store = 4 (conv_out)."""
     from ctrlv_amd import packing
