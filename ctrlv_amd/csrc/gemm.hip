@@ -23,6 +23,9 @@
 int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
 bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d);
 bool ctrlv_conv_halo_order(const ctrlv_gemm_desc& d);      // gemm_pp_m0.hip: K order (dy, 32-channel block, dx) for this conv?
+// four-waves-per-SIMD 16x16x32 core (gemm_w16_kernel.h, gemm_w16.hip): tile 12 = 256x256, tile 13 = 256x320
+int ctrlv_gemm_launch_w16(const ctrlv_gemm_desc& d, int tile, hipStream_t stream);
+bool ctrlv_gemm_w16_supports(const ctrlv_gemm_desc& d, int tile);
 constexpr int kHaloOrderFlag = 0x100;                      // set in the kernel's copy of d.tile (host-side field otherwise)
 
 namespace {
@@ -364,6 +367,19 @@ static int splitk_plan(const ctrlv_gemm_desc& d, int* tile_out) {
   return best_s;
 }
 
+// Which LAYERS run on the 16x16x32 core (0 = none): a function of the layer's shape only -- never of M -- because the core
+// sums a K half-step in one instruction whose internal order is not the 32x32x16 kernels': a layer given to it runs there at
+// EVERY row count, so a clip's bits do not depend on the batch (tests/test_fullsize_gpu.py clip independence).
+static int w16_tile_of(const ctrlv_gemm_desc& d) {
+  static int on = -1;                    // A/B handle: CTRLV_W16=0 -> every layer on the 32x32x16 kernels
+  if (on < 0) { const char* e = getenv("CTRLV_W16"); on = e ? atoi(e) : 1; }
+  if (!on || d.mode != 0) return 0;
+  int tile = 0;
+  if (d.geglu) tile = (d.Cin >= 640 && d.N % 256 == 0) ? 12 : 0;      // the C = 640 / 1280 GEGLU projections
+  if (tile && !ctrlv_gemm_w16_supports(d, tile)) tile = 0;           // (raw_out, odd pitches ...: shape-level conditions too)
+  return tile;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const ctrlv_gemm_desc& d, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128 + kGeluTabBytes;   // staging ring | Phi table (GEGLU launches)
@@ -453,18 +469,19 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
       }
     }
   }
-  // Per-clip rows: tile 11 = "this is a per-clip GEMM" (the plans say so for every GEMM of the conditioning path: the choice is
-  // the LAYER's, whatever the batch size); without a tile request, launches of up to 64 rows take it too.
-  const bool gemv_ok = d.mode == 0 && !d.geglu && !d.A2 && !d.raw_out && d.n_scale2 == 0 && (d.out_f32 & ~1) == 0 && !split_io;
-  CTRLV_CHECK_ARG(d.tile != 11 || gemv_ok, "ctrlv_gemm: tile 11 (per-clip rows) serves plain mode-0 launches only");
-  if (d.tile == 11 || (d.tile == 0 && gemv_ok && d.M <= 64)) {
-    static int on = -1;                  // A/B handle: CTRLV_GEMV=0 -> the 128 x 128 MFMA tile
-    if (on < 0) { const char* e = getenv("CTRLV_GEMV"); on = e ? atoi(e) : 1; }
-    if (on || d.tile == 11) {
-      hipLaunchKernelGGL(gemv_small_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)((d.M + 7) / 8)), dim3(256), 0, stream, d);
-      CTRLV_LAUNCH_CHECK();
-      return CTRLV_OK;
-    }
+  // Per-clip rows: tile 11 = "this is a per-clip GEMM".  The plans say so for every GEMM of the conditioning path: the choice
+  // is the LAYER's, never the row count's (no launch is routed here by its M: a layer's bits must not change with the batch).
+  if (d.tile == 11) {
+    CTRLV_CHECK_ARG(d.mode == 0 && !d.geglu && !d.A2 && !d.raw_out && d.n_scale2 == 0 && (d.out_f32 & ~1) == 0 && !split_io,
+                    "ctrlv_gemm: tile 11 (per-clip rows) serves plain mode-0 launches only");
+    hipLaunchKernelGGL(gemv_small_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)((d.M + 7) / 8)), dim3(256), 0, stream, d);
+    CTRLV_LAUNCH_CHECK();
+    return CTRLV_OK;
+  }
+  if (d.tile == 12 || d.tile == 13) return ctrlv_gemm_launch_w16(d, d.tile, stream);
+  if (d.tile == 0) {
+    const int w16 = w16_tile_of(d);
+    if (w16) return ctrlv_gemm_launch_w16(d, w16, stream);
   }
   int tile = d.tile;
   if (tile == 0) {

@@ -402,7 +402,7 @@ def test_gemm_split_contraction_linear(ops, epi):
 
 @pytest.mark.parametrize("M,K,N", [(1, 320, 1280), (2, 1280, 1280), (5, 1024, 11520), (8, 64, 64)])
 def test_gemm_per_clip_rows(ops, M, K, N):
-    """M <= 8 (the conditioning path's per-clip GEMMs: csrc/gemm.hip gemv_small_kernel): every epilogue operand set the
+    """The conditioning path's per-clip GEMMs (tile 11: csrc/gemm.hip gemv_small_kernel): every epilogue operand set the
     plan uses there (SiLU, residual + SiLU, fp32 output, row vector) against fp32 PyTorch and the 128 x 128 MFMA tile;
     a row's bits do not depend on the other rows."""
     from ctrlv_amd import packing
@@ -423,23 +423,146 @@ def test_gemm_per_clip_rows(ops, M, K, N):
     }
     for name, (kw, ref, dt) in cases.items():
         out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
-        ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, **kw)
+        ops.gemm(Ad, Wd, out, N=N, cin=K, bias=bd, tile=11, **kw)
         assert parity_err(out, ref, name) < (1e-4 if dt == torch.float32 else tol(3e-3))
         mfma = torch.empty_like(out)
         ops.gemm(Ad, Wd, mfma, N=N, cin=K, bias=bd, tile=1, **kw)
         assert rel_l2(out.float().cpu(), mfma.float().cpu()) < (1e-5 if dt == torch.float32 else tol(2e-3))
+        auto = torch.empty_like(out)          # no tile request: never the per-clip kernel (the choice is the layer's, not M's)
+        ops.gemm(Ad, Wd, auto, N=N, cin=K, bias=bd, **kw)
+        assert torch.equal(auto, mfma)
         if M > 1 and "R1" not in kw and "V" not in kw:
             one = torch.empty((1, N), dtype=dt, device=DEV)
-            ops.gemm(Ad[M - 1:], Wd, one, N=N, cin=K, bias=bd, **kw)
+            ops.gemm(Ad[M - 1:], Wd, one, N=N, cin=K, bias=bd, tile=11, **kw)
             assert torch.equal(one[0], out[M - 1])
+
+
+# ---- the four-waves-per-SIMD 16x16x32 core (csrc/gemm_w16_kernel.h): tile 12 = 256x256, tile 13 = 256x320
+@pytest.mark.parametrize("tile,M,N,K", [(12, 300, 256, 128), (12, 1000, 512, 320), (12, 2048 + 77, 1280, 640), (13, 300, 320, 128),
+                                        (13, 700, 640, 1280), (13, 2048 + 77, 960, 320), (13, 515, 1920, 640), (12, 64, 3840, 256)])
+def test_gemm_w16_plain_epilogues(ops, tile, M, N, K):
+    """Every epilogue operand set of the 16x16x32 core (its accumulators hold the interleaved column pairs: 8 consecutive
+    output columns per lane, stored straight from registers) against fp32 PyTorch; ragged last row tile, several column
+    tiles, the pre-scaled q block."""
+    from ctrlv_amd import packing
+    A = bf(torch.randn(M, K, generator=g(1)))
+    Wt = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    bias = torch.randn(N, generator=g(3))
+    R1 = bf(torch.randn(M, N, generator=g(4)))
+    R2 = bf(torch.randn(M, N, generator=g(5)))
+    V = torch.randn(7, N, generator=g(6))
+    Wp = packing.pack_linear(Wt)
+    lin = A.float() @ Wp[:N].float().T + bias
+    m = torch.arange(M)
+    vidx = (m // 13) % 7
+    vidx2 = ((m // 50) * 10 + (m % 10)) % 7
+    Ad, Wd, bd, R1d, R2d, Vd = (t.to(DEV) for t in (A, Wp, bias, R1, R2, V))
+
+    def run(**kw):
+        out = torch.full((M, N), float("nan"), dtype=EL, device=DEV)
+        ops.gemm(Ad, Wd, out, N=N, cin=K, tile=tile, **kw)
+        return out
+    assert parity_err(run(bias=bd, R1=R1d, s1=0.5, R2=R2d, s2=-0.25, s_acc=0.7), 0.7 * lin + 0.5 * R1.float() - 0.25 * R2.float()) < tol(3e-3)
+    assert parity_err(run(bias=bd, R1=R1d, V=Vd, vmode=1, vdiv=13, vmod=7), lin + R1.float() + V[vidx]) < tol(3e-3)
+    assert parity_err(run(bias=bd, R1=R1d, V=Vd, vmode=2, vdiv=50, vS=10, vmod=7), lin + R1.float() + V[vidx2]) < tol(3e-3)
+    assert parity_err(run(bias=bd, V=Vd, vmode=1, vdiv=13, vmod=7), lin + V[vidx]) < tol(3e-3)
+    assert parity_err(run(bias=bd, R1=R1d), lin + R1.float()) < tol(3e-3)
+    assert parity_err(run(), lin - bias) < tol(3e-3)
+    unit = 80 if tile == 13 else 64              # the scale switches per wave tile on the 320-wide tile, per 32 columns else
+    n2 = (N // 2) // unit * unit
+    if n2:
+        sc = torch.where(torch.arange(N) < n2, 0.25, 1.5)
+        assert parity_err(run(bias=bd, s_acc=1.5, n_scale2=n2, s_acc2=0.25), lin * sc) < tol(3e-3)
+    with pytest.raises(ValueError):              # SiLU / fp32 output stay on the 2-stage kernels
+        run(bias=bd, act=1)
+    # a row's bits do not depend on how many rows the launch has (the core serves its layers at EVERY row count)
+    full = run(bias=bd, R1=R1d)
+    for rows in (1, 17, 256, M - 3):
+        if rows < M:
+            part = torch.empty(rows, N, dtype=EL, device=DEV)
+            ops.gemm(Ad[:rows], Wd, part, N=N, cin=K, bias=bd, R1=R1d[:rows], tile=tile)
+            assert torch.equal(part, full[:rows]), rows
+
+
+@pytest.mark.parametrize("M,C", [(333, 320), (2048 + 200, 640), (700, 1280)])
+def test_gemm_w16_geglu(ops, M, C):
+    """GEGLU on the 16x16x32 core: the (16 value | 16 gate) weight row blocks are read as (value even, value odd, gate even,
+    gate odd) of a 32-output-column range, value and gate of a column meet in one lane."""
+    from ctrlv_amd import packing
+    A = bf(torch.randn(M, C, generator=g(1)))
+    Wt = torch.randn(8 * C, C, generator=g(2)) / math.sqrt(C)
+    b = torch.randn(8 * C, generator=g(3))
+    Wp, bp = packing.pack_geglu(Wt, b)
+    proj = A.float() @ bf(Wt).float().T + b
+    ref = proj[:, :4 * C] * F.gelu(proj[:, 4 * C:])
+    out = torch.full((M, 4 * C), float("nan"), dtype=EL, device=DEV)
+    ops.gemm(A.to(DEV), Wp.to(DEV), out, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, tile=12)
+    assert parity_err(out, ref) < tol(3e-3)
+    old = torch.empty_like(out)
+    ops.gemm(A.to(DEV), Wp.to(DEV), old, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, tile=5)
+    assert rel_l2(out.float().cpu(), old.float().cpu()) < tol(2e-3)      # same arithmetic up to the MFMA's internal K order
+    one = torch.empty(5, 4 * C, dtype=EL, device=DEV)
+    ops.gemm(A[:5].to(DEV), Wp.to(DEV), one, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, tile=12)
+    assert torch.equal(one, out[:5])
+    if C >= 640:       # the layers the dispatcher gives to the core take it at every row count
+        auto = torch.empty_like(out)
+        ops.gemm(A.to(DEV), Wp.to(DEV), auto, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1)
+        assert torch.equal(auto, out)
+        ops.gemm(A[:5].to(DEV), Wp.to(DEV), one, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1)
+        assert torch.equal(one, out[:5])
+
+
+@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
+def test_gemm_w16_conv3x3(ops, tile, stride, up):
+    from ctrlv_amd import packing
+    n, cin, H, W = 5, 64, 16, 24
+    cout = 256 if tile == 12 else 320
+    x = bf(torch.randn(n, cin, H, W, generator=g(1)))
+    wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g(3))
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, bf(wt).float(), b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    M = n * Ho * Wo
+    R1 = bf(torch.randn(M, cout, generator=g(4)))
+    V = torch.randn(n, cout, generator=g(5))
+    rows = rows_from_nchw(ref)
+    xd, wd, bd = rows_from_nchw(x).to(DEV), packing.pack_conv3x3(wt).to(DEV), b.to(DEV)
+    kw = dict(N=wd.shape[0], cin=cin, taps=9, mode=1, conv=(H, W, Ho, Wo, stride, up), bias=bd, n_store=cout, tile=tile)
+    out = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    ops.gemm(xd, wd, out, **kw)
+    assert parity_err(out, rows) < tol(3e-3)
+    ops.gemm(xd, wd, out, R1=R1.to(DEV), s1=0.5, s_acc=0.75, **kw)
+    assert parity_err(out, 0.75 * rows + 0.5 * R1.float()) < tol(3e-3)
+    ops.gemm(xd, wd, out, V=V.to(DEV), vmode=1, vdiv=Ho * Wo, **kw)
+    assert parity_err(out, rows + V[torch.arange(M) // (Ho * Wo)]) < tol(3e-3)
+
+
+@pytest.mark.parametrize("tile", [12, 13])
+def test_gemm_w16_temporal_conv(ops, tile):
+    from ctrlv_amd import packing
+    B, Fr, S, cin = 2, 5, 60, 64
+    cout = 256 if tile == 12 else 320
+    x = bf(torch.randn(B, cin, Fr, S, 1, generator=g(1)))
+    wt = torch.randn(cout, cin, 3, 1, 1, generator=g(2)) / math.sqrt(3 * cin)
+    b = torch.randn(cout, generator=g(3))
+    ref = F.conv3d(x.float(), bf(wt).float(), b, padding=(1, 0, 0))          # (B, cout, F, S, 1)
+    rows = ref.permute(0, 2, 3, 4, 1).reshape(B * Fr * S, cout)
+    xd = x.permute(0, 2, 3, 4, 1).reshape(B * Fr * S, cin).contiguous().to(DEV)
+    R1 = bf(torch.randn(B * Fr * S, cout, generator=g(4)))
+    out = torch.full((B * Fr * S, cout), float("nan"), dtype=EL, device=DEV)
+    ops.gemm(xd, packing.pack_conv_temporal(wt).to(DEV), out, N=cout, cin=cin, taps=3, mode=2, temporal=(Fr, S), bias=b.to(DEV),
+             R1=R1.to(DEV), s_acc=0.5, tile=tile)
+    assert parity_err(out, 0.5 * rows + R1.float()) < tol(3e-3)
 
 
 @pytest.mark.parametrize("K,N", [(1280, 1280), (1024, 2560)])
 def test_gemm_per_clip_rows_do_not_depend_on_the_batch(ops, K, N):
     """A clip's conditioning vectors (time / added-id MLPs, time_emb_proj, the one-key cross-attention vectors) have the
     same BITS at every batch size: the per-clip-rows kernel serves these launches in 8-row chunks, chosen by the layer
-    (tile 11 from the plans; any launch of up to 64 rows without a tile request) -- never by M (the round-4
-    dispatch switched to the MFMA tile, with another summation order, at M = 9)."""
+    (tile 11 from the plans) -- never by M (the round-4 dispatch switched to the MFMA tile, with another
+    summation order, at M = 9)."""
     from ctrlv_amd import packing
     M = 70
     A = bf(torch.randn(M, K, generator=g(1)))
@@ -451,7 +574,7 @@ def test_gemm_per_clip_rows_do_not_depend_on_the_batch(ops, K, N):
     for kw, ref, dt in ((dict(act=1), F.silu(lin), EL), (dict(out_f32=True), lin, torch.float32),
                         (dict(R1=R1d, act=1), F.silu(lin + R1.float()), EL)):
         outs = {}
-        for rows, tile in ((2, 0), (8, 0), (10, 0), (33, 0), (64, 0), (70, 11), (1, 11)):
+        for rows, tile in ((2, 11), (8, 11), (10, 11), (33, 11), (64, 11), (70, 11), (1, 11)):
             out = torch.full((rows, N), float("nan"), dtype=dt, device=DEV)
             k2 = dict(kw)
             if "R1" in k2:
