@@ -1,6 +1,7 @@
 """ctypes binding of libctrlv_hip.so (include/ctrlv_hip.h).  No torch types cross this boundary."""
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libctrlv_hip.so")            # element type bf16
@@ -146,6 +147,20 @@ SIGNATURES = {
 }
 
 _libs = {}                # element dtype code (2 bf16 / 1 fp16) -> CDLL
+_tls = threading.local()  # .failed = the library whose call returned a negative status last (this thread)
+# c_int-returning entry points whose value is NOT a status code
+_NO_STATUS = {"ctrlv_abi_version", "ctrlv_elem_dtype", "ctrlv_build_id", "ctrlv_last_error", "ctrlv_ff_fused_w1f_bytes",
+              "ctrlv_gemm_gn_partials_serves", "ctrlv_ff_fused_serves", "ctrlv_plan_num_down_residuals"}
+
+
+def _status_recorder(lib, fn):
+    def call(*args):
+        rc = fn(*args)
+        if rc < 0:
+            _tls.failed = lib
+        return rc
+    call.__name__ = getattr(fn, "__name__", "ctrlv_fn")
+    return call
 ABI_VERSION = 17
 
 
@@ -208,6 +223,10 @@ def load(dtype=None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header / library out of sync
         fn.restype, fn.argtypes = res, args
+        if res is c_int and name not in _NO_STATUS:
+            # status-returning entry points remember WHICH library failed last on this thread: check() then reads that
+            # library's message, not a stale one of the other library (two libraries may be loaded)
+            setattr(lib, name, _status_recorder(lib, fn))
     if lib.ctrlv_abi_version() != ABI_VERSION:
         raise CtrlvHipError(f"{path}: ABI version {lib.ctrlv_abi_version()}, this host layer needs {ABI_VERSION}")
     if lib.ctrlv_elem_dtype() != code:
@@ -237,12 +256,14 @@ def last_error(lib=None):
     return " | ".join(msgs)
 
 
-def check(rc, what):
+def check(rc, what, lib=None):
     """Map the C status convention (include/ctrlv_hip.h) onto the reference's exception types: bad shapes /
-    arguments -> ValueError (as controlnet.py:80-98, pipeline_video_control.py:51-68), HIP failures -> RuntimeError."""
+    arguments -> ValueError (as controlnet.py:80-98, pipeline_video_control.py:51-68), HIP failures -> RuntimeError.
+    The message is the one of the library whose call failed (`lib`, else the library that returned a negative status last
+    on this thread)."""
     if rc == 0:
         return
-    msg = f"{what}: {last_error()} (status {rc})"
+    msg = f"{what}: {last_error(lib or getattr(_tls, 'failed', None))} (status {rc})"
     if rc in (-1, -2, -4, -5):     # bad argument / shape / dtype / workspace size
         raise ValueError(msg)
     raise CtrlvHipError(msg)

@@ -255,6 +255,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ---- in-kernel clock (DIAGNOSTIC BUILD ONLY: -DCTRLV_CLOCK_STAMP, tools/clock_probe.py; the product library contains no
+// stamp).  MI355X_MICROARCH "DVFS give-back" item 6: the clock the chip holds inside a kernel is d(s_memtime) /
+// d(s_memrealtime) x 100 MHz.  Thread 0 of every workgroup adds its two deltas to a buffer of this translation unit's own
+// (nothing else reads it, no output value depends on it); CTRLV_CLOCK_READER(unit) exports its reader.
+#ifdef CTRLV_CLOCK_STAMP
+static __device__ unsigned long long g_ctrlv_clock[2];
+#define CTRLV_CLOCK_BEGIN() \
+  const unsigned long long ck_t0_ = __builtin_amdgcn_s_memtime(), ck_r0_ = __builtin_amdgcn_s_memrealtime()
+#define CTRLV_CLOCK_END()                                                                  \
+  do {                                                                                     \
+    if (threadIdx.x == 0) {                                                                \
+      atomicAdd(&g_ctrlv_clock[0], __builtin_amdgcn_s_memtime() - ck_t0_);                 \
+      atomicAdd(&g_ctrlv_clock[1], __builtin_amdgcn_s_memrealtime() - ck_r0_);             \
+    }                                                                                      \
+  } while (0)
+#define CTRLV_CLOCK_READER(unit)                                                                                   \
+  extern "C" int ctrlv_debug_clock_##unit(unsigned long long* out2, int reset) {                                   \
+    if (hipDeviceSynchronize() != hipSuccess) return -3;                                                           \
+    if (out2 && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_ctrlv_clock), 16) != hipSuccess) return -3;                 \
+    const unsigned long long z[2] = {0, 0};                                                                        \
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ctrlv_clock), z, 16) != hipSuccess) return -3;                     \
+    return 0;                                                                                                      \
+  }
+#else
+#define CTRLV_CLOCK_BEGIN()
+#define CTRLV_CLOCK_END()
+#define CTRLV_CLOCK_READER(unit)
+#endif
+
 // ---- host side ----
 void ctrlv_set_error(const char* fmt, ...);
 #define CTRLV_MAX_DEVICES 64

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
   const int M = d.M;
   const int tiles = (M + 255) / 256, G = gridDim.x;
 
+  CTRLV_CLOCK_BEGIN();
   gelu_table_fill(smem + kTabOff, threadIdx.x, 512);
 
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1f, 0, kChunks * kW1Slot, 0x00020000);
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging reads done before the next tile's x_hi writes
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last chunks: nothing may be in flight
+  CTRLV_CLOCK_END();
 #endif
 }
 
@@ -322,6 +324,8 @@ int launch_ff(const FfArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+CTRLV_CLOCK_READER(ff_fused)
 
 extern "C" int ctrlv_ff_fused_w1f_bytes(void) { return kChunks * kW1Slot; }
 

@@ -126,14 +126,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const ctrlv_gemm_desc
     }
     // K order: tap outermost (gemm_pp_kernel.h issue_end: the same order, so the same bits; the block-major alternative
     // behind the same macro)
-#ifdef CTRLV_CONV_BLOCK_MAJOR
-    const int cb = kt / d.taps;
-    const int tap = kt - cb * d.taps;
-    int cc = cb << 6;
-#else
     const int tap = kt / kpt;
     int cc = (kt - tap * kpt) << 6;
-#endif
     const int wcol = tap * d.Cin + cc;
     const el_t* src = (const el_t*)d.A;
     int ld = d.lda;

@@ -95,3 +95,5 @@ int ctrlv_gemm_launch_pp(const ctrlv_gemm_desc& d, int tile, hipStream_t stream)
   if (tile == 5 || tile == 7) return launch_epi<256, 2, 4, 0>(d, persistent, stream);
   return launch_epi<320, 4, 2, 0>(d, persistent, stream);
 }
+
+CTRLV_CLOCK_READER(pp_m0)

@@ -6,3 +6,5 @@ int ctrlv_gemm_launch_pp_conv(const ctrlv_gemm_desc& d, int tile, bool persisten
   if (tile == 5 || tile == 7) return launch_epi<256, 2, 4, 1>(d, persistent, stream);
   return launch_epi<320, 4, 2, 1>(d, persistent, stream);
 }
+
+CTRLV_CLOCK_READER(pp_m1)

@@ -58,3 +58,5 @@ int ctrlv_gemm_launch_w16(const ctrlv_gemm_desc& d, int tile, hipStream_t stream
   if (d.mode == 1) return launch_w16_epi<320, 1>(d, stream);
   return launch_w16_epi<320, 2>(d, stream);
 }
+
+CTRLV_CLOCK_READER(w16)

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
   constexpr int TAB_OFF = NH * SLOT;                          // Phi table of the GEGLU epilogue (common.h)
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  CTRLV_CLOCK_BEGIN();
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
   }
   wait_vmcnt<0>();
+  CTRLV_CLOCK_END();
 #endif
 }
 

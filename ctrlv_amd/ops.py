@@ -21,10 +21,10 @@ def _p(t):
 
 def _L(*tensors):
     """The library that serves these element tensors: libctrlv_hip_f16.so when they are fp16, else the bf16 library."""
-    for t in tensors:
-        if t is not None and t.dtype == torch.float16:
-            return _lib.load(torch.float16)
-    return _lib.load()
+    els = {t.dtype for t in tensors if t is not None and t.dtype in (torch.float16, torch.bfloat16)}
+    if len(els) > 1:
+        raise ValueError("ctrlv_amd: one call mixes bf16 and fp16 element tensors (a library serves ONE element type)")
+    return _lib.load(torch.float16 if torch.float16 in els else None)
 
 
 def _need_gpu(t, name="tensor"):

@@ -16,6 +16,10 @@
 
 #include "common.h"
 
+#ifndef CTRLV_ATTN_DBG
+#define CTRLV_ATTN_DBG 0
+#endif
+
 namespace {
 
 constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
@@ -183,8 +187,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
       for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+#if CTRLV_ATTN_DBG == 5          // diagnostic build (timing only): no K.Q^T (K fragment reads + MFMAs)
+        sacc[kt][ks] = (float)lane;
+#else
         const elx8 kf = *(const elx8*)(kst + (kt * 32 + r32) * 128 + (((ks * 2 + hsel) ^ sw) * 16));
         sacc[kt] = mfma_32x32x16(kf, qf[ks], sacc[kt]);
+#endif
       }
       // keep the four K fragments of the second 32-key half out of flight until the first half is consumed: the
       // kernel has to fit 128 VGPRs (4 waves per SIMD), and hoisting all eight costs 16 registers
@@ -208,8 +216,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         f32x2_t x = {sacc[kt][e], sacc[kt][e + 1]};
+#if CTRLV_ATTN_DBG == 3          // diagnostic build (timing only): no softmax arithmetic
+        f32x2_t pe = x;
+#else
         x = x * kScale + nm;
         f32x2_t pe = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#endif
         sacc[kt][e] = pe.x;
         sacc[kt][e + 1] = pe.y;
         rs2 += pe;
@@ -249,8 +261,12 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+#if CTRLV_ATTN_DBG == 4          // diagnostic build (timing only): no P.V (V fragment reads + MFMAs)
+          asm volatile("" ::"v"(pf));
+#else
           const elx8 vf = vt_frag(vst, v_off(kb, dt * 32 + vcol), v_off(kb + 8, dt * 32 + vcol));
           oacc[dt] = mfma_32x32x16(vf, pf, oacc[dt]);
+#endif
         }
       }
     }
@@ -264,10 +280,17 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 4 : 3) void attn_spatial_kernel(c
   issue(0, 0);
   if (NSLOT == 3 && nt > 1) issue(1, 1);
   for (int t = 0; t < nt_full; ++t) {
+#if CTRLV_ATTN_DBG == 1          // diagnostic build: no K/V traffic, no workgroup sync after the first tile (wrong results)
+    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("s_barrier" ::: "memory"); }
+#elif CTRLV_ATTN_DBG == 2        // diagnostic build: K/V traffic but no workgroup barrier (wrong results)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + NSLOT - 1 < nt) issue(t + NSLOT - 1, (t + NSLOT - 1) % NSLOT);
+#else
     if (NSLOT == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (t + NSLOT - 1 < nt) issue(t + NSLOT - 1, (t + NSLOT - 1) % NSLOT);
+#endif
     tile(t, std::false_type{});
   }
   if (nt_full < nt) {      // ragged last tile: separate instantiation with key masking
@@ -326,7 +349,6 @@ template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __restrict__ qkv, el_t* __restrict__ out,
                                                               float* __restrict__ lse, int S, int C) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 x (K 8 KiB | V 8 KiB) ring
-  CTRLV_CLOCK_BEGIN();
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, hsel = lane >> 5, sw = (lane >> 1) & 7;
@@ -335,9 +357,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
   // workgroups out to the XCDs round-robin).  Repeated launches of this kernel alone are 1-4 % slower with it (K / V then
   // come out of the Infinity Cache either way); inside the model, where they come from HBM beside the other stream's
   // traffic, the family is 1.5-2 % faster (42.7 -> 42.0 ms per step, three alternations).  -DCTRLV_ATTN_NO_XCD: old order.
+#ifndef CTRLV_ATTN_NO_XCD
   const int nqb = gridDim.x, nhd = gridDim.y;
   const int wg = xcd_remap((int)(blockIdx.x + nqb * (blockIdx.y + nhd * blockIdx.z)), nqb * nhd * (int)gridDim.z);
   const int qblk = wg % nqb, head = (wg / nqb) % nhd, img = wg / (nqb * nhd);
+#else
+  const int qblk = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+#endif
   const long row0 = (long)img * S;
   const int ld = 3 * C;
   const el_t* qp = qkv + head * 64;
@@ -388,7 +414,20 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[rb][dt][e] = 0.f;
   float m_run[2] = {-INFINITY, -INFINITY};
+#ifndef CTRLV_ATTN_MFMA_SUM
   float l_run[2] = {0.f, 0.f};
+#else
+  // running row sums of P' = P 2^-kPShift on the matrix pipe: lanes 0..15, elements 0 / 1 (see mfma_16x16x32)
+  f32x4v lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  elx8 ones;
+  {
+    const int m16 = lane & 15, kb = lane >> 4;
+    const bool on = (m16 == 0 && (kb & 1) == 0) || (m16 == 1 && (kb & 1) == 1);
+    const unsigned one2 = CTRLV_ELEM_DTYPE == 1 ? 0x3C003C00u : 0x3F803F80u;
+    const uint4 u = on ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
+    ones = __builtin_bit_cast(elx8, u);
+  }
+#endif
   // PRE: -m of each row block as the C operand of its score chains (+inf before the first tile: the first tile's sums
   // are inf and take the slow path, exactly as with m = -inf in the subtracting form)
   f32x16 negm[2];
@@ -422,6 +461,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
           if (SUB && ks == 0) sacc[rb][kt] = mfma_keep_c(kf, qf[rb][ks], negm[rb]);
           else sacc[rb][kt] = mfma_32x32x16(kf, qf[rb][ks], sacc[rb][kt]);
       }
+#ifdef CTRLV_ATTN64_SERIAL
+      if (kt == 0) asm volatile("" ::: "memory");   // keep the second half's K fragments out of flight (registers)
+#endif
     }
     if (MASKED) {
 #pragma unroll
@@ -442,7 +484,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
   auto exp_pack = [&](const f32x16 (&sacc)[2], elx8 (&pf)[2][2], float m, auto direct_tag) -> float {
     constexpr bool DIRECT = decltype(direct_tag)::value;
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#ifndef CTRLV_ATTN_MFMA_SUM
     const float nm = -m;
+#else
+    const float nm = -(m + kPShift);
+#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -462,10 +508,27 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
         elx8& d = pf[kt][e >> 3];
         const int o = e & 7;
         d[o] = (el_native_t)p0; d[o + 1] = (el_native_t)p1; d[o + 2] = (el_native_t)p2; d[o + 3] = (el_native_t)p3;
+#ifndef CTRLV_ATTN_MFMA_SUM
         r0 += p0; r1 += p1; r2 += p2; r3 += p3;
+#endif
       }
     return (r0 + r1) + (r2 + r3);
   };
+#ifdef CTRLV_ATTN_MFMA_SUM
+  // OR of a row block's packed P' registers: bit 14 / 30 set <=> some P' >= 2 (or inf / NaN)
+  auto p_bits = [&](const elx8 (&pf)[2][2]) -> unsigned {
+    unsigned acc = 0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const uint4 u = __builtin_bit_cast(uint4, pf[kt][st]);
+        acc |= u.x | u.y;
+        acc |= u.z | u.w;
+      }
+    return acc;
+  };
+#endif
   auto tile = [&](int t, auto masked_tag) {
     const char* kst = smem + (t % kNS64) * 16384;
     const char* vst = kst + 8192;
@@ -477,7 +540,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::integral_constant<bool, PRE>{});
     }
+#ifndef CTRLV_ATTN_MFMA_SUM
     if (!__all(rs[0] <= kSumLimit && rs[1] <= kSumLimit)) {       // slow path: see attn_spatial_kernel
+#else
+    if (__any(((p_bits(pf[0]) | p_bits(pf[1])) & 0x40004000u) != 0u)) {
+#endif
       f32x16 sacc[2][2];
       scores(kst, sacc, t, masked_tag, std::false_type{});
 #pragma unroll
@@ -491,24 +558,40 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
         const float m_new = fmaxf(m_run[rb], mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
         m_run[rb] = m_new;
+#ifndef CTRLV_ATTN_MFMA_SUM
         l_run[rb] *= alpha;
+#else
+        // the sums of queries n / n + 16 live in lane n (elements 0 / 1): fetch their rescale factors from the query lanes
+        lacc[rb][0] *= __shfl(alpha, lane & 15);
+        lacc[rb][1] *= __shfl(alpha, (lane & 15) + 16);
+#endif
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) oacc[rb][dt][e] *= alpha;
         if (PRE) {
 #pragma unroll
+#ifndef CTRLV_ATTN_MFMA_SUM
           for (int e = 0; e < 16; ++e) negm[rb][e] = -m_new;
+#else
+          for (int e = 0; e < 16; ++e) negm[rb][e] = -(m_new + kPShift);
+#endif
         }
         rs[rb] = exp_pack(sacc[rb], pf[rb], m_run[rb], std::false_type{});
       }
     }
+#ifndef CTRLV_ATTN_MFMA_SUM
     l_run[0] += rs[0];
     l_run[1] += rs[1];
+#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+#ifdef CTRLV_ATTN_MFMA_SUM
+        lacc[0] = mfma_16x16x32(ones, pf[0][kt][s], lacc[0]);
+        lacc[1] = mfma_16x16x32(ones, pf[1][kt][s], lacc[1]);
+#endif
         const int kb = kt * 32 + 16 * s + vkey;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -541,8 +624,15 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
 
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
+#ifndef CTRLV_ATTN_MFMA_SUM
     const float l_tot = half_sum(l_run[rb]);
     const float m_fin = m_run[rb];
+#else
+    // query r32's sum: lane r32 & 15, element r32 >> 4 (both key halves are already in it)
+    const float l_lo = __shfl(lacc[rb][0], r32 & 15), l_hi = __shfl(lacc[rb][1], r32 & 15);
+    const float l_tot = (r32 & 16) ? l_hi : l_lo;
+    const float m_fin = m_run[rb] + kPShift;
+#endif
     const float inv = 1.0f / l_tot;
     if (lse && qrow[rb] < S && hsel == 0)
       lse[((long)img * gridDim.y + head) * S + qrow[rb]] = m_fin + __builtin_amdgcn_logf(l_tot);
@@ -559,7 +649,6 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const el_t* __re
         }
     }
   }
-  CTRLV_CLOCK_END();
 }
 
 // ---------------------------------------------------------------------------------------------- temporal
@@ -708,8 +797,6 @@ static int attention_spatial_launch(const void* qkv, void* out, float* lse, int 
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
-
-CTRLV_CLOCK_READER(attention)
 
 extern "C" int ctrlv_attention_spatial(const void* qkv, void* out, int n_img, int S, int C, ctrlv_stream_t stream) {
   return attention_spatial_launch(qkv, out, nullptr, n_img, S, C, false, (hipStream_t)stream);

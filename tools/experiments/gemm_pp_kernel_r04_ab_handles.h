@@ -28,6 +28,12 @@
 
 #include "common.h"
 
+// s_setprio around the MFMA groups measured 0.5-1 % SLOWER than none (each is an issue slot in an issue-bound loop)
+#ifdef CTRLV_PP_PRIO
+#define PP_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PP_SETPRIO(x)
+#endif
 
 // K order (dy, 32-channel block, dx) + row-halo staging for this 3x3 conv?  One decision for every kernel that may serve
 // the layer (defined in gemm_pp_m0.hip: conv_halo_geometry() below and the CTRLV_CONV_HALO switch, default on).
@@ -109,6 +115,11 @@ __device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wb
   return __builtin_amdgcn_raw_buffer_load_b128(rsB, (lane < WTN / 4 && !zero) ? (unsigned)((wbase_n + lane * 4) * 4) : 0xFFFFFFFFu,
                                                0, 0);
 }
+// A/B handles of the epilogue's output stores (tools/ab_build.py): CTRLV_PP_STORE_AUX = cache-policy bits of the
+// buffer store (0 default, 2 = nt); CTRLV_PP_NOSTORE = compute the packed output and drop it (timing diagnosis only).
+#ifndef CTRLV_PP_STORE_AUX
+#define CTRLV_PP_STORE_AUX 0
+#endif
 // STORE-DATA HAZARD (root cause of two "intermittent wrong dword" defects).  A buffer_store_dwordx4
 // reads its four data VGPRs over several cycles AFTER it has issued; a VALU instruction that overwrites one of them within
 // the next two issue slots replaces the bytes that leave the CU, for some lanes (the ones whose quad the store has not
@@ -120,11 +131,19 @@ __device__ __forceinline__ u32x4_t pp_bias_load(const ctrlv_gemm_desc& d, int wb
 // are written out: an `s_nop 1` that takes the stored registers as operands -- the register allocator cannot hand them to
 // another value before it, the scheduler cannot move a redefinition above it.
 __device__ __forceinline__ void store_data_hazard_guard(const u32x4_t& pv) {
+#ifndef CTRLV_PP_NO_STORE_GUARD     // A/B handle: reproduces the defect (tools/ab_build.py)
   asm volatile("s_nop 1" ::"v"(pv));
+#endif
 }
 __device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff, soff, 0);
+#ifdef CTRLV_PP_NOSTORE
+  asm volatile("" ::"v"(pv), "v"(voff), "s"(soff));
+#elif defined(CTRLV_PP_STORE_L2)   // TIMING EXPERIMENT ONLY: every store lands in a window of CTRLV_PP_STORE_L2 bytes (power of two) of the output
+  __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff == 0xFFFFFFFFu ? voff : ((voff + (unsigned)soff) & (unsigned)(CTRLV_PP_STORE_L2 - 16)), 0, 0);
+#else
+  __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff, soff, CTRLV_PP_STORE_AUX);
   store_data_hazard_guard(pv);
+#endif
 }
 
 template <int WTN>
@@ -560,9 +579,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // single-kernel sweeps of round 1, but inside the model 4 of 5 is the faster one (234.5 -> 233.2 ms per step, three
   // alternations on one device; 1 of 5: 243 ms): repeated launches of one kernel flatter whatever leans on the caches.
   constexpr int NPIECE = A_Q + B_Q;
+#ifdef CTRLV_PP_NL
+  constexpr int NL = CTRLV_PP_NL < NPIECE ? CTRLV_PP_NL : NPIECE - 1;
+#else
+#ifdef CTRLV_PP_NL_HALO      // A/B handle of the row-halo kernels alone
+  constexpr int NL = HALO ? (CTRLV_PP_NL_HALO < NPIECE ? CTRLV_PP_NL_HALO : NPIECE - 1)
+                          : (BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q));
+#else
   constexpr int NL = HALO ? NPIECE - 1 : (BN == 256 ? A_Q + 1 : (BN == 320 ? A_Q + 2 : A_Q));
+#endif
+#endif
   constexpr int NC = NPIECE - NL;                            // pieces issued in the compute phase
-  static_assert(NL >= 0 && NL < NPIECE, "piece placement out of range");
+  static_assert(NL >= 0 && NL < NPIECE, "CTRLV_PP_NL out of range");
   // When B_TOT is not a multiple of the wave count (320-wide: 20 pieces, 8 waves) the waves without a real last piece
   // issue a DUMMY one -- out-of-range source (zeros, no memory traffic) into a private 1-KiB scratch strip -- so that
   // every wave has exactly NPIECE loads per half-step and the counted vmcnt waits need no per-wave cases.
@@ -578,7 +606,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   constexpr int TAB_OFF = P3_OFF + (OWN_P3 ? NW * 1024 : 0);      // Phi table of the GEGLU epilogue (common.h)
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 ring slots | 8 bias strips | dummy piece | P3 | Phi
-  CTRLV_CLOCK_BEGIN();
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -819,6 +846,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
       }
       return;
     }
+#ifdef CTRLV_CONV_BLOCK_MAJOR
+    if (MODE != 0) {
+      if (is_cc & 32) {
+        ++is_tap;
+        if (is_tap == d.taps) { is_tap = 0; is_cc += 32; } else { is_cc -= 32; }
+      } else {
+        is_cc += 32;
+      }
+      return;
+    }
+#endif
     is_cc += 32;
     if (MODE != 0 && is_cc == d.Cin) { is_cc = 0; ++is_tap; }   // (plain GEMM: one tap, next_tile() rewinds)
   };
@@ -953,7 +991,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     // (half-steps g+1 of the new tile) were issued BEFORE that epilogue: its NSTORE stores are newer and may stay in
     // flight -- with the steady-state count the wave would sit here until the tile's output has been acknowledged by
     // HBM (stamps: 300-550 cycles per half-step on the K = 320 layers, averaged over the tile's ten).
+#ifdef CTRLV_PP_NO_EPI_VMCNT       // A/B handle (tools/ab_build.py)
+    if (false) {}
+#else
     if (MAY_BE_FIRST && after_epi && j < 2) wait_vmcnt<NPIECE + NL + NSTORE>();
+#endif
     else wait_vmcnt<NPIECE + NL>();
     STAMP(t2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -975,6 +1017,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
 #pragma unroll
     for (int grpi = 0; grpi < 4; ++grpi) {
       const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
+      PP_SETPRIO(1);
       if (MAY_BE_FIRST && j == 0 && ks == 0) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
@@ -990,6 +1033,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
           for (int n = 0; n < TN; ++n)
             acc[i][n] = mfma_32x32x16(wf[n][ks], af[i][ks], acc[i][n]);
       }
+      PP_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NC; ++k)
@@ -1123,7 +1167,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   // the issue stream ran three half-steps past the end (zero-filled pieces): nothing may be in flight when the
   // workgroup's LDS is released
   wait_vmcnt<0>();
-  CTRLV_CLOCK_END();
 #ifdef CTRLV_PP_STAMP
   STAMP(t_end);
   if (lane == 0 && d.V != nullptr && d.vmode == 0) {
