@@ -207,12 +207,17 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
 
   f32x4v acc[TM][TN];
   int g = 0;
+#ifdef CTRLV_PP_STAMP
+  unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
+  STAMP(t_begin);
+#endif
   if (grp == 1) raw_barrier();                                // stagger: group 1 runs one barrier slot behind
 
   bool after_epi = false;
   auto half_step = [&](bool first, bool early) {
     const char* st = smem + (g & (NH - 1)) * SLOT;
     elx8 af[TM], wf[TN];
+    STAMP(t0);
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
       if constexpr (GEGLU) {                                  // (value even, value odd, gate even, gate odd)
@@ -228,9 +233,18 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     if constexpr (ODD) wf[TN - 1] = *(const elx8*)(st + wL_frag);
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = *(const elx8*)(st + a_frag + i * 16 * 64);
+    STAMP(t1);
     issue(g + 3);
+    STAMP(t1b);
     wait_next(early && after_epi);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(t2b);
     lds_done_barrier();
+    STAMP(t3);
+    STAMP_ADD(c_lread, t0, t1);
+    STAMP_ADD(c_lissue, t1, t1b);
+    STAMP_ADD(c_lwait, t1b, t2b);
+    STAMP_ADD(c_lbar, t2b, t3);
     __builtin_amdgcn_sched_barrier(0);
     if (first) {
 #pragma unroll
@@ -244,7 +258,11 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
         for (int n = 0; n < TN; ++n) acc[i][n] = mfma_16x16x32(wf[n], af[i], acc[i][n]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(t4);
     raw_barrier();
+    STAMP(t5);
+    STAMP_ADD(c_mfma, t3, t4);
+    STAMP_ADD(c_cbar, t4, t5);
   };
 
   for (int tr = 0; tr < my_ntiles; ++tr) {
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     for (int j = J - 3; j < J; ++j, ++g) half_step(false, J == 4 && j == 1);
     // tile boundary: the two groups' epilogues run concurrently (gemm_pp_kernel.h)
     if (grp == 0) raw_barrier();
+    STAMP(t6);
     {
       constexpr int kFlags = 0x00020000;
       int lane_e = lane;
@@ -397,10 +416,20 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
       }
     }
     after_epi = true;
+    STAMP(t7);
+    STAMP_ADD(c_epi, t6, t7);
     if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
   }
   wait_vmcnt<0>();
   CTRLV_CLOCK_END();
+#ifdef CTRLV_PP_STAMP     // (diagnostic build, tools/gemm_stamp.py: the ping-pong kernel's record format, 16 waves per workgroup)
+  STAMP(t_end);
+  if (lane == 0 && d.V != nullptr && d.vmode == 0) {
+    unsigned long long* o = (unsigned long long*)d.V + ((long)blockIdx.x * NW + wid) * 10;
+    o[0] = t_end - t_begin; o[1] = c_lread; o[2] = c_lissue; o[3] = c_lwait; o[4] = c_lbar; o[5] = c_mfma;
+    o[6] = c_cbar; o[7] = c_epi; o[8] = (unsigned long long)my_ntiles * J; o[9] = (unsigned long long)my_ntiles;
+  }
+#endif
 #endif
 }
 

@@ -62,7 +62,7 @@ def main():
         geglu = 1 if "geglu" in name else 0
         out = torch.empty(M, N // 2 if geglu else N, dtype=torch.bfloat16, device=dev)
         R1 = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if r1 else None
-        stamps = torch.zeros(256 * 8 * 10, dtype=torch.int64, device=dev)
+        stamps = torch.zeros(256 * 16 * 10, dtype=torch.int64, device=dev)
         d = _lib.GemmDesc()
         d.A, d.W, d.out, d.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr()
         d.R1 = R1.data_ptr() if r1 else None
