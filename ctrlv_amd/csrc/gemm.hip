@@ -369,7 +369,9 @@ static int w16_tile_of(const ctrlv_gemm_desc& d) {
   if (on < 0) { const char* e = getenv("CTRLV_W16"); on = e ? atoi(e) : 1; }
   if (!on || d.mode != 0) return 0;
   int tile = 0;
-  if (d.geglu) tile = (d.Cin >= 640 && d.N % 256 == 0) ? 12 : 0;      // the C = 640 / 1280 GEGLU projections
+  // in-model A/B (tools/shape_table.py, two alternations on one device, profiles/r05_w16_in_model_ab.txt): the C = 1280 GEGLU
+  // projections 14.2 -> 13.35 ms per step (-5.7 %), the C = 640 one 15.97 -> 16.48 ms (+3.2 %: stays on the ping-pong tile)
+  if (d.geglu) tile = (d.Cin >= 1280 && d.N % 256 == 0) ? 12 : 0;
   if (tile && !ctrlv_gemm_w16_supports(d, tile)) tile = 0;           // (raw_out, odd pitches ...: shape-level conditions too)
   return tile;
 }
@@ -472,7 +474,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
-  if (d.tile == 12 || d.tile == 13) return ctrlv_gemm_launch_w16(d, d.tile, stream);
+  if (d.tile >= 12 && d.tile <= 15) return ctrlv_gemm_launch_w16(d, d.tile, stream);
   if (d.tile == 0) {
     const int w16 = w16_tile_of(d);
     if (w16) return ctrlv_gemm_launch_w16(d, w16, stream);
