@@ -115,9 +115,12 @@ SIGNATURES = {
     "ctrlv_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                      c_float, c_void_p, c_void_p]),
     "ctrlv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p]),
-    "ctrlv_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
-    "ctrlv_dot_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "ctrlv_gemm_wgrad_scratch_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
+    "ctrlv_gemm_wgrad": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    "ctrlv_colsum_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ctrlv_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctrlv_dot_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
     "ctrlv_groupnorm_bwd_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

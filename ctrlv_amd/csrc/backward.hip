@@ -36,6 +36,7 @@ __device__ __forceinline__ elx8 tr_frag(const char* tile, int kb, int cb, int la
 
 struct WgradArgs {
   const el_t* A; const el_t* A2; const el_t* dY; float* dW; float* dbias; float scale; int torch_layout;
+  float* part;        // deterministic mode: slab partials [slabs][N][Ktot] fp32 (+ [slabs][N] bias sums behind them), else null
   int M, N, Cin, taps, lda, lda2, c_split, ldy, mode, H, Wd, Ho, Wo, stride, up, F, S, rows_per_slab;
 };
 
@@ -158,6 +159,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         const int tp = (int)(k / a.Cin);
         col = (k - (long)tp * a.Cin) * a.taps + tp;
       }
+      if (a.part) {     // deterministic: this workgroup's own tile of its slab's partial matrix (packed K order, unscaled)
+        float* ps = a.part + (long)blockIdx.z * a.N * ktot;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (n < a.N) ps[(long)n * ktot + k] = acc[i][j][e];
+        }
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -174,8 +184,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
-      atomicAdd(a.dbias + n0 + tid, t * a.scale);
+      if (a.part) a.part[(long)gridDim.z * a.N * ktot + (long)blockIdx.z * a.N + n0 + tid] = t;
+      else atomicAdd(a.dbias + n0 + tid, t * a.scale);
     }
+  }
+}
+
+// Deterministic wgrad, second kernel: dW (+ dbias) += scale * the slab partials summed IN SLAB ORDER, one thread per (n, 4 k)
+// -- a single writer per element, so the accumulated gradient has the same bits in every run (the atomics of the one-kernel
+// form arrive in a different order every time).  Also does the [N][Cin][taps] scatter of torch_layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int N, long ktot, int Cin,
+                                                           int taps, int torch_layout, float scale, float* __restrict__ dW,
+                                                           float* __restrict__ dbias) {
+  const long k4 = ktot >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (long)N * k4) {
+    const long n = idx / k4, k = (idx - n * k4) * 4;
+    const float* p = part + n * ktot + k;
+    float4 a = *(const float4*)p;
+    for (int sidx = 1; sidx < slabs; ++sidx) {
+      const float4 b = *(const float4*)(p + (long)sidx * N * ktot);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (!torch_layout) {
+      float4* o = (float4*)(dW + n * ktot + k);
+      float4 v = *o;
+      v.x += a.x * scale; v.y += a.y * scale; v.z += a.z * scale; v.w += a.w * scale;
+      *o = v;
+    } else {
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long kk = k + e;
+        const int tp = (int)(kk / Cin);
+        dW[n * ktot + (kk - (long)tp * Cin) * taps + tp] += av[e] * scale;
+      }
+    }
+  }
+  if (dbias && idx < N) {
+    const float* pb = part + (long)slabs * N * ktot;
+    float t = 0.f;
+    for (int sidx = 0; sidx < slabs; ++sidx) t += pb[(long)sidx * N + idx];
+    dbias[idx] += t * scale;
   }
 }
 
@@ -183,9 +233,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // 64 column groups of 8 (16-B loads) x 4 row lanes per workgroup; the row lanes are folded through LDS so that a
 // workgroup issues ONE atomic per column (same-address float atomics execute serially at the memory side: the first
 // version -- one column per thread, 2-B loads, an atomic per 256 rows -- cost 124 us per call on average).
+// `part` (deterministic mode, non-null): the block writes its sums to part[blockIdx.y][N] instead (the launcher makes
+// rows_per_block divide vdiv, so a block never straddles two table rows) and colsum_reduce_kernel adds them in block order.
 __global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x, int M, int N, int ldx, int rows_per_block,
                                                      int vmode, int vdiv, int vmod, float scale, float* __restrict__ out,
-                                                     int ldo) {
+                                                     int ldo, float* __restrict__ part) {
   __shared__ float red[4][64][8];
   __shared__ int red_idx[4];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -196,8 +248,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x,
   int cur = -1;
   auto flush = [&](int idx) {
     if (idx >= 0 && col_ok) {
+      if (part) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(out + (long)idx * ldo + n0 + e, acc[e] * scale);
+        for (int e = 0; e < 8; ++e) part[(long)blockIdx.y * N + n0 + e] = acc[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(out + (long)idx * ldo + n0 + e, acc[e] * scale);
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -232,11 +289,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x,
     flush(cur);
   }
 }
+// out[idx(b)][n] += scale * sum over the blocks b of table row idx, in block order (single writer per element)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int rows_per_block, int N,
+                                                            int vmode, int vdiv, int vmod, float scale, float* __restrict__ out,
+                                                            int ldo) {
+  const int n = blockIdx.x * 256 + threadIdx.x, idx = blockIdx.y;
+  if (n >= N) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    const int bi = vmode ? (int)(((long)b * rows_per_block / vdiv) % vmod) : 0;
+    if (bi == idx) t += part[(long)b * N + n];
+  }
+  out[(long)idx * ldo + n] += t * scale;
+}
 
 // out[0] += scale * sum_i dy[i] * (p[i] - q[i])      (gradient of a folded AlphaBlender's mixing weight)
 __global__ __launch_bounds__(256) void dot_diff_kernel(const el_t* __restrict__ dy, const el_t* __restrict__ p,
                                                        const el_t* __restrict__ q, size_t n, float scale,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ part) {
   __shared__ float red[4];
   float acc = 0.f;
   const size_t nv = n >> 3;
@@ -255,7 +325,17 @@ __global__ __launch_bounds__(256) void dot_diff_kernel(const el_t* __restrict__ 
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+  if (threadIdx.x == 0) {
+    if (part) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];       // deterministic: summed in block order below
+    else atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+  }
+}
+__global__ __launch_bounds__(64) void dot_diff_reduce_kernel(const float* __restrict__ part, int nblocks, float scale,
+                                                             float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double t = 0.0;
+  for (int b = 0; b < nblocks; ++b) t += (double)part[b];
+  out[0] += (float)t * scale;
 }
 
 // ------------------------------------------------------------------------------------------------ GroupNorm backward
@@ -343,8 +423,9 @@ __global__ __launch_bounds__(256) void gn_bwd_group_kernel(GnB s, const float* _
 }
 // pass 2b: dgamma[c] += sum s1, dbeta[c] += sum s2 over every (image, chunk): 64 channels x 4 row lanes per workgroup,
 // gridDim.y row groups, one atomic per channel per workgroup            grid (ceil(C/64), <= 16)
-__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnB s, const float* __restrict__ part, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+// (round 5: no atomics -- every row group writes its own [2][C] slice of `lvl2`, gn_bwd_affine_fold_kernel adds the slices
+//  in order: the parameter gradients are bit-reproducible)
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnB s, const float* __restrict__ part, float* __restrict__ lvl2) {
   __shared__ float red[4][64][2];
   const int tx = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -360,9 +441,19 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnB s, const float* 
   red[rl][tx][1] = a2;
   __syncthreads();
   if (rl == 0 && c < s.C) {
-    atomicAdd(dgamma + c, red[0][tx][0] + red[1][tx][0] + red[2][tx][0] + red[3][tx][0]);
-    atomicAdd(dbeta + c, red[0][tx][1] + red[1][tx][1] + red[2][tx][1] + red[3][tx][1]);
+    lvl2[((long)blockIdx.y * 2) * s.C + c] = red[0][tx][0] + red[1][tx][0] + red[2][tx][0] + red[3][tx][0];
+    lvl2[((long)blockIdx.y * 2 + 1) * s.C + c] = red[0][tx][1] + red[1][tx][1] + red[2][tx][1] + red[3][tx][1];
   }
+}
+// out0[c] += sum_g lvl2[g][0][c], out1[c] += sum_g lvl2[g][1][c]   (groups in order; one thread per column: single writer)
+__global__ __launch_bounds__(256) void affine_fold_kernel(const float* __restrict__ lvl2, int groups, int C, float* __restrict__ out0,
+                                                          float* __restrict__ out1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < groups; ++g) { a += lvl2[((long)g * 2) * C + c]; b += lvl2[((long)g * 2 + 1) * C + c]; }
+  out0[c] += a;
+  out1[c] += b;
 }
 // pass 3: dx = rstd * (dz * gamma - m1 - xhat * m2)
 __global__ void gn_bwd_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, GnB s,
@@ -494,7 +585,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const el_t* __restrict__ x,
 
 // out0[c] += sum_r part[r][c], out1[c] += sum_r part[r][C + c]: 64 columns x 4 row lanes per workgroup, gridDim.y row groups
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int rows, int C,
-                                                            float* __restrict__ out0, float* __restrict__ out1) {
+                                                            float* __restrict__ lvl2) {
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   float s = 0.f;
@@ -504,7 +595,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   __syncthreads();
   if (rl == 0 && col < 2 * C) {
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(col < C ? out0 + col : out1 + (col - C), s);
+    lvl2[(long)blockIdx.y * 2 * C + col] = s;             // (row group g: [dgamma C | dbeta C]; folded in order, no atomics)
   }
 }
 
@@ -543,7 +634,10 @@ static long ln_bwd_blocks(int M) {
   long blocks = ((long)M + 3) / 4;
   return blocks > 256 * 4 ? 256 * 4 : blocks;
 }
-extern "C" size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C) { return (size_t)ln_bwd_blocks(M) * 4 * 2 * (size_t)C; }
+constexpr int kFoldGroups = 16;       // row groups of the parameter-gradient folds (level-2 slices behind the level-1 partials)
+extern "C" size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C) {
+  return (size_t)ln_bwd_blocks(M) * 4 * 2 * (size_t)C + (size_t)kFoldGroups * 2 * (size_t)C;
+}
 
 extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V,
                                    int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch,
@@ -565,9 +659,11 @@ extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, 
   }
 #undef LNB_LAUNCH
   CTRLV_LAUNCH_CHECK();
-  const int rows = (int)blocks * 4;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64, rows >= 64 ? 16 : 1), dim3(256), 0, st, scratch, rows, C,
-                     dgamma, dbeta);
+  const int rows = (int)blocks * 4, groups = rows >= 64 ? kFoldGroups : 1;
+  float* lvl2 = scratch + (size_t)rows * 2 * C;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64, groups), dim3(256), 0, st, scratch, rows, C, lvl2);
+  CTRLV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(affine_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, lvl2, groups, C, dgamma, dbeta);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }
@@ -583,8 +679,26 @@ extern "C" int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I,
   return CTRLV_OK;
 }
 
+// M slabs of a wgrad launch: enough to fill the chip (two workgroups per CU), each a multiple of 64 rows
+static int wgrad_slabs(const ctrlv_gemm_desc& d, int* rows_per_slab) {
+  const int ktiles = (d.taps * d.Cin + 255) / 256, ntiles = (d.N + 127) / 128;
+  int slabs = 512 / (ktiles * ntiles);
+  if (slabs < 1) slabs = 1;
+  int rps = ((d.M + slabs - 1) / slabs + 63) / 64 * 64;
+  if (rps < 64) rps = 64;
+  *rows_per_slab = rps;
+  return (d.M + rps - 1) / rps;
+}
+
+extern "C" size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* dp) {
+  if (!dp || dp->M <= 0 || dp->N <= 0 || dp->Cin <= 0 || dp->taps <= 0) return 0;
+  int rps;
+  const int slabs = wgrad_slabs(*dp, &rps);
+  return (size_t)slabs * ((size_t)dp->N * dp->taps * dp->Cin + dp->N) * sizeof(float);
+}
+
 extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, float* dbias, float scale,
-                                int torch_layout, ctrlv_stream_t stream) {
+                                int torch_layout, void* scratch, size_t scratch_bytes, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dp && dY && dW, "gemm_wgrad: null pointer");
   const ctrlv_gemm_desc& d = *dp;
   CTRLV_CHECK_ARG(d.A != nullptr, "gemm_wgrad: A must be non-null");
@@ -599,47 +713,85 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   a.mode = d.mode; a.H = d.H; a.Wd = d.Wd; a.Ho = d.Ho; a.Wo = d.Wo; a.stride = d.stride ? d.stride : 1; a.up = d.up;
   a.F = d.F; a.S = d.S;
   const int ktiles = (d.taps * d.Cin + 255) / 256, ntiles = (d.N + 127) / 128;
-  // enough M slabs to fill the chip (two workgroups per CU), each a multiple of 64 rows
-  int slabs = 512 / (ktiles * ntiles);
-  if (slabs < 1) slabs = 1;
-  int rps = ((d.M + slabs - 1) / slabs + 63) / 64 * 64;
-  if (rps < 64) rps = 64;
-  slabs = (d.M + rps - 1) / rps;
+  int rps;
+  const int slabs = wgrad_slabs(d, &rps);
   a.rows_per_slab = rps;
   CTRLV_CHECK_SHAPE(slabs <= 65535 && ktiles <= 65535, "gemm_wgrad: grid too large");
+  // scratch given: DETERMINISTIC -- slab partials with plain stores, then an ordered sum (wgrad_reduce_kernel); without it
+  // the slabs add into dW with fp32 atomics (order varies from run to run)
+  a.part = nullptr;
+  if (scratch) {
+    CTRLV_CHECK_ARG(scratch_bytes >= ctrlv_gemm_wgrad_scratch_bytes(dp), "gemm_wgrad: scratch smaller than ctrlv_gemm_wgrad_scratch_bytes()");
+    CTRLV_CHECK_SHAPE((d.taps * d.Cin) % 4 == 0, "gemm_wgrad: K must be a multiple of 4");
+    a.part = (float*)scratch;
+  }
   hipLaunchKernelGGL(wgrad_kernel, dim3(ntiles, ktiles, slabs), dim3(256), 0, (hipStream_t)stream, a);
   CTRLV_LAUNCH_CHECK();
+  if (a.part) {
+    const long ktot = (long)d.taps * d.Cin, n_thr = (long)d.N * (ktot >> 2);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, slabs,
+                       d.N, ktot, d.Cin, d.taps, torch_layout, scale, dW, dbias);
+    CTRLV_LAUNCH_CHECK();
+  }
   return CTRLV_OK;
 }
 
+// rows per block of a colsum launch; deterministic mode: a divisor of vdiv, so that a block never straddles two table rows
+static int colsum_rpb(int M, int vmode, int vdiv, bool det) {
+  int rpb = M >= (1 << 18) ? 1024 : (M >= (1 << 14) ? 256 : 64);           // >= ~225 workgroups per 512 columns at L0
+  if (det && vmode) {
+    while (rpb > 4 && vdiv % rpb != 0) rpb >>= 1;
+    if (vdiv % rpb != 0) rpb = 0;                                          // (odd row groups: not served deterministically)
+  }
+  return rpb;
+}
+extern "C" size_t ctrlv_colsum_scratch_floats(int M, int N, int vmode, int vdiv) {
+  const int rpb = colsum_rpb(M, vmode, vdiv, true);
+  return rpb > 0 ? (size_t)((M + rpb - 1) / rpb) * (size_t)N : 0;
+}
+
 extern "C" int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out,
-                            int ldo, ctrlv_stream_t stream) {
+                            int ldo, float* scratch, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && out, "colsum: null pointer");
   CTRLV_CHECK_SHAPE(M > 0 && N > 0 && N % 8 == 0 && ldx >= N && ldx % 8 == 0, "colsum: N and ldx must be multiples of 8");
   CTRLV_CHECK_ARG(vmode == 0 || (vmode == 1 && vdiv > 0 && vmod > 0), "colsum: vmode must be 0 or 1 with vdiv, vmod > 0");
-  const int rpb = M >= (1 << 18) ? 1024 : (M >= (1 << 14) ? 256 : 64);      // >= ~225 workgroups per 512 columns at L0
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
-                     (const el_t*)x, M, N, ldx, rpb, vmode, vdiv, vmod, scale, out, ldo);
+  // scratch (ctrlv_colsum_scratch_floats) given: DETERMINISTIC -- per-block sums, then an ordered add (no atomics)
+  const int rpb = colsum_rpb(M, vmode, vdiv, scratch != nullptr);
+  CTRLV_CHECK_SHAPE(rpb > 0, "colsum: deterministic mode needs a row-group size vdiv=%d divisible by a power of two >= 4", vdiv);
+  const int nblocks = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, nblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const el_t*)x, M, N, ldx, rpb, vmode, vdiv, vmod, scale, out, ldo, scratch);
   CTRLV_LAUNCH_CHECK();
+  if (scratch) {
+    const int n_idx = vmode ? (int)(((long)(M - 1) / vdiv + 1) < vmod ? ((long)(M - 1) / vdiv + 1) : vmod) : 1;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256, n_idx), dim3(256), 0, (hipStream_t)stream, scratch, nblocks, rpb, N,
+                       vmode, vdiv, vmod, scale, out, ldo);
+    CTRLV_LAUNCH_CHECK();
+  }
   return CTRLV_OK;
 }
 
 extern "C" int ctrlv_dot_diff(const void* dy, const void* p, const void* q, size_t n, float scale, float* out,
-                              ctrlv_stream_t stream) {
+                              float* scratch, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dy && p && q && out, "dot_diff: null pointer");
   size_t blocks = (n / 8 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
+  // scratch (1024 floats) given: DETERMINISTIC -- per-block sums, added in block order by one thread
   hipLaunchKernelGGL(dot_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const el_t*)dy,
-                     (const el_t*)p, (const el_t*)q, n, scale, out);
+                     (const el_t*)p, (const el_t*)q, n, scale, out, scratch);
   CTRLV_LAUNCH_CHECK();
+  if (scratch) {
+    hipLaunchKernelGGL(dot_diff_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (int)blocks, scale, out);
+    CTRLV_LAUNCH_CHECK();
+  }
   return CTRLV_OK;
 }
 
 extern "C" int ctrlv_groupnorm_bwd_scratch_floats(int n_img, int S, int C, int imgs_per_stat) {
   const int chunks = ctrlv_groupnorm_chunks(n_img, S, C, imgs_per_stat);
   if (chunks < 0) return chunks;
-  const long need = (long)n_img * chunks * C * 2 + (long)(n_img / imgs_per_stat) * 64;
+  const long need = (long)n_img * chunks * C * 2 + (long)(n_img / imgs_per_stat) * 64 + (long)kFoldGroups * 2 * C;
   CTRLV_CHECK_SHAPE(need < (1L << 31), "groupnorm_bwd: scratch too large");
   return (int)need;
 }
@@ -666,7 +818,11 @@ extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int
   CTRLV_LAUNCH_CHECK();
   {
     const long tot = (long)n_img * s.n_chunks;
-    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 63) / 64, tot >= 64 ? 16 : 1), dim3(256), 0, st, s, part, dgamma, dbeta);
+    const int groups = tot >= 64 ? kFoldGroups : 1;
+    float* lvl2 = gmean + (size_t)(n_img / imgs_per_stat) * 64;
+    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, s, part, lvl2);
+    CTRLV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(affine_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, lvl2, groups, C, dgamma, dbeta);
   }
   CTRLV_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, n_img), dim3(nt), 0, st, (const el_t*)x, (const el_t*)dy, s, stats,

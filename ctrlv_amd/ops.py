@@ -32,6 +32,22 @@ def _need_gpu(t, name="tensor"):
         raise _lib.CtrlvHipError(f"ctrlv_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
 
 
+# Parameter-gradient reductions of the training step (wgrad, bias / row-vector column sums, the mixing-weight dot product):
+# True = ordered sums through scratch buffers (bit-reproducible gradients), False = fp32 atomics.
+DETERMINISTIC = __import__("os").environ.get("CTRLV_DETERMINISTIC", "1") != "0"
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes, tag):
+    """Reduction scratch, one buffer per (device, stream, purpose), grown on demand (launches of a stream are ordered)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=None, temporal=None, dbias=None, scale=1.0,
                torch_layout=False):
     """dW[N, taps*cin] (fp32, packed tap-major K order) += scale * dY^T . gather(A) for the forward GEMM of the same
@@ -48,8 +64,14 @@ def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=No
         d.H, d.Wd, d.Ho, d.Wo, d.stride, d.up = conv
     if temporal is not None:
         d.F, d.S = temporal
-    check(_L(A, dY).ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
-                                       1 if torch_layout else 0, _stream()), "ctrlv_gemm_wgrad")
+    lib = _L(A, dY)
+    # deterministic by default (DETERMINISTIC = False: fp32 atomics, arrival order): slab partials + an ordered sum
+    scratch, nbytes = None, 0
+    if DETERMINISTIC:
+        nbytes = lib.ctrlv_gemm_wgrad_scratch_bytes(ctypes.byref(d))
+        scratch = _scratch(A.device, nbytes, "wgrad")
+    check(lib.ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
+                               1 if torch_layout else 0, _p(scratch), nbytes, _stream()), "ctrlv_gemm_wgrad")
     return dW
 
 
@@ -79,14 +101,22 @@ def pack_weight(weight, form=0, geglu=False, dtype=torch.bfloat16):
 def colsum(x, out, vmode=0, vdiv=1, vmod=1, scale=1.0):
     """out[idx(m), :N] += scale * sum_m x[m, :]  (fp32, atomics): bias gradients (vmode 0) / per-clip row-vector gradients."""
     _need_gpu(x, "x")
-    check(_L(x).ctrlv_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), vmode, vdiv, vmod, float(scale), _p(out),
-                                   out.stride(0) if out.dim() > 1 else x.shape[1], _stream()), "ctrlv_colsum")
+    lib = _L(x)
+    scratch = None
+    if DETERMINISTIC:
+        nfl = lib.ctrlv_colsum_scratch_floats(x.shape[0], x.shape[1], vmode, vdiv)
+        if nfl:
+            scratch = _scratch(x.device, nfl * 4, "colsum")
+    check(lib.ctrlv_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), vmode, vdiv, vmod, float(scale), _p(out),
+                           out.stride(0) if out.dim() > 1 else x.shape[1], _p(scratch), _stream()), "ctrlv_colsum")
     return out
 
 
 def dot_diff(dy, p, q, out, scale=1.0):
     _need_gpu(dy, "dy")
-    check(_L(dy).ctrlv_dot_diff(_p(dy), _p(p), _p(q), dy.numel(), float(scale), _p(out), _stream()), "ctrlv_dot_diff")
+    scratch = _scratch(dy.device, 4096, "dot_diff") if DETERMINISTIC else None
+    check(_L(dy).ctrlv_dot_diff(_p(dy), _p(p), _p(q), dy.numel(), float(scale), _p(out), _p(scratch), _stream()),
+          "ctrlv_dot_diff")
     return out
 
 

@@ -278,9 +278,13 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
  * [N][taps*Cin] in the packed (tap-major) K order -- or, with torch_layout = 1, [N][Cin][taps], the layout of the
  * nn.Conv2d / nn.Conv3d / nn.Linear parameter itself -- accumulated with atomics: zero it first.  dbias (fp32 [N], or
  * NULL) += scale * column sums of dY, computed by the workgroups that stream dY anyway; dW is scaled by `scale` too
- * (the forward's s_acc). */
+ * (the forward's s_acc).
+ * scratch (ctrlv_gemm_wgrad_scratch_bytes(fwd) bytes, or NULL): with it the launch is DETERMINISTIC -- the row slabs write
+ * fp32 partial matrices with plain stores and a second kernel adds them to dW / dbias in slab order (a single writer per
+ * element): the same gradient bits in every run.  Without it the slabs add with fp32 atomics (arrival order). */
+size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* fwd);
 int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float* dW, float* dbias, float scale,
-                     int torch_layout, ctrlv_stream_t stream);
+                     int torch_layout, void* scratch, size_t scratch_bytes, ctrlv_stream_t stream);
 /* One-kernel packing of a PyTorch-layout parameter (fp32 / fp16 / bf16: src_dtype 0 / 1 / 2; [N][C][taps] contiguous:
  * nn.Linear taps 1, Conv2d 3x3 taps 9, Conv3d (3,1,1) taps 3) into the bf16 GEMM layouts -- what a training step does
  * to every trainable weight every step.  form 0: the forward layout dst[n][tap*C + c] (geglu: rows in the packed
@@ -289,15 +293,20 @@ int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float*
 int ctrlv_pack_weight(const void* src, int src_dtype, int N, int C, int taps, int form, int geglu, void* dst, int ld_dst,
                       ctrlv_stream_t stream);
 /* out[idx(m)][n] += scale * x[m][n] summed over rows; idx = 0 (vmode 0: bias gradient) or (m / vdiv) % vmod (vmode 1: the
- * gradient of a per-clip row-vector operand V).  x bf16 [M][ldx], out fp32 [*][ldo], accumulated with atomics. */
+ * gradient of a per-clip row-vector operand V).  x bf16 [M][ldx], out fp32 [*][ldo], accumulated -- with atomics, or,
+ * given `scratch` (ctrlv_colsum_scratch_floats floats; 0 = this row grouping has no deterministic form), per-block sums
+ * added in block order: bit-reproducible. */
+size_t ctrlv_colsum_scratch_floats(int M, int N, int vmode, int vdiv);
 int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int vdiv, int vmod, float scale, float* out, int ldo,
-                 ctrlv_stream_t stream);
+                 float* scratch, ctrlv_stream_t stream);
 /* out[0] += scale * sum_i dy[i] * (p[i] - q[i]) over n bf16 elements: the gradient of a folded AlphaBlender's mixing
- * weight (out = xs + (1 - a) * h  =>  dL/da = -sum dy * (out - xs) / (1 - a)). */
-int ctrlv_dot_diff(const void* dy, const void* p, const void* q, size_t n, float scale, float* out, ctrlv_stream_t stream);
+ * weight (out = xs + (1 - a) * h  =>  dL/da = -sum dy * (out - xs) / (1 - a)).  scratch: 1024 floats (deterministic: block
+ * sums added in order) or NULL (one atomic per block). */
+int ctrlv_dot_diff(const void* dy, const void* p, const void* q, size_t n, float scale, float* out, float* scratch,
+                   ctrlv_stream_t stream);
 /* GroupNorm(32)(+SiLU) backward on channels-last rows.  `fwd_partials` is the buffer ctrlv_groupnorm_stats filled for
- * the same x (its (mean, rstd) table is reused); dx bf16; dgamma / dbeta fp32 [C], ACCUMULATED; scratch fp32 of
- * ctrlv_groupnorm_bwd_scratch_floats() elements. */
+ * the same x (its (mean, rstd) table is reused); dx bf16; dgamma / dbeta fp32 [C], ACCUMULATED (ordered two-level sums, no
+ * atomics: bit-reproducible); scratch fp32 of ctrlv_groupnorm_bwd_scratch_floats() elements. */
 int ctrlv_groupnorm_bwd_scratch_floats(int n_img, int S, int C, int imgs_per_stat);
 int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, int imgs_per_stat,
                         const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,

@@ -60,6 +60,44 @@ def test_wgrad_linear_and_colsum(ops, M, N, K):
     assert parity_err(dV, ref, "row-vector grad") < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,taps", [(20000, 320, 320, 1), (9000, 128, 64, 9), (50000, 64, 64, 1)])
+def test_parameter_gradient_reductions_are_bit_reproducible(ops, M, N, K, taps):
+    """wgrad (incl. the fused bias gradient and the [N][Cin][taps] scatter), colsum (bias and per-clip row-vector form) and
+    dot_diff: slab / block partials added in a fixed order -- the same bits in every run (the atomics of
+    the one-kernel forms arrive in a different order every time), and the same values as the atomic forms."""
+    assert ops.DETERMINISTIC
+    H = W = 0
+    if taps == 9:
+        n, H, W = 3, 50, 60
+        M = n * H * W
+    A, dY = bf(torch.randn(M, K, generator=g(1))).to(DEV), bf(torch.randn(M, N, generator=g(2))).to(DEV)
+    kw = dict(N=N, cin=K, taps=taps, mode=1 if taps == 9 else 0, conv=(H, W, H, W, 1, 0) if taps == 9 else None)
+
+    def grads(torch_layout):
+        dW = torch.zeros(N, K, taps, dtype=torch.float32, device=DEV) if torch_layout else torch.zeros(N, taps * K, dtype=torch.float32, device=DEV)
+        db = torch.zeros(N, dtype=torch.float32, device=DEV)
+        for _ in range(2):                                      # accumulates: two calls into the same buffers
+            ops.gemm_wgrad(A, dY, dW, dbias=db, scale=0.5, torch_layout=torch_layout, **kw)
+        dV = torch.zeros(4, N, dtype=torch.float32, device=DEV)
+        ops.colsum(dY, dV, vmode=1, vdiv=1024, vmod=4)
+        acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+        ops.dot_diff(dY, dY, A[:, :N].contiguous() if K >= N else dY, acc, scale=0.25)
+        return dW, db, dV, acc
+    runs = [grads(tl) for tl in (False, False, False, True, True)]
+    for r in runs[1:3]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[4], runs[3]))
+    if taps > 1:                                                # the parameter's own layout = the packed one, permuted
+        assert torch.equal(runs[3][0], runs[0][0].reshape(N, taps, K).permute(0, 2, 1).contiguous())
+    prev, ops.DETERMINISTIC = ops.DETERMINISTIC, False
+    try:
+        ref = grads(False)
+    finally:
+        ops.DETERMINISTIC = prev
+    for a, b in zip(runs[0], ref):
+        assert parity_err(a, b) < 1e-4
+
+
 @pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
 def test_wgrad_conv3x3(ops, stride, up):
     n, cin, cout, H, W = 3, 64, 128, 12, 10

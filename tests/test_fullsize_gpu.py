@@ -314,6 +314,19 @@ def test_cfg5_training_step_at_the_reference_size(models):
     l0 = [training.train_step(ctrl, unet, batch, optimizer=None) for _ in range(2)]
     torch.cuda.synchronize()
     assert torch.isfinite(l0[0]) and torch.equal(l0[0], l0[1]), l0
+    # gradient determinism (round 5): two backward passes from the same state give bit-identical gradients for EVERY
+    # parameter -- wgrad, bias / row-vector column sums, norm affine gradients and the mixing-weight dot products are ordered
+    # sums now (ctrlv_amd.ops.DETERMINISTIC), the attention backward never used atomics
+    grads = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        training.train_step(ctrl, unet, batch, optimizer=None)
+        torch.cuda.synchronize()
+        grads.append([None if p.grad is None else p.grad.detach().clone() for p in params])
+    bad = [i for i, (a, b) in enumerate(zip(*grads)) if (a is None) != (b is None) or (a is not None and not torch.equal(a, b))]
+    assert not bad, f"{len(bad)} of {len(params)} parameter gradients differ between two runs (first: {bad[:5]})"
+    del grads
     for p in params:
         p.grad = None
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=1e-2, fused=True)

@@ -178,9 +178,9 @@ def test_forward_after_an_optimizer_step_uses_the_updated_weights(hip_lib):
 
 def test_gradient_checkpointing_gives_the_same_step_with_less_memory(hip_lib):
     """`enable_gradient_checkpointing()` (tools/train_video_controlnet.py:185-186): the GEGLU feed-forward intermediates are
-    recomputed in the backward by the forward's own launch (the same bits), so the loss is bit-identical and every gradient
-    agrees with the plain step to the run-to-run noise of the plain step itself (wgrad accumulates with fp32 atomics: two
-    plain steps differ in the last bits too) -- and the step's peak memory is lower."""
+    recomputed in the backward by the forward's own launch (the same bits), so the loss AND EVERY GRADIENT are bit-identical
+    to the plain step (round 5: the parameter-gradient reductions are ordered sums, ctrlv_amd.ops.DETERMINISTIC; with the
+    fp32 atomics of round 4 two plain steps differed in their last bits) -- and the step's peak memory is lower."""
     import ctrlv_ref as R
     from ctrlv_amd.training import train_step
     config = dict(R.TINY_CONFIG)
@@ -211,5 +211,6 @@ def test_gradient_checkpointing_gives_the_same_step_with_less_memory(hip_lib):
             worst = max(worst, rel_l2(c, a))
     print(f"  worst per-parameter rel-L2 between the checkpointed and the plain step: {worst:.2e}")
     assert worst < 1e-5
+    assert all(torch.equal(a, c) for a, c in zip(g0, g1))
     print(f"  peak above the resident set: plain {m0 / 2**20:.1f} MiB, checkpointed {m1 / 2**20:.1f} MiB")
     assert m1 < 0.9 * m0
