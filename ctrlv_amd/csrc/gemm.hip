@@ -474,7 +474,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
-  if (d.tile >= 12 && d.tile <= 15) return ctrlv_gemm_launch_w16(d, d.tile, stream);
+  if (d.tile == 12 || d.tile == 13) return ctrlv_gemm_launch_w16(d, d.tile, stream);
   if (d.tile == 0) {
     const int w16 = w16_tile_of(d);
     if (w16) return ctrlv_gemm_launch_w16(d, w16, stream);

@@ -2,17 +2,17 @@
 #include "gemm_w16_kernel.h"
 
 // tile 12: 256 x 256 (wave tile 64 x 64; GEGLU and N % 256 == 0 layers), tile 13: 256 x 320 (wave tile 64 x 80).
-template <int BN, int MODE, int SCHED = 0>
+template <int BN, int MODE>
 static int launch_w16_epi(const ctrlv_gemm_desc& d, hipStream_t stream) {
   switch (pp_epi_of(d)) {
-    case 0: return launch_w16<BN, MODE, false, 0, SCHED>(d, stream);
-    case 1: return launch_w16<BN, MODE, false, 1, SCHED>(d, stream);
-    case 2: return launch_w16<BN, MODE, false, 2, SCHED>(d, stream);
+    case 0: return launch_w16<BN, MODE, false, 0>(d, stream);
+    case 1: return launch_w16<BN, MODE, false, 1>(d, stream);
+    case 2: return launch_w16<BN, MODE, false, 2>(d, stream);
     case 3:
-      if constexpr (MODE == 0) return launch_w16<BN, MODE, false, 3, SCHED>(d, stream);
+      if constexpr (MODE == 0) return launch_w16<BN, MODE, false, 3>(d, stream);
       break;
     case 6:
-      if constexpr (MODE == 0) return launch_w16<BN, MODE, false, 6, SCHED>(d, stream);
+      if constexpr (MODE == 0) return launch_w16<BN, MODE, false, 6>(d, stream);
       break;
     default: break;
   }
@@ -22,7 +22,7 @@ static int launch_w16_epi(const ctrlv_gemm_desc& d, hipStream_t stream) {
 
 // what the core can run at all (the launcher's conditions; ctrlv_gemm_w16_serves adds the policy: which LAYERS it is given)
 bool ctrlv_gemm_w16_supports(const ctrlv_gemm_desc& d, int tile) {
-  const int bn = (tile == 12 || tile == 14) ? 256 : 320;
+  const int bn = tile == 12 ? 256 : 320;
   const long lim = 0xFFFFFFF0L;
   if (d.A2 || d.raw_out || d.gn_partials || d.ksplit || d.act || (d.out_f32 & 1) || d.R1_lo || d.R2_lo || d.out_lo) return false;
   if ((long)d.M * d.ldo * 2 > lim || (d.R1 && (long)d.M * d.ldr1 * 2 > lim) || (d.R2 && (long)d.M * d.ldr2 * 2 > lim)) return false;
@@ -46,16 +46,6 @@ bool ctrlv_gemm_w16_supports(const ctrlv_gemm_desc& d, int tile) {
 int ctrlv_gemm_launch_w16(const ctrlv_gemm_desc& d, int tile, hipStream_t stream) {
   if (!ctrlv_gemm_w16_supports(d, tile)) {
     ctrlv_set_error("ctrlv_gemm: launch not served by the 16x16x32 core (tile %d)", tile);
-    return CTRLV_E_BAD_ARG;
-  }
-  // tiles 14 / 15 (development A/B): the same tiles on the single-stream schedule (gemm_w16_kernel.h SCHED 1), plain GEMMs
-  if (tile == 14) {
-    if (d.geglu) return launch_w16<256, 0, true, 0, 1>(d, stream);
-    if (d.mode == 0) return launch_w16_epi<256, 0, 1>(d, stream);
-  }
-  if (tile == 15 && d.mode == 0) return launch_w16_epi<320, 0, 1>(d, stream);
-  if (tile == 14 || tile == 15) {
-    ctrlv_set_error("ctrlv_gemm: tiles 14 / 15 serve mode 0 only");
     return CTRLV_E_BAD_ARG;
   }
   if (tile == 12) {

@@ -43,10 +43,12 @@ __device__ __forceinline__ f32x4v mfma_16x16x32(const elx8& a, const elx8& b, co
 }
 
 // EPI: bit 0 row-vector table V, bit 1 residual R1, bit 2 residual R2 (bias, s_acc, n_scale2 always honoured).
-// (A single-stream schedule -- every wave reads, issues, computes and retires in one stream, one barrier per half-step, the
-//  four waves of a SIMD covering each other's fragment-read latency -- was built and measured: within +-4 % of this one on
-//  every shape, profiles/r05_w16_sweeps.txt; tools/experiments/gemm_w16_kernel_r05_single_stream_schedule.h.)
-template <int BN, int MODE, bool GEGLU, int EPI>
+// SCHED 0: the two-group ping-pong described above (two barriers per half-step).  SCHED 1: ONE stream -- every wave reads its
+// fragments, issues its pieces, runs its MFMAs, retires its pieces of the next half-step, one barrier per half-step: the four
+// waves of a SIMD cover each other's fragment-read latency instead of alternating in lock step (the stamps of SCHED 0,
+// profiles/r05_w16_phase_stamps.txt: the load phase is bound by the LDS array -- a 64 x 64 wave tile re-reads 8 KiB per 16
+// MFMAs -- and every slot ends ~340 cycles after the longer of its two phases).
+template <int BN, int MODE, bool GEGLU, int EPI, int SCHED = 0>
 __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d, const int cgrp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, NW = 16, NH = 4, WM = 4, WN = 4;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
   unsigned long long c_lread = 0, c_lissue = 0, c_lwait = 0, c_lbar = 0, c_mfma = 0, c_cbar = 0, c_epi = 0;
   STAMP(t_begin);
 #endif
-  if (grp == 1) raw_barrier();                                // stagger: group 1 runs one barrier slot behind
+  if (SCHED == 0 && grp == 1) raw_barrier();                  // stagger: group 1 runs one barrier slot behind
 
   bool after_epi = false;
   auto half_step = [&](bool first, bool early) {
@@ -239,13 +241,15 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     STAMP(t1);
     issue(g + 3);
     STAMP(t1b);
-    wait_next(early && after_epi);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(t2b);
-    lds_done_barrier();
-    STAMP(t3);
-    STAMP_ADD(c_lwait, t1b, t2b);
-    STAMP_ADD(c_lbar, t2b, t3);
+    if constexpr (SCHED == 0) {
+      wait_next(early && after_epi);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(t2b);
+      lds_done_barrier();
+      STAMP(t3);
+      STAMP_ADD(c_lwait, t1b, t2b);
+      STAMP_ADD(c_lbar, t2b, t3);
+    }
     STAMP_ADD(c_lread, t0, t1);
     STAMP_ADD(c_lissue, t1, t1b);
     __builtin_amdgcn_sched_barrier(0);
@@ -262,10 +266,21 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(t4);
-    raw_barrier();
-    STAMP(t5);
-    STAMP_ADD(c_mfma, t3, t4);
-    STAMP_ADD(c_cbar, t4, t5);
+    if constexpr (SCHED == 0) {
+      raw_barrier();
+      STAMP(t5);
+      STAMP_ADD(c_mfma, t3, t4);
+      STAMP_ADD(c_cbar, t4, t5);
+    } else {
+      // (the MFMAs consumed every fragment read: no LDS read of this wave is outstanding at the barrier)
+      wait_next(early && after_epi);
+      STAMP(t4b);
+      raw_barrier();
+      STAMP(t5);
+      STAMP_ADD(c_mfma, t1b, t4);
+      STAMP_ADD(c_lwait, t4, t4b);
+      STAMP_ADD(c_cbar, t4b, t5);
+    }
   };
 
   for (int tr = 0; tr < my_ntiles; ++tr) {
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
 #pragma clang loop unroll(disable)
     for (int j = J - 3; j < J; ++j, ++g) half_step(false, J == 4 && j == 1);
     // tile boundary: the two groups' epilogues run concurrently (gemm_pp_kernel.h)
-    if (grp == 0) raw_barrier();
+    if (SCHED == 0 && grp == 0) raw_barrier();
     STAMP(t6);
     {
       constexpr int kFlags = 0x00020000;
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
     after_epi = true;
     STAMP(t7);
     STAMP_ADD(c_epi, t6, t7);
-    if (grp == 1 && tr + 1 < my_ntiles) raw_barrier();
+    if (SCHED == 0 && grp == 1 && tr + 1 < my_ntiles) raw_barrier();
   }
   wait_vmcnt<0>();
   CTRLV_CLOCK_END();
@@ -436,12 +451,12 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
 #endif
 }
 
-template <int BN, int MODE, bool GEGLU, int EPI>
+template <int BN, int MODE, bool GEGLU, int EPI, int SCHED = 0>
 int launch_w16(const ctrlv_gemm_desc& d, hipStream_t stream) {
   constexpr int smem = 4 * (256 + BN) * 64 + (GEGLU ? kGeluTabBytes : 0);
   static_assert(smem <= 160 * 1024, "w16 tile does not fit the LDS");
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = gemm_w16_kernel<BN, MODE, GEGLU, EPI>;
+  auto kfn = gemm_w16_kernel<BN, MODE, GEGLU, EPI, SCHED>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
