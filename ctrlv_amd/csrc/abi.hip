@@ -1,5 +1,6 @@
 // ABI basics of libctrlv_hip.so / libctrlv_hip_f16.so: version, build id, thread-local error text, per-device property cache.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -15,6 +16,30 @@ void ctrlv_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+const ctrlv_debug_t& ctrlv_debug() {
+  static const ctrlv_debug_t dbg = [] {
+    auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    ctrlv_debug_t d;
+    d.w16 = env("CTRLV_W16", 1);
+    d.splitk = env("CTRLV_SPLITK", 1);
+    d.force_tile = env("CTRLV_GEMM_FORCE_TILE", 0);
+    d.conv_halo = env("CTRLV_CONV_HALO", 1);
+    d.gn_fused = env("CTRLV_GN_FUSED", 1);
+    d.gn_cross = env("CTRLV_GN_CROSS", 1);
+    d.gn_rev = env("CTRLV_GN_REV", 1);
+    d.gn_rows = env("CTRLV_GN_ROWS", 256);
+    if (d.gn_rows < 32 || d.gn_rows > 1024) d.gn_rows = 256;
+    d.ln_rows = env("CTRLV_LN_ROWS", 1);
+    d.ff_fused = env("CTRLV_FF_FUSED", 1);
+    d.ff_ln = env("CTRLV_FF_LN", 0);
+    d.pp_balanced = env("CTRLV_PP_BALANCED", 1);
+    d.pp_cgrp = env("CTRLV_PP_CGRP", 0);
+    d.attn_rows = env("CTRLV_ATTN_ROWS", 0);
+    return d;
+  }();
+  return dbg;
 }
 
 int ctrlv_current_device() {

@@ -682,13 +682,9 @@ static int attention_spatial_launch(const void* qkv, void* out, float* lse, int 
   CTRLV_CHECK_ARG(qkv && out, "attention_spatial: null pointer");
   CTRLV_CHECK_SHAPE(n_img > 0 && S > 0 && C > 0 && C % 64 == 0, "attention_spatial: C=%d must be a multiple of 64 (head_dim 64)", C);
   CTRLV_CHECK_SHAPE(n_img <= 65535 && C / 64 <= 65535, "attention_spatial: grid too large");
-  // 64 query rows per wave on the long sequences; CTRLV_ATTN_ROWS=32|64 forces one (A/B, tests)
-  static int rows = 0;
-  if (rows == 0) {
-    const char* e = getenv("CTRLV_ATTN_ROWS");
-    rows = (e && e[0] == '3') ? 32 : (e && e[0] == '6') ? 64 : -1;
-  }
-  const bool use64 = rows == 64 || (rows == -1 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
+  // 64 query rows per wave on the long sequences; ctrlv_debug().attn_rows = 32 | 64 forces one (A/B, tests)
+  const int rows = ctrlv_debug().attn_rows;
+  const bool use64 = rows == 64 || (rows != 32 && S >= 1024);   // measured: +4-5 % at S = 9216 / 2304, -16 % at S = 576
   if (use64) {
     dim3 grid64((S + 255) / 256, C / 64, n_img);
     if (pre)

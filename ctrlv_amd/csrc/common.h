@@ -285,6 +285,25 @@ static __device__ unsigned long long g_ctrlv_clock[2];
 #endif
 
 // ---- host side ----
+// Developer switches: ONE struct, read ONCE from the environment (abi.hip ctrlv_debug()).  Every field is the A/B handle of a
+// measured decision; the defaults are the shipped configuration and the only one the test suites exercise.
+struct ctrlv_debug_t {
+  int w16;          // CTRLV_W16 [1]          0: no layer is given to the 16x16x32 core (gemm.hip w16_tile_of)
+  int splitk;       // CTRLV_SPLITK [1]       0: no split contraction of the small-image long-K convs
+  int force_tile;   // CTRLV_GEMM_FORCE_TILE [0]  5 / 6: that ping-pong tile for every large launch (tools/shape_table.py)
+  int conv_halo;    // CTRLV_CONV_HALO [1]    0: per-tap gather in tap-major K order for the stride-1 3x3 convs
+  int gn_fused;     // CTRLV_GN_FUSED [1]     0: every GroupNorm runs its own statistics pass
+  int gn_cross;     // CTRLV_GN_CROSS [1]     0: ... except across the res-block -> transformer boundary
+  int gn_rev;       // CTRLV_GN_REV [1]       bit 0 / 1: statistics / apply pass walk the tensor from its end
+  int gn_rows;      // CTRLV_GN_ROWS [256]    rows per GroupNorm chunk at S >= 4096
+  int ln_rows;      // CTRLV_LN_ROWS [1]      0: one row per wave (ln_kernel)
+  int ff_fused;     // CTRLV_FF_FUSED [1]     0: the two launches instead of the fused C = 320 feed-forward
+  int ff_ln;        // CTRLV_FF_LN [0]        1: LayerNorm folded into the fused feed-forward's prologue
+  int pp_balanced;  // CTRLV_PP_BALANCED [1]  0: one persistent workgroup per CU whatever the tile count
+  int pp_cgrp;      // CTRLV_PP_CGRP [0]      -1 row-major tile order, 0 traffic model, n = fixed column-group width
+  int attn_rows;    // CTRLV_ATTN_ROWS [0]    32 / 64: query rows per wave of the spatial attention (0: by sequence length)
+};
+const ctrlv_debug_t& ctrlv_debug();
 void ctrlv_set_error(const char* fmt, ...);
 #define CTRLV_MAX_DEVICES 64
 int ctrlv_current_device();   // hipGetDevice clamped to [0, CTRLV_MAX_DEVICES)

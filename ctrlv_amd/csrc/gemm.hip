@@ -326,9 +326,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctrlv_gemm_des
 // only (pixels per image, N, Cin, taps) -- priced for the 50 frame-images of a CFG'd 25-frame clip, never the actual batch:
 // a clip takes the same path, with the same summation order, alone and in any batch.
 static int splitk_plan(const ctrlv_gemm_desc& d, int* tile_out) {
-  static int on = -1;                    // A/B handle: CTRLV_SPLITK=0
-  if (on < 0) { const char* e = getenv("CTRLV_SPLITK"); on = e ? atoi(e) : 1; }
-  if (!on || (d.mode == 0 && d.S <= 0) || d.geglu || d.A2 || d.act || d.out_f32 || d.raw_out || d.gn_partials || d.n_scale2 || d.tile) return 1;
+  if (!ctrlv_debug().splitk || (d.mode == 0 && d.S <= 0) || d.geglu || d.A2 || d.act || d.out_f32 || d.raw_out || d.gn_partials || d.n_scale2 || d.tile) return 1;
   if (d.N % 32 || d.N < 256 || d.n_store != d.N || d.ldo % 8 || (d.R1 && d.ldr1 % 8) || (d.R2 && d.ldr2 % 8) ||
       (d.vmode && d.ldv % 8) || d.Cin % 64)
     return 1;
@@ -365,9 +363,7 @@ static int splitk_plan(const ctrlv_gemm_desc& d, int* tile_out) {
 // sums a K half-step in one instruction whose internal order is not the 32x32x16 kernels': a layer given to it runs there at
 // EVERY row count, so a clip's bits do not depend on the batch (tests/test_fullsize_gpu.py clip independence).
 static int w16_tile_of(const ctrlv_gemm_desc& d) {
-  static int on = -1;                    // A/B handle: CTRLV_W16=0 -> every layer on the 32x32x16 kernels
-  if (on < 0) { const char* e = getenv("CTRLV_W16"); on = e ? atoi(e) : 1; }
-  if (!on || d.mode != 0) return 0;
+  if (!ctrlv_debug().w16 || d.mode != 0) return 0;
   int tile = 0;
   // in-model A/B (tools/shape_table.py, two alternations on one device, profiles/r05_w16_in_model_ab.txt): the C = 1280 GEGLU
   // projections 14.2 -> 13.35 ms per step (-5.7 %), the C = 640 one 15.97 -> 16.48 ms (+3.2 %: stays on the ping-pong tile)
@@ -494,8 +490,7 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     // trunk's widths), the 2-stage kernel serves everything else -- the same operation sequence in both
     if (split_io && tile >= 5) tile = d.N % 320 == 0 ? 6 : 1;
     {
-      static int force = -1;             // A/B handle (tools/shape_table.py): CTRLV_GEMM_FORCE_TILE = 5 / 6 for every large launch
-      if (force < 0) { const char* e = getenv("CTRLV_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }
+      const int force = ctrlv_debug().force_tile;     // (tools/shape_table.py: tile 5 / 6 for every large launch)
       if ((force == 5 || force == 6) && tile >= 5 && tile <= 6) tile = force;
     }
   }

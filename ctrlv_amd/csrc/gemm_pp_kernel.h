@@ -1152,12 +1152,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set[dev] = true;
   }
-  int num_cu = ctrlv_num_cu(dev);
-  {
-    static int cap = -1;                 // A/B handle: CTRLV_PP_MAX_WG = persistent workgroups per launch (default: one per CU)
-    if (cap < 0) { const char* e = getenv("CTRLV_PP_MAX_WG"); cap = e ? atoi(e) : 0; }
-    if (cap > 0 && cap < num_cu) num_cu = cap;
-  }
+  const int num_cu = ctrlv_num_cu(dev);
   const int tiles = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN) * (EPI == 8 ? d.ksplit : 1);
   // persistent: one 512-thread workgroup per CU, every workgroup the same number of tiles.  1800 tiles (the N = 320 layers of
   // the 72 x 128 level) are 8 rounds on 256 CUs with 8 workgroups in the last one: 225 workgroups finish at the same time
@@ -1165,9 +1160,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   int grid = tiles;
   if (persistent && tiles > num_cu) {
     const int rounds = (tiles + num_cu - 1) / num_cu;
-    static int balanced = -1;            // A/B handle: CTRLV_PP_BALANCED=0 -> one workgroup per CU whatever the tile count
-    if (balanced < 0) { const char* e = getenv("CTRLV_PP_BALANCED"); balanced = e ? atoi(e) : 1; }
-    grid = balanced ? (tiles + rounds - 1) / rounds : num_cu;
+    grid = ctrlv_debug().pp_balanced ? (tiles + rounds - 1) / rounds : num_cu;
   }
   // Column-group width of the tile order (see the kernel), from a traffic model of the L2 <-> fabric reads (checked against
   // TCC_EA0_RDREQ, tools/pmc_fetch.sh): an XCD's 32 CUs work on 32 consecutive tile numbers.
@@ -1177,8 +1170,7 @@ int launch_one(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stream) {
   const int tiles_n = (d.N + BN - 1) / BN;
   int cgrp = tiles_n;
   {
-    static int forced = -2;              // A/B handle: CTRLV_PP_CGRP = -1 row-major, 0 model (default), n = fixed width
-    if (forced == -2) { const char* e = getenv("CTRLV_PP_CGRP"); forced = e ? atoi(e) : 0; }
+    const int forced = ctrlv_debug().pp_cgrp;        // -1 row-major, 0 model (default), n = fixed width
     const double w_tile = (double)BN * d.taps * d.Cin * 2, w_all = (double)d.N * d.taps * d.Cin * 2;
     const double a_all = (double)d.M * d.Cin * 2, budget = 3.0 * 1048576.0;
     if (forced > 0) cgrp = forced < tiles_n ? forced : tiles_n;

@@ -5,9 +5,7 @@ int ctrlv_gemm_launch_pp_conv(const ctrlv_gemm_desc& d, int tile, bool persisten
 int ctrlv_gemm_launch_pp_temporal(const ctrlv_gemm_desc& d, int tile, bool persistent, hipStream_t stream);  // gemm_pp_m2.hip
 
 bool ctrlv_conv_halo_order(const ctrlv_gemm_desc& d) {
-  static int on = -1;                    // A/B handle: CTRLV_CONV_HALO=0 -> per-tap gather, tap-major K order (round 3)
-  if (on < 0) { const char* e = getenv("CTRLV_CONV_HALO"); on = e ? atoi(e) : 1; }
-  return on != 0 && conv_halo_geometry(d);
+  return ctrlv_debug().conv_halo != 0 && conv_halo_geometry(d);     // (0: per-tap gather, tap-major K order of round 3)
 }
 
 // does the ping-pong family serve this descriptor's epilogue? (gemm.hip falls back to the 128x128 kernel otherwise)
@@ -48,9 +46,7 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
 extern "C" int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* dp) {
   if (!dp) return 0;
   const ctrlv_gemm_desc& d = *dp;
-  static int on = -1;                    // A/B handle: CTRLV_GN_FUSED=0 -> every GroupNorm runs its own statistics pass
-  if (on < 0) { const char* e = getenv("CTRLV_GN_FUSED"); on = e ? atoi(e) : 1; }
-  if (!on) return 0;
+  if (!ctrlv_debug().gn_fused) return 0;
   const int cpg = d.N / 32;
   if (d.N <= 0 || d.N % 320 != 0 || !(cpg == 10 || cpg == 20 || cpg == 40)) return 0;      // 160-column wave tiles hold whole groups
   if (d.n_store != d.N || d.ldo % 8 != 0 || d.geglu || d.A2 || d.raw_out || d.n_scale2 || pp_split_io(d)) return 0;
@@ -61,8 +57,7 @@ extern "C" int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* dp) {
     if (!(e == 1 || e == 2) || !ctrlv_conv_halo_order(d)) return 0;
     S = (long)d.Ho * d.Wo;
   } else if (d.mode == 2) {
-    static int cross = -1;               // A/B handle: CTRLV_GN_CROSS=0 -> the {R1} temporal conv (a res block's last GEMM,
-    if (cross < 0) { const char* e2 = getenv("CTRLV_GN_CROSS"); cross = e2 ? atoi(e2) : 1; }   // feeding the transformer's norm) does not serve
+    const int cross = ctrlv_debug().gn_cross;   // (0: the {R1} temporal conv -- a res block's last GEMM, feeding the transformer's norm -- does not serve)
     if (!(e == 1 || (e == 2 && cross))) return 0;
     S = d.S;
   } else {

@@ -468,8 +468,7 @@ int launch_w16(const ctrlv_gemm_desc& d, hipStream_t stream) {
       const double cost_grp = a_all * ((tiles_n + cmax - 1) / cmax) + 8.0 * w_all;
       if (cost_grp < 0.8 * cost_row) cgrp = cmax;
     }
-    static int forced = -2;              // A/B handle shared with the ping-pong kernel: CTRLV_PP_CGRP
-    if (forced == -2) { const char* e = getenv("CTRLV_PP_CGRP"); forced = e ? atoi(e) : 0; }
+    const int forced = ctrlv_debug().pp_cgrp;        // (the ping-pong kernel's A/B handle)
     if (forced > 0) cgrp = forced < tiles_n ? forced : tiles_n;
     else if (forced < 0) cgrp = tiles_n;
   }

@@ -226,8 +226,7 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
     // 295 MB: 195.6 -> 186.9 us per norm; 14.7 -> 14.4 ms per step; same directions for both passes: no gain).  Which
     // workgroup reads what first does not change any partial sum.  A/B handle: CTRLV_GN_REV bit 0 = statistics pass
     // from the end, bit 1 = apply pass from the end.
-    static int rev = -1;
-    if (rev < 0) { const char* e = getenv("CTRLV_GN_REV"); rev = e ? atoi(e) : 1; }
+    const int rev = ctrlv_debug().gn_rev;
     s->rev_stats = rev & 1; s->rev_apply = (rev >> 1) & 1;
   }
   // The row chunking -- and with it the order of every partial sum -- depends on the image size only, never on how
@@ -235,12 +234,7 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
   // (clip independence, tests/test_fullsize_gpu.py).  ~1000-2000 workgroups at the cfg3 batch of 50 images:
   // 256-row chunks at S = 9216, 64 at S = 2304, 32 below.
   {
-    static int rpc_big = 0;              // A/B handle: CTRLV_GN_ROWS=<rows per chunk at S >= 4096> (default 256)
-    if (rpc_big == 0) {
-      const char* e = getenv("CTRLV_GN_ROWS");
-      rpc_big = e ? atoi(e) : 256;
-      if (rpc_big < 32 || rpc_big > 1024) rpc_big = 256;
-    }
+    const int rpc_big = ctrlv_debug().gn_rows;       // rows per chunk at S >= 4096 (default 256)
     s->rows_per_chunk = S >= 4096 ? rpc_big : (S >= 1024 ? 64 : 32);
   }
   // very large images (the VAE decoder: up to 576 x 1024 pixels per frame): at most 256 chunks per image, so that the
@@ -563,7 +557,7 @@ extern "C" int ctrlv_layernorm_split(const void* x, const void* x_lo, int M, int
   const int nv = (C / 8 + 63) / 64;
   hipStream_t st = (hipStream_t)stream;
   // C = 320 / 640 / 1280 (every LayerNorm of the model): 8 / 16 / 32 lanes per row, 5 chunks per lane (ln_rows_kernel)
-  static const int rows_path = [] { const char* e = getenv("CTRLV_LN_ROWS"); return e ? atoi(e) : 1; }();
+  const int rows_path = ctrlv_debug().ln_rows;
   const int lpr = C / 40;
   if (rows_path && C % 40 == 0 && (lpr == 8 || lpr == 16 || lpr == 32) && (!V || (ldv % 4 == 0 && ((uintptr_t)V & 15) == 0))) {
     const int lg = lpr == 8 ? 3 : (lpr == 16 ? 4 : 5), rpb = 4 * (64 >> lg);

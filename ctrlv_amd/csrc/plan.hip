@@ -686,27 +686,12 @@ int frame_embedding(Ctx& c, const Transformer& t, int F, float* e) {
   return CTRLV_OK;
 }
 
-// GEGLU projection -> FF output as M-CHUNKED pairs (blocks.py::_ff_pair).  At the C = 320 level u (the 4C-wide GEGLU
-// output) is 590 MB for the 50 frame-images of a CFG step; written whole and then read whole it misses the 256 MB
-// Infinity Cache on the way back.  In chunks of <= 160 MB the FF-out GEMM (HBM-bound there: K = 1280, N = 320) reads
-// what the projection has just written: -8 % on the isolated pair (tools/ff_chunk_bench.py: 1754 -> 1614 us), same
-// bits; wider levels (K >= 640) lose from the shorter launches.  IN THE MODEL it is a loss (242.5 vs 241.2 ms per step,
-// three alternating runs on one device: the ControlNet's kernels on the side stream share the cache and fill the
-// launch gaps differently), so it is OPT-IN: CTRLV_FF_CHUNK=1.
-int ff_rows_per_chunk(long M, int C) {
-  static const bool on = [] { const char* e = getenv("CTRLV_FF_CHUNK"); return e && atoi(e) != 0; }();   // opt-in (see above)
-  const long u_bytes = M * 4L * C * 2;
-  if (!on || C > 320 || u_bytes <= (256L << 20)) return (int)M;
-  const long n = (u_bytes + (160L << 20) - 1) / (160L << 20);
-  return (int)(((M + n - 1) / n + 255) / 256 * 256);
-}
 // `u` = the 4C-wide intermediate of the two-launch path, allocated HERE on first need (a transformer whose three
 // feed-forwards all run fused never reserves it: 1.2 GB per lane at the 72 x 128 level); proj.out / outd.A are set from it.
 int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd, int C, el_t** u) {
   // C = 320: one fused launch, the 4C-wide intermediate stays on chip (ff_fused.hip): 234.5 -> 231.3 ms per step (three
   // alternations on one device).  CTRLV_FF_FUSED=0: the two launches.
-  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
-  if (fuse && f.w1f && ctrlv_ff_fused_serves(&outd, proj.lda)) {
+  if (ctrlv_debug().ff_fused && f.w1f && ctrlv_ff_fused_serves(&outd, proj.lda)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
@@ -717,23 +702,8 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
   if (*u == nullptr) *u = c.rows(proj.M, 4 * C);
   proj.out = *u;
   outd.A = *u;
-  const int M = proj.M, rows = ff_rows_per_chunk(M, C);
-  for (int m0 = 0; m0 < M; m0 += rows) {
-    const int mc = M - m0 < rows ? M - m0 : rows;
-    ctrlv_gemm_desc p = proj, o = outd;
-    p.M = o.M = mc;
-    p.A = (const el_t*)proj.A + (long)m0 * proj.lda;
-    p.out = (el_t*)proj.out + (long)m0 * proj.ldo;
-    o.A = (const el_t*)outd.A + (long)m0 * outd.lda;
-    o.out = (el_t*)outd.out + (long)m0 * outd.ldo;
-    if (outd.R1) o.R1 = (const el_t*)outd.R1 + (long)m0 * outd.ldr1;
-    if (outd.R2) o.R2 = (const el_t*)outd.R2 + (long)m0 * outd.ldr2;
-    if (outd.R1_lo) o.R1_lo = (const el_t*)outd.R1_lo + (long)m0 * outd.ldr1;
-    if (outd.R2_lo) o.R2_lo = (const el_t*)outd.R2_lo + (long)m0 * outd.ldr2;
-    if (outd.out_lo) o.out_lo = (el_t*)outd.out_lo + (long)m0 * outd.ldo;
-    TRY(gemm(c, p));
-    TRY(gemm(c, o));
-  }
+  TRY(gemm(c, proj));
+  TRY(gemm(c, outd));
   return CTRLV_OK;
 }
 
@@ -743,9 +713,7 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
 // fused kernel's per-tile prologue takes it back), so the default keeps ctrlv_layernorm in front of the fused kernel.
 int ln_ff(Ctx& c, const FeedFwd& f, const Norm& nm, const Trk& xraw, const float* lnV, int lnvdiv, int lnvmod, int lnldv,
           el_t* tt, const ctrlv_gemm_desc& proj, const ctrlv_gemm_desc& outd, int C, el_t** u) {
-  static const bool fuse = [] { const char* e = getenv("CTRLV_FF_FUSED"); return !e || atoi(e) != 0; }();
-  static const bool fold = [] { const char* e = getenv("CTRLV_FF_LN"); return e && atoi(e) != 0; }();
-  if (fuse && fold && f.w1f && !xraw.lo && ctrlv_ff_fused_serves(&outd, C)) {
+  if (ctrlv_debug().ff_fused && ctrlv_debug().ff_ln && f.w1f && !xraw.lo && ctrlv_ff_fused_serves(&outd, C)) {
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),

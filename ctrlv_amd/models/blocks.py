@@ -127,24 +127,12 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
-def _ff_rows_per_chunk(M, C):
-    """csrc/plan.hip::ff_rows_per_chunk -- the C = 320 level runs GEGLU projection -> FF output in M chunks whose slice of
-    u (<= 160 MB) is still in the 256 MB Infinity Cache when the FF-out GEMM reads it back: -8 % on the isolated pair, but
-    +0.5 % on the whole step, so opt-in (CTRLV_FF_CHUNK=1)."""
-    u_bytes = M * 4 * C * 2
-    if os.environ.get("CTRLV_FF_CHUNK", "0") != "1" or C > 320 or u_bytes <= (256 << 20):
-        return M
-    n = (u_bytes + (160 << 20) - 1) // (160 << 20)
-    return ((M + n - 1) // n + 255) // 256 * 256
-
-
 _FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
 
 
 def _ff_pair(ws, x, ffp, ubox, out, C, rows_per_image=0, **epi):
     """u = GEGLU(x); out = epilogue(u @ wout^T).  ffp = (wproj, bproj, wout, bout[, w1f, w2f]): at C = 320 one fused launch
-    that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs, issued as
-    M-chunked pairs (same arithmetic, same bits).  `ubox` = [u or None]: the 4C-wide intermediate of the two-launch path is
+    that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs.  `ubox` = [u or None]: the 4C-wide intermediate of the two-launch path is
     allocated from the arena on first need (csrc/plan.hip ff_pair)."""
     wproj, bproj, wout, bout = ffp[:4]
     if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(x, out, **epi):
@@ -154,12 +142,8 @@ def _ff_pair(ws, x, ffp, ubox, out, C, rows_per_image=0, **epi):
     if ubox[0] is None:
         ubox[0] = ws.alloc((M, 4 * C))
     u = ubox[0]
-    rows = _ff_rows_per_chunk(M, C)
-    for m0 in range(0, M, rows):
-        m1 = min(M, m0 + rows)
-        kw = {k: (v[m0:m1] if k in ("R1", "R2") else v) for k, v in epi.items()}
-        ops.gemm(x[m0:m1], wproj, u[m0:m1], N=8 * C, cin=C, bias=bproj, geglu=1)
-        ops.gemm(u[m0:m1], wout, out[m0:m1], N=C, cin=4 * C, bias=bout, rows_per_image=rows_per_image, **kw)
+    ops.gemm(x, wproj, u, N=8 * C, cin=C, bias=bproj, geglu=1)
+    ops.gemm(u, wout, out, N=C, cin=4 * C, bias=bout, rows_per_image=rows_per_image, **epi)
 
 
 _FF_LN = os.environ.get("CTRLV_FF_LN", "0") not in ("", "0")   # opt-in, the plan's switch (csrc/plan.hip ln_ff)
