@@ -329,6 +329,11 @@ class _GegluCell:
         self.done = True
 
     def take(self, which):
+        """Hands out u / raw once per recompute: a second take of the same tensor (ctx.saved_tensors read twice,
+        backward(retain_graph=True) run again) recomputes instead of returning None."""
+        if self.done and getattr(self, which) is None:
+            self.done = False                        # that tensor was already handed out: run the projection again
+            self.u = self.raw = None
         self._recompute()
         t = getattr(self, which)
         setattr(self, which, None)
@@ -357,7 +362,12 @@ def _ff_region():
         try:
             yield
         finally:
-            _CELLS.clear()
+            # every checkpointed u must have been claimed by its consumer's save_for_backward: a consumer that saved a copy
+            # (a .contiguous() / reshaped u) would silently keep the tensor and make checkpointing a no-op
+            leaked, _ = len(_CELLS), _CELLS.clear()
+        if leaked:
+            raise RuntimeError(f"gradient checkpointing: {leaked} GEGLU intermediate(s) were not claimed by the output "
+                               "projection's saved tensors (the consumer saved a copy?)")
 
 
 class GegluProj(torch.autograd.Function):

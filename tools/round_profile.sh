@@ -3,6 +3,8 @@
 #   1. bench.py (HIP-graph replay, default flags)                       -> bench.json
 #   2. rocprofv3 --kernel-trace --stats of an eager bench run           -> kernel_stats.csv
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes         -> pmc_hbm_traffic_summary.json (build-id stamped)
+#   4. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... + in-kernel clock   -> pmc_mfma_busy_summary.json (tools/pmc_mfma_pass.sh)
+#   5. the other configurations of the same build, incl. bench.py --dtype fp16 --trunk fp16x2 (north_star's tolerance)
 # usage: tools/round_profile.sh <tag> [extra bench args]
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-round}; shift
@@ -20,8 +22,11 @@ cd $R
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_hbm_traffic_summary.json 2 > $OUT/pmc_summary.txt 2>&1
 tail -12 $OUT/pmc_summary.txt
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/prof/p_kernel_trace.csv
-# 4. the other configurations of the same build (no CPU leg): SVD UNet only (cfg2), the reference's default 320x512 size,
-#    the cfg5 training step, the end-to-end clip latency through the pipeline
+tools/pmc_mfma_pass.sh $TAG
+# 5. the other configurations of the same build (no CPU leg unless noted): the fp16 element build with the split residual
+#    trunk (WITH the CPU oracle leg: its parity object is the north_star tolerance claim), SVD UNet only (cfg2), the
+#    reference's default 320x512 size, the cfg5 training step, the end-to-end clip latency through the pipeline
+python3 bench.py --steps 8 --warmup 2 --dtype fp16 --trunk fp16x2 > $OUT/bench_fp16_split_trunk.json 2>> $OUT/bench.err
 python3 bench.py --steps 8 --warmup 2 --workload svd_unet --no-cpu-baseline > $OUT/bench_svd_unet.json 2>> $OUT/bench.err
 python3 bench.py --steps 12 --warmup 3 --height 320 --width 512 --no-cpu-baseline > $OUT/bench_320x512.json 2>> $OUT/bench.err
 python3 tools/train_bench.py --steps 4 --warmup 2 > $OUT/train_step.json 2>> $OUT/bench.err
