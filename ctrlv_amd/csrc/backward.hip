@@ -38,6 +38,7 @@ struct WgradArgs {
   const el_t* A; const el_t* A2; const el_t* dY; float* dW; float* dbias; float scale; int torch_layout;
   float* part;        // deterministic mode: slab partials [slabs][N][Ktot] fp32 (+ [slabs][N] bias sums behind them), else null
   int M, N, Cin, taps, lda, lda2, c_split, ldy, mode, H, Wd, Ho, Wo, stride, up, F, S, rows_per_slab;
+  int ntiles, ktiles, slabs;     // grid decomposition (the launch is one-dimensional: wgrad_kernel deals it out XCD-aware)
 };
 
 // source row of output row m for tap t, or -1 (zero padding / frame edge)
@@ -72,9 +73,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(1024))) char ty[2 * 8192];   // dY rows: 2 panels [64][64 n]
   __shared__ __attribute__((aligned(1024))) char ta[4 * 8192];   // A  rows: 4 panels [64][64 k]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 256;
+  // XCD-aware order (round 5): the workgroups of ONE row slab -- its (n tile, k tile) pairs, which all stream the same rows of
+  // dY and A -- are dealt to ONE XCD (consecutive ids after common.h xcd_remap), so a slab's rows are fetched into one L2
+  // instead of all eight.  With the hardware's round-robin placement every XCD pulled every slab through the fabric: at 87
+  // FLOP per staged byte (128 x 256 tile, 64-row chunks) that is what the kernel ran at (537 TFLOP/s ~ 6 TB/s).
+  const int ntiles_ = a.ntiles, ktiles_ = a.ktiles;
+  const int lin = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int bx = lin % ntiles_, by = (lin / ntiles_) % ktiles_, bz = lin / (ntiles_ * ktiles_);
+  const int n0 = bx * 128, k0 = by * 256;
   const long ktot = (long)a.taps * a.Cin;
-  const int m_lo = blockIdx.z * a.rows_per_slab;
+  const int m_lo = bz * a.rows_per_slab;
   const int m_hi = min(a.M, m_lo + a.rows_per_slab);
   const int nh = wid & 1, kh = wid >> 1;
   // staging roles: dY piece i of this thread = row (tid >> 4) + 16 i, 16-B chunk (tid & 15) of 16;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const long ald = second ? a.lda2 : a.lda;
   auto sw = [](int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) * 16); };
   // bias gradient (column sums of dY) rides along in the workgroups of the first K tile: they stream dY anyway
-  const bool do_bias = a.dbias != nullptr && blockIdx.y == 0;
+  const bool do_bias = a.dbias != nullptr && by == 0;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint4 vy[4], va[8];
   auto load = [&](int m0) {
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         col = (k - (long)tp * a.Cin) * a.taps + tp;
       }
       if (a.part) {     // deterministic: this workgroup's own tile of its slab's partial matrix (packed K order, unscaled)
-        float* ps = a.part + (long)blockIdx.z * a.N * ktot;
+        float* ps = a.part + (long)bz * a.N * ktot;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int n = n0 + 64 * nh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
-      if (a.part) a.part[(long)gridDim.z * a.N * ktot + (long)blockIdx.z * a.N + n0 + tid] = t;
+      if (a.part) a.part[(long)a.slabs * a.N * ktot + (long)bz * a.N + n0 + tid] = t;
       else atomicAdd(a.dbias + n0 + tid, t * a.scale);
     }
   }
@@ -716,7 +724,8 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   int rps;
   const int slabs = wgrad_slabs(d, &rps);
   a.rows_per_slab = rps;
-  CTRLV_CHECK_SHAPE(slabs <= 65535 && ktiles <= 65535, "gemm_wgrad: grid too large");
+  CTRLV_CHECK_SHAPE((long)ntiles * ktiles * slabs < (1L << 30), "gemm_wgrad: grid too large");
+  a.ntiles = ntiles; a.ktiles = ktiles; a.slabs = slabs;
   // scratch given: DETERMINISTIC -- slab partials with plain stores, then an ordered sum (wgrad_reduce_kernel); without it
   // the slabs add into dW with fp32 atomics (order varies from run to run)
   a.part = nullptr;
@@ -725,7 +734,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
     CTRLV_CHECK_SHAPE((d.taps * d.Cin) % 4 == 0, "gemm_wgrad: K must be a multiple of 4");
     a.part = (float*)scratch;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(ntiles, ktiles, slabs), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ntiles * ktiles * slabs)), dim3(256), 0, (hipStream_t)stream, a);
   CTRLV_LAUNCH_CHECK();
   if (a.part) {
     const long ktot = (long)d.taps * d.Cin, n_thr = (long)d.N * (ktot >> 2);
