@@ -2,22 +2,30 @@
 // BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff), gfx950.
 //
 // The two GEMM launches it replaces (ctrlv_gemm with geglu = 1, then the 1280 -> 320 projection) write the 4C-wide
-// intermediate u to HBM and read it back: 2.4 GB per pair at M = 460 800, and the write-back of u is what the GEGLU kernel
-// waits for (store experiments).  Here u never leaves the CU:
-//   * 256-row tile per workgroup, 8 waves x 32 rows; a wave keeps its 32 x 320 OUTPUT accumulators (160 registers) for the
-//     whole tile and its x rows as MFMA B fragments: k-steps 0..9 in registers (40), 10..19 in LDS (80 KB per workgroup)
-//   * the hidden dimension is walked in CHUNKS of 16 columns: 20 MFMAs (x . W1 chunk, K = 320; the chunk's 16 value + 16
-//     gate rows, bias as the C operand) -> 8 GEGLU results per lane (Phi table, common.h) -> packed to bf16 and used AS THEY
-//     SIT as the B operand of 10 MFMAs (h chunk . W2 chunk).  In the result layout of v_mfma_f32_32x32x16 a lane holds, of
-//     its row, hidden columns 8q + 4h + r (q = 0..1, r = 0..3, h = lane >> 5); as a B operand its eight values are k-slots
-//     8h + 4q + r.  ctrlv_ff_fused_pack() stores W2 with its K index permuted accordingly, so no data moves between lanes.
-//   * W1 / W2 chunks (21 + 10 KiB, fragment-major so that every ds_read_b128 is a contiguous KiB per wave) stream through
-//     LDS rings by LDS-DMA, two chunks ahead of the window boundary; one barrier per chunk.  The two waves of a SIMD run a
-//     third of a chunk apart (see the kernel) so that one's GEGLU runs beside the other's MFMAs; in step, the first version
-//     only tied with the two launches (1.35-1.45 ms at M = 460 800; this one 1.29-1.30 against 1.44-1.52; -1.35 % per step)
-//   * epilogue = the ping-pong GEMM's (gemm_epilogue_lds: s_acc * acc + s1 R1 + s2 R2 + V, LDS transpose, 16-B stores)
-// Arithmetic: the same MFMA, the same K order inside GEMM 1, the same bias-as-C-operand, the same GELU table and the same
-// bf16 rounding of u as the two-launch path; GEMM 2 sums its K = 1280 in chunk order with the permuted slot assignment, so
+// intermediate u to HBM and read it back: 2.4 GB per pair at M = 460 800.  Here u never leaves the CU.
+//
+// Round 5 structure ("pair" kernel; rounds 3-4 ran 8 waves x (32 rows x 320 output columns), whose 160 accumulator + 40
+// x registers left the compiler no room: fragment reads two at a time right in front of their MFMAs, the LDS latency of
+// every pair exposed, matrix pipe 47 % busy):
+//   * 128-row tile per workgroup, 8 waves = 4 row groups x 2 halves.  The two waves of a row group (w, w + 4: the two
+//     waves of one SIMD) hold the SAME 32 x rows, all 20 k-steps in registers (80; no x strip in LDS), and each keeps
+//     32 x 160 OUTPUT accumulators (80 registers) -- half the output columns.
+//   * the hidden dimension is walked in chunks of 16 columns; GEMM 1 + GEGLU of a chunk (21 MFMAs: K = 320 plus the bias
+//     step, then the Phi table) is done ONCE per row group -- even chunks by half 0, odd chunks by half 1 -- and the 32 x 16
+//     result h (bf16, already in B-operand form: 1 KiB) is handed to the partner through LDS; GEMM 2 of a chunk PAIR
+//     (2 x 5 MFMAs per wave: its 160 columns) is done by both.  Same MFMAs, same K order, same chunk order of the GEMM 2
+//     sum as the round 3-4 kernel: bit-identical results.
+//   * time is cut into SLOTS separated by one workgroup barrier.  In slot t the half (t & 1) does segment A of chunk t
+//     (GEMM 1, GEGLU, h -> LDS) and the other half segment B of the chunk pair whose h are both visible (10 MFMAs) plus
+//     the LDS-DMA issue: on every SIMD one wave is in its 21-MFMA chain while its partner's 10 MFMAs, DMA issue and waits
+//     fill the rest -- 31 MFMAs per SIMD and slot, the GEGLU of one wave beside the MFMAs of the other by construction.
+//   * W1 chunks (21 KiB, fragment-major) through a 3-deep LDS-DMA ring, issued two slots ahead; W2 chunk pairs (2 x 10 KiB)
+//     through a 4-chunk ring, issued at the even slot two before their first use.  Fragment reads run SIX MFMAs ahead
+//     through rotating registers, every step fenced (sched_barrier) so that the compiler keeps that distance.
+//   * epilogue = the ping-pong GEMM's (gemm_epilogue_lds: s_acc * acc + s1 R1 + s2 R2 + V, LDS transpose, 16-B stores) on
+//     the wave's 32 x 160 block.
+// Arithmetic: the same MFMA, the same K order inside GEMM 1, the same bias step, the same GELU table and the same bf16
+// rounding of u as the two-launch path; GEMM 2 sums its K = 1280 in chunk order with the permuted slot assignment, so
 // its fp32 sums differ from ctrlv_gemm's in the last bits.  Every C = 320 feed-forward of the inference path goes through
 // this kernel whatever M is (the training forward keeps the two launches: it needs u and the raw projection).
 #include "common.h"
@@ -26,12 +34,15 @@
 namespace {
 
 constexpr int kC = 320, kHid = 1280, kChunks = kHid / 16;        // 80 chunks of 16 hidden columns
-constexpr int kXHi = 8 * 10 * 1024;                              // x k-steps 10..19: [wave][ks][lane] x 16 B
+constexpr int kTileM = 128;
+constexpr int kNQ = 6;                                           // W1 fragment reads in flight ahead of the MFMA chain
 constexpr int kW1Pieces = 21;                                    // 20 k-steps of K = 320 + one carrying the bias (see below)
 constexpr int kW1Slot = kW1Pieces * 1024, kW2Slot = 10 * 1024;
-constexpr int kW1Off = kXHi;                                     // W1 ring: 2 slots (chunk c, chunk c + 1 in flight)
-constexpr int kW2Off = kW1Off + 2 * kW1Slot;                     // W2 ring: 3 slots (c - 1 for the late group, c, c + 1)
-constexpr int kTabOff = kW2Off + 3 * kW2Slot;
+constexpr int kStgOff = 0;                                       // epilogue staging: 8 waves x 4 KiB
+constexpr int kHfOff = kStgOff + 8 * 4096;                       // h exchange: [row group][chunk & 3] x 1 KiB
+constexpr int kW1Off = kHfOff + 16 * 1024;                       // W1 ring: 3 chunks
+constexpr int kW2Off = kW1Off + 3 * kW1Slot;                     // W2 ring: 4 chunks (two pairs)
+constexpr int kTabOff = kW2Off + 4 * kW2Slot;
 constexpr int kSmem = kTabOff + kGeluTabBytes;
 static_assert(kSmem <= 160 * 1024, "fused feed-forward tile does not fit the LDS");
 
@@ -45,88 +56,95 @@ struct FfArgs {
   const float* lnv; int ln_vdiv, ln_vmod, ln_ldv;
 };
 
-template <int EPI, bool LO = false>
+template <int EPI, bool LO = false, bool LN = false>
 __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rg = wid & 3, hh = wid >> 2;                      // row group, half (waves w and w + 4 share a SIMD)
   const int r32 = lane & 31, hsel = lane >> 5;
   const ctrlv_gemm_desc& d = a.o;
   const int M = d.M;
-  const int tiles = (M + 255) / 256, G = gridDim.x;
+  const int tiles = (M + kTileM - 1) / kTileM, G = gridDim.x;
 
   CTRLV_CLOCK_BEGIN();
   gelu_table_fill(smem + kTabOff, threadIdx.x, 512);
 
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1f, 0, kChunks * kW1Slot, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2f, 0, kChunks * kW2Slot, 0x00020000);
-  // The 31 KiB pieces of a chunk (21 of W1, then 10 of W2) are all issued by waves 0-3 (piece k * 4 + wid, k = 0..7): by
-  // the stamps (tools/ff_stamp.py) that group reached every window boundary ~900 cycles before waves 4-7 and waited at
-  // the barrier, while waves 4-7 -- the arbitration losers of their SIMDs -- spent 540 cycles issuing their four pieces
-  // right behind it (waves 0-3: 230).  `cg` = the workgroup's running chunk count (ring phase), `chunk` = which of the 80.
-  auto dma = [&](int chunk, int cg) {
-    if (wid >= 4) return;                                    // (wave-uniform)
-    char* s1 = smem + kW1Off + (cg & 1) * kW1Slot;
-    char* s2 = smem + kW2Off + (cg % 3) * kW2Slot;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)d.M * a.ldx * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.bias ? d.bias : (const float*)a.w1f), 0,
+                                                                         d.bias ? kC * 4 : 0, 0x00020000);
+  // LDS-DMA of one W1 chunk (21 KiB pieces) / one W2 chunk (10): the four waves of the half that is in its B segment
+  // take piece k * 4 + rg.  `g` = the workgroup's running chunk count (ring phase), `chunk` = which of the 80.
+  auto dma_w1 = [&](int chunk, int g) {
+    char* s1 = smem + kW1Off + (g % 3) * kW1Slot;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pi = k * 4 + wid;
+    for (int k = 0; k < 6; ++k) {
+      const int pi = k * 4 + rg;
       if (pi < kW1Pieces)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, LDS_PTR(s1 + pi * 1024), 16, lane * 16, chunk * kW1Slot + pi * 1024, 0, 0);
-      else if (pi < kW1Pieces + 10)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, LDS_PTR(s2 + (pi - kW1Pieces) * 1024), 16, lane * 16,
-                                                 chunk * kW2Slot + (pi - kW1Pieces) * 1024, 0, 0);
     }
   };
-  dma(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                           // chunk 0 and the table visible to every wave
-  dma(1, 1);                                                 // (every later DMA is issued at a window boundary)
-  const char* tab = smem + kTabOff;
-  char* const xhi = smem + wid * 10 * 1024 + lane * 16;
-  // The two waves of a SIMD (w, w + 4) run A THIRD OF A CHUNK APART: between two barriers group 0 does [GEMM 1, GEGLU,
-  // GEMM 2] of chunk c, group 1 [GEMM 2 of chunk c - 1, GEMM 1, GEGLU of chunk c] -- so one wave's GEGLU (VALU + table
-  // reads) runs beside its partner's MFMAs instead of beside its partner's GEGLU (in step, the matrix pipe idled through
-  // both: the first version of this kernel only tied with the two launches).  W2 chunks therefore live for two windows
-  // (3-slot ring).  The LDS for the third slot comes from the GEMM-1 bias: it is not a 10 KB strip read as the C operand
-  // but a 21st K step -- the packed W1 chunk carries (bf16(b), bf16(b - bf16(b))) in two K slots against a constant-one x
-  // fragment, which adds b to within 2^-17 |b| in the fp32 accumulator -- and from b2, read from global once per tile.
-  const int grp = wid >> 2;
-  const uint4 xone_u = hsel == 0 ? make_uint4(CTRLV_ELEM_DTYPE == 1 ? 0x3C003C00u : 0x3F803F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
-  const elx8 xone = __builtin_bit_cast(elx8, xone_u);
-
-  int cglob = 0;                                             // chunks processed so far by this workgroup (ring phase)
-  for (int tile = blockIdx.x; tile < tiles; tile += G) {
-    const int bm = tile * 256;
-    const int m = bm + wid * 32 + r32;
-    // ---- x rows of this wave as B fragments: k-step ks = columns ks*16 + 8*hsel .. +8 of row m
-    elx8 xr[10];
-    {
-      const el_t* xp = a.x + (long)m * a.ldx + 8 * hsel;
-      const bool ok = m < M;
+  auto dma_w2 = [&](int chunk, int g) {
+    char* s2 = smem + kW2Off + (g & 3) * kW2Slot;
 #pragma unroll
-      for (int ks = 0; ks < 10; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = *(const uint4*)(xp + ks * 16);
-        xr[ks] = __builtin_bit_cast(elx8, v);
-      }
-#pragma unroll
-      for (int ks = 10; ks < 20; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = *(const uint4*)(xp + ks * 16);
-        *(uint4*)(xhi + (ks - 10) * 1024) = v;
-      }
+    for (int k = 0; k < 3; ++k) {
+      const int pi = k * 4 + rg;
+      if (pi < 10)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, LDS_PTR(s2 + pi * 1024), 16, lane * 16, chunk * kW2Slot + pi * 1024, 0, 0);
     }
-    if (a.ln_g) {
+  };
+  // the W2 ring starts as zeros: the empty pair of the first tile multiplies it by zero h fragments (0 x NaN bits would not be 0)
+  for (int i = threadIdx.x * 16; i < 4 * kW2Slot; i += 512 * 16) *(uint4*)(smem + kW2Off + i) = make_uint4(0, 0, 0, 0);
+  // kernel start: W1 chunks 0 and 1 of the first tile (later tiles find theirs prefetched by the tile before)
+  if (hh == 0) dma_w1(0, 0); else dma_w1(1, 1);
+  wait_vmcnt<0>();
+  __syncthreads();                                           // chunks 0 / 1 and the table visible to every wave
+  const char* tab = smem + kTabOff;
+  const unsigned tab_lds = (unsigned)(unsigned long)LDS_PTR(smem + kTabOff);
+  char* const hfx = smem + kHfOff + rg * 4096 + lane * 16;   // this row group's four exchange buffers
+  // GEMM-1 bias: not a strip read as the C operand but a 21st K step -- the packed W1 chunk carries (bf16(b), bf16(b -
+  // bf16(b))) in two K slots against a constant-one x fragment, which adds b to within 2^-17 |b| in the fp32 accumulator
+  const unsigned xone1 = hsel == 0 ? (CTRLV_ELEM_DTYPE == 1 ? 0x3C003C00u : 0x3F803F80u) : 0u;   // (1, 1) in K slots 0, 1
+
+  int gbase = 0;                                             // chunks started so far by this workgroup (ring phase)
+  // The x rows (20 loads per lane) and the accumulator start (bias + the tile's row vector: one float4 for 40 lanes of a
+  // wave) of the NEXT tile are requested behind a tile's last A segment and arrive under its closing slots and epilogue: a
+  // tile used to open with 15-20 thousand cycles of exposed memory latency (16 % of its time with the epilogue).
+  elx8 xr[20];
+  u32x4_t ini_b, ini_v;
+  const __amdgpu_buffer_rsrc_t rsVt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.vtab ? a.vtab : (const float*)a.w1f), 0, a.vtab ? (int)((long)a.vmod * a.ldv * 4) : 0, 0x00020000);
+  auto tile_loads = [&](int tile) {
+    // (through buffer descriptors: rows >= M lie behind the end and read as zeros, an absent bias / row vector is an empty
+    //  descriptor -- no branch; 22 vector-memory operations: the closing slot barrier counts on that)
+    const int bm = tile * kTileM;
+    const unsigned xoff = (unsigned)(bm + rg * 32 + r32) * (unsigned)(a.ldx * 2) + 16 * hsel;
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks)
+      xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
+    const unsigned col4 = lane < 40 ? (unsigned)(hh * 160 + lane * 4) * 4 : 0xFFFFFFFFu;
+    ini_b = __builtin_amdgcn_raw_buffer_load_b128(rsB2, col4, 0, 0);
+    ini_v = __builtin_amdgcn_raw_buffer_load_b128(rsVt, col4, a.vtab ? ((bm / a.vdiv) % a.vmod) * (a.ldv * 4) : 0, 0);
+  };
+  tile_loads(blockIdx.x);
+  for (int tile = blockIdx.x; tile < tiles; tile += G, gbase += kChunks) {
+    const int bm = tile * kTileM;
+    const int m = bm + rg * 32 + r32;
+#ifdef CTRLV_FF_STAMP
+    unsigned long long st_tb; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_tb)::"memory");
+#endif
+    // ---- x rows of this row group as B fragments (both halves hold them): k-step ks = columns ks*16 + 8*hsel .. +8 of row m
+    if constexpr (LN) {
       // LayerNorm of the rows in place (the norm3 / norm_in in front of every feed-forward: one kernel launch and one
-      // write + read of the activation less).  A row's 320 values sit in its two lanes (hsel = 0 / 1, 160 each: 80 in xr,
-      // 80 in the wave's x_hi strip); statistics about the row's first value as pilot (shifted sums: no cancellation), one
-      // lane exchange; the normalised values are rounded to bf16 like ctrlv_layernorm's output and overwrite the raw ones.
+      // write + read of the activation less).  A row's 320 values sit in its two lanes (hsel = 0 / 1, 160 each);
+      // statistics about the row's first value as pilot (shifted sums: no cancellation), one lane exchange; the
+      // normalised values are rounded to the element type like ctrlv_layernorm's output and overwrite the raw ones.
       const float* lv = a.lnv ? a.lnv + (long)((m / a.ln_vdiv) % a.ln_vmod) * a.ln_ldv + 8 * hsel : nullptr;
       auto raw8 = [&](int ks, float* f) {
-        const uint4 v = ks < 10 ? __builtin_bit_cast(uint4, xr[ks]) : *(const uint4*)(xhi + (ks - 10) * 1024);
-        unpack_elx8(v, f);
+        unpack_elx8(__builtin_bit_cast(uint4, xr[ks]), f);
         if (lv) {
           const float4 p = *(const float4*)(lv + ks * 16), q = *(const float4*)(lv + ks * 16 + 4);
           f[0] += p.x; f[1] += p.y; f[2] += p.z; f[3] += p.w; f[4] += q.x; f[5] += q.y; f[6] += q.z; f[7] += q.w;
@@ -166,110 +184,216 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
         for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
         uint4 o = pack_elx8(f);
         if (!(m < M)) o = make_uint4(0, 0, 0, 0);
-        if (ks < 10) xr[ks] = __builtin_bit_cast(elx8, o);
-        else *(uint4*)(xhi + (ks - 10) * 1024) = o;
+        xr[ks] = __builtin_bit_cast(elx8, o);
         if (ks % 5 == 4) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // output accumulators start from b2 -- plus the tile's row vector: V is constant over a tile (vdiv is a multiple of
-    // 256, checked by the host; the frame positional embedding of ff_in: one vector per frame of S pixels) and s_acc is 1
-    // there, so it rides in the accumulator instead of the epilogue
-    f32x16 acc[1][10];
-    const float* vrow = a.vtab ? a.vtab + (long)((bm / a.vdiv) % a.vmod) * a.ldv : nullptr;
+    // output accumulators (this half's 160 columns) start from b2 -- plus the tile's row vector: V is constant over a tile
+    // (vdiv is a multiple of 256, checked by the host; the frame positional embedding of ff_in: one vector per frame of S
+    // pixels) and s_acc is 1 there, so it rides in the accumulator instead of the epilogue
+    f32x16 acc[1][5];
+    char* const stg = smem + kStgOff + wid * 4096;          // this wave's epilogue staging; here: the strip of its 160 start values
+    {
+      const f32x4 b = __builtin_bit_cast(f32x4, ini_b), w = __builtin_bit_cast(f32x4, ini_v);
+      if (lane < 40) *(float4*)(stg + lane * 16) = make_float4(b.x + w.x, b.y + w.y, b.z + w.z, b.w + w.w);
+      __builtin_amdgcn_wave_barrier();                       // (compiler-only: the strip is exchanged between lanes of this wave)
 #pragma unroll
-    for (int n = 0; n < 10; ++n)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias) v = *(const float4*)(d.bias + n * 32 + 8 * q + 4 * hsel);
-        if (vrow) {
-          const float4 w = *(const float4*)(vrow + n * 32 + 8 * q + 4 * hsel);
-          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
+      for (int i = 0; i < 20; ++i) {
+        const int n = i >> 2, q = i & 3;
+        const float4 v = *(const float4*)(stg + (n * 32 + 8 * q + 4 * hsel) * 4);
         acc[0][n][4 * q] = v.x; acc[0][n][4 * q + 1] = v.y; acc[0][n][4 * q + 2] = v.z; acc[0][n][4 * q + 3] = v.w;
       }
-    // One instruction stream for both groups -- GEMM 1, GEGLU, GEMM 2 per chunk -- and ONE window boundary per chunk (wait
-    // for the DMA issued a window ago, barrier, issue the DMA two chunks ahead), which group 0 takes after GEMM 2 and
-    // group 1 between GEGLU and GEMM 2.  Ring safety: after boundary k the W1 slot of chunk k + 2 was last read by GEMM 1
-    // of chunk k (both groups: before their boundary k), its W2 slot by group 1's GEMM 2 of chunk k - 1 (between its
-    // boundaries k - 1 and k).  x_hi, the staging and the accumulators are wave-private: a new tile needs no barrier.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the strip is read before the epilogue reuses the staging)
+    }
 #ifdef CTRLV_FF_STAMP      // diagnostic build (tools/ff_stamp.py): cycles per phase, summed per wave, written to a.lnv
 #define FSTAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-    unsigned long long st_g1 = 0, st_ge = 0, st_b = 0, st_g2 = 0;
+    unsigned long long st_g1 = 0, st_ge = 0, st_b = 0, st_bar = 0, st_dma = 0, st_mid = 0, st_tile0;
+    { FSTAMP(tt0); st_tile0 = tt0; }
 #else
 #define FSTAMP(v)
 #endif
-#ifdef CTRLV_FF_STAMP
-    unsigned long long st_w = 0, st_bar = 0, st_dma = 0;
-#endif
-    auto boundary = [&](int c) {
-      FSTAMP(b0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      FSTAMP(b1);
-      __syncthreads();
-      FSTAMP(b2);
-      dma((c + 2) % kChunks, cglob + 2);
-#ifdef CTRLV_FF_STAMP
-      FSTAMP(b3);
-      st_w += b1 - b0; st_bar += b2 - b1; st_dma += b3 - b2;
-#endif
-    };
-    for (int c = 0; c < kChunks; ++c, ++cglob) {
+    // ---- segment A of chunk t (this half's turn): GEMM 1 (21 chained MFMAs), GEGLU, h -> own registers + exchange buffer
+    elx8 hcur, hprev;                                        // this half's h of its last two chunks
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      hcur = hprev = __builtin_bit_cast(elx8, z);
+    }
+    // The slot's SECOND barrier: between the A half's MFMA chain and its GEGLU, and between the B half's DMA issue +
+    // fragment prefetch and its 10 MFMAs -- so that those MFMAs run beside the partner's GEGLU, not inside its chain
+    // (without it the chain took 31 x 32 cycles, the partner's MFMAs in it, and the pipe idled through the GEGLU)
+    auto mid_barrier = [&]() { lds_done_barrier(); };
+    auto seg_a = [&](int t) {
       FSTAMP(t0);
-      const char* s1 = smem + kW1Off + (cglob & 1) * kW1Slot + lane * 16;
+      // (the A segment is the slot's critical path: its wave outranks the partner, whose 10 MFMAs and DMA issue then take
+      //  the slots it leaves -- without it the younger half's chain took 1250 cycles against the older half's 860)
+      __builtin_amdgcn_s_setprio(2);
+      const char* s1 = smem + kW1Off + ((gbase + t) % 3) * kW1Slot + lane * 16;
+      elx8 wq[kNQ];
+#pragma unroll
+      for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
       f32x16 a1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) a1[e] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 20; ++ks) {
-        const elx8 wf = *(const elx8*)(s1 + ks * 1024);
-        const elx8 xf = ks < 10 ? xr[ks] : *(const elx8*)(xhi + (ks - 10) * 1024);
-        a1 = mfma_32x32x16(wf, xf, a1);
+      for (int ks = 0; ks < 21; ++ks) {                      // k-step 20: the bias against the constant-one fragment
+        elx8 xf;
+        if (ks == 20) {                                      // (built here: four registers for one step, not for the loop)
+          unsigned one = xone1;
+          asm volatile("" : "+v"(one));
+          xf = __builtin_bit_cast(elx8, make_uint4(one, 0, 0, 0));
+        } else {
+          xf = xr[ks];
+        }
+        a1 = mfma_32x32x16(wq[ks % kNQ], xf, a1);
+        if (ks + kNQ < 21) wq[ks % kNQ] = *(const elx8*)(s1 + (ks + kNQ) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      a1 = mfma_32x32x16(*(const elx8*)(s1 + 20 * 1024), xone, a1);   // + bias
       FSTAMP(t1);
+      mid_barrier();
+      FSTAMP(t1b);
       // GEGLU in the result layout: accumulators 0..7 are the 8 value columns of this lane, 8..15 their gates
+      // (table reads as asm statements with their own wait: the compiler puts a vmcnt(0) in front of an LDS read it knows
+      //  of when LDS-DMA of this wave is in flight -- the pieces this wave issued a slot ago -- and the wave stood there)
       float h[8];
+      {
+        float fr[8];
+        f32x2_t te[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = geglu_tab(a1[e], a1[8 + e], tab);
+        for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)
+          float tq = __builtin_fmaf(a1[8 + e], 100.0f, 512.0f);
+          tq = __builtin_amdgcn_fmed3f(tq, 0.0f, 1023.99994f);
+          fr[e] = __builtin_amdgcn_fractf(tq);
+          const unsigned addr = tab_lds + (unsigned)((int)tq) * 8u;
+          asm volatile("ds_read_b64 %0, %1" : "=v"(te[e]) : "v"(addr));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(te[6]), "+v"(te[7]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = geglu_tab_finish(a1[e], a1[8 + e], fr[e], make_float2(te[e].x, te[e].y));
+      }
       const uint4 hp = make_uint4(pack_elx2(h[0], h[1]), pack_elx2(h[2], h[3]), pack_elx2(h[4], h[5]),
                                   pack_elx2(h[6], h[7]));
-      const elx8 hf = __builtin_bit_cast(elx8, hp);
-      FSTAMP(t2);
-      if (grp == 1) boundary(c);
-      FSTAMP(t3);
-      const char* s2 = smem + kW2Off + (cglob % 3) * kW2Slot + lane * 16;
-#pragma unroll
-      for (int n = 0; n < 10; ++n) {
-        const elx8 wf = *(const elx8*)(s2 + n * 1024);
-        acc[0][n] = mfma_32x32x16(wf, hf, acc[0][n]);
-      }
-      FSTAMP(t4);
-      if (grp == 0) boundary(c);
+      *(uint4*)(hfx + (t & 3) * 1024) = hp;
+      hprev = hcur;
+      hcur = __builtin_bit_cast(elx8, hp);
+      __builtin_amdgcn_s_setprio(0);
 #ifdef CTRLV_FF_STAMP
-      FSTAMP(t5);
-      st_g1 += t1 - t0; st_ge += t2 - t1; st_b += (t3 - t2) + (t5 - t4); st_g2 += t4 - t3;
+      FSTAMP(t2);
+      st_g1 += t1 - t0; st_mid += t1b - t1; st_ge += t2 - t1b;
+#endif
+    };
+    // ---- segment B in slot t: the slot's LDS-DMA issue, then this half's 2 x 5 MFMAs of chunk pair j (chunks 2j, 2j + 1)
+    // the slot's LDS-DMA issue (the half in its B segment; the ring buffers written here were last read in slot t - 1)
+    auto seg_dma = [&](int t) {
+      FSTAMP(t0);
+      dma_w1((t + 2) % kChunks, gbase + t + 2);              // chunks 80, 81 = the next tile's 0, 1
+      if ((t & 1) == 0) { dma_w2(t, gbase + t); dma_w2(t + 1, gbase + t + 1); }
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(t1);
+      st_dma += t1 - t0;
+#endif
+    };
+    // ---- segment B: this half's 2 x 5 MFMAs of chunk pair j (chunks 2j, 2j + 1).  A pair outside 0..39 (the first B
+    // segment of half 0 and the last one of half 1: see the slot plan) runs on zero h fragments -- 10 MFMAs that add
+    // nothing, beside the partner's A segment, and in exchange the accumulators are updated in ONE straight line
+    auto seg_b = [&](int j) {
+      FSTAMP(t0);
+      const int c0 = 2 * j;
+      const bool live = j >= 0 && j < kChunks / 2;
+      const elx8 hpart = *(const elx8*)(hfx + ((c0 + (hh ^ 1)) & 3) * 1024);   // the partner's chunk of the pair
+      const char* s2a = smem + kW2Off + ((gbase + c0) & 3) * kW2Slot + (5 * hh) * 1024 + lane * 16;
+      const char* s2b = smem + kW2Off + ((gbase + c0 + 1) & 3) * kW2Slot + (5 * hh) * 1024 + lane * 16;
+      elx8 vq[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vq[i] = *(const elx8*)((i < 5 ? s2a + i * 1024 : s2b + (i - 5) * 1024));
+      // own h of the pair: half 0 computed chunk 2j two A segments ago (2j + 2 came in between), half 1 chunk 2j + 1 last
+      const uint4 hz = make_uint4(0, 0, 0, 0);
+      const uint4 hp_u = __builtin_bit_cast(uint4, hpart);
+      const uint4 own_u = hh == 0 ? __builtin_bit_cast(uint4, hprev) : __builtin_bit_cast(uint4, hcur);
+      const uint4 h0_u = !live ? hz : hh == 0 ? own_u : hp_u;
+      const uint4 h1_u = !live ? hz : hh == 0 ? hp_u : own_u;
+      const elx8 h0 = __builtin_bit_cast(elx8, h0_u), h1 = __builtin_bit_cast(elx8, h1_u);
+      FSTAMP(t0b);
+      mid_barrier();
+      FSTAMP(t0c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        acc[0][i % 5] = mfma_32x32x16(vq[i % 6], i < 5 ? h0 : h1, acc[0][i % 5]);
+        if (i + 6 < 10) vq[i % 6] = *(const elx8*)(s2b + (i + 6 - 5) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(t1);
+      st_b += (t1 - t0c) + (t0b - t0); st_mid += t0c - t0b;
+#endif
+    };
+    auto slot_barrier = [&](bool dma_wave) {
+      FSTAMP(b0);
+      if (dma_wave) wait_vmcnt<0>();                         // (its DMA of the slot before last: landed before this barrier)
+      lds_done_barrier();
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(b1);
+      st_bar += b1 - b0;
+#endif
+    };
+    // Slot plan, t = 0..81: half (t & 1) does A(chunk t) (t < 80), the other half the slot's DMA issue and a B segment.
+    // h of chunk c is written in slot c and read by the partner in slot c + 2; a wave's DMA of slot t is waited for (vmcnt)
+    // in front of the barrier of slot t + 2.  (The DMA issue FIRST in the B segment, under the partner's chain: behind the
+    // B MFMAs its 300-570 cycles made the B half the slot's critical path.)  Both halves run ONE program -- 40 x [A | DMA, B] and a closing B -- half 1 a
+    // slot behind half 0 (it opens with the DMA of slot 0, half 0 closes with the barrier of slot 81):
+    //   half 0: A(2k) in slot 2k,     B(pair k - 1) in slot 2k + 1  (k = 0: the empty pair -1), closing B(39) in slot 81
+    //   half 1: A(2k + 1) in slot 2k + 1, B(pair k) in slot 2k + 2,                           closing B(40): empty
+    // With the two roles as branches of one loop (or one loop per half) the register allocator put the accumulators of
+    // the paths into different registers: 40 v_mov_b64 per slot and spilled x fragments.
+    if (hh == 1) { slot_barrier(true); seg_dma(0); mid_barrier(); }
+    for (int k = 0; k < kChunks / 2; ++k) {
+      slot_barrier(false);
+      seg_a(2 * k + hh);
+      slot_barrier(true);
+      if (2 * k + 1 + hh < kChunks) seg_dma(2 * k + 1 + hh);
+      seg_b(k - 1 + hh);
+    }
+    tile_loads(tile + G);                                    // (the x registers are free: both halves are past their last A)
+    slot_barrier(false);
+    if (hh == 0) {
+      mid_barrier();
+      FSTAMP(b0);
+      wait_vmcnt<22>();                                      // its DMA of slot 79 -- everything but the 22 loads just issued
+      lds_done_barrier();
+#ifdef CTRLV_FF_STAMP
+      FSTAMP(b1);
+      st_bar += b1 - b0;
 #endif
     }
+    hprev = hcur;                                            // (half 0: no A segment came after chunk 78's)
+    seg_b(kChunks / 2 - 1 + hh);
 #ifdef CTRLV_FF_STAMP
     if (lane == 0 && a.lnv) {
-      unsigned long long* o = (unsigned long long*)a.lnv + ((long)blockIdx.x * 8 + wid) * 4;
-      o[0] += st_g1; o[1] += st_w; o[2] += st_bar; o[3] += st_dma;      // (variant: the boundary split up)
-      (void)st_ge; (void)st_b; (void)st_g2;
+      FSTAMP(tt1);
+      unsigned long long* o = (unsigned long long*)a.lnv + ((long)blockIdx.x * 8 + wid) * 8;
+      o[0] += st_g1; o[1] += st_ge; o[2] += st_dma; o[3] += st_b; o[4] += st_bar + st_mid; o[5] += tt1 - st_tile0;
+      o[6] += st_tile0 - st_tb;
     }
+    unsigned long long st_e0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_e0)::"memory");
 #endif
-    // (x fragments are dead here: end their live ranges so that the epilogue's prefetch window gets their registers)
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) asm volatile("" : "=v"(xr[ks]));
-    // ---- epilogue: the ping-pong GEMM's, on this wave's 32 x 320 block; staging = four KiB of the wave's x_hi strip
-    char* stg = smem + wid * 10 * 1024;
+    // ---- epilogue: the ping-pong GEMM's, on this wave's 32 x 160 block; staging = four KiB of this wave's own
     int lane_e = lane;                                       // (opaque copy: keeps the epilogue's lane constants per-tile values
     asm volatile("" : "+v"(lane_e));                         //  instead of hoisted, spilled ones -- gemm_pp_kernel.h)
-    gemm_epilogue_lds<1, 10, false, EPI, false, false, LO>(d, acc, bm, 0, wid, 0, 32, kC, lane_e, stg, stg + 1024, stg + 2048,
-                                                           stg + 3072, nullptr, tab);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging reads done before the next tile's x_hi writes
+    gemm_epilogue_lds<1, 5, false, EPI, false, false, LO>(d, acc, bm, 0, rg, hh, 32, 160, lane_e, stg, stg + 1024, stg + 2048,
+                                                          stg + 3072, nullptr, tab);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging reads done before the next tile's writes
+#ifdef CTRLV_FF_STAMP
+    if (lane == 0 && a.lnv) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long st_e1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_e1)::"memory");
+      ((unsigned long long*)a.lnv + ((long)blockIdx.x * 8 + wid) * 8)[7] += st_e1 - st_e0;
+    }
+#endif
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last chunks: nothing may be in flight
+  wait_vmcnt<0>();                                           // the look-ahead DMA of the last slots: nothing may be in flight
   CTRLV_CLOCK_END();
 #endif
 }
@@ -302,17 +426,17 @@ __global__ void ff_pack_kernel(const el_t* __restrict__ w1p, const float* __rest
   }
 }
 
-template <int EPI, bool LO = false>
-int launch_ff(const FfArgs& a, hipStream_t stream) {
+template <int EPI, bool LO, bool LN>
+int launch_ff_ln(const FfArgs& a, hipStream_t stream) {
   static bool attr_set[CTRLV_MAX_DEVICES] = {};
-  auto kfn = ff_fused_kernel<EPI, LO>;
+  auto kfn = ff_fused_kernel<EPI, LO, LN>;
   const int dev = ctrlv_current_device();
   if (!attr_set[dev]) {
     CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
     attr_set[dev] = true;
   }
   const int num_cu = ctrlv_num_cu(dev);
-  const int tiles = (a.o.M + 255) / 256;
+  const int tiles = (a.o.M + kTileM - 1) / kTileM;
   int grid = tiles;
   if (tiles > num_cu) {                     // persistent, every workgroup the same number of tiles
     const int rounds = (tiles + num_cu - 1) / num_cu;
@@ -321,6 +445,12 @@ int launch_ff(const FfArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kSmem, stream, a);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
+}
+
+// (the LayerNorm prologue is a kernel of its own: its registers and spills stay out of the plain kernel)
+template <int EPI, bool LO = false>
+int launch_ff(const FfArgs& a, hipStream_t stream) {
+  return a.ln_g ? launch_ff_ln<EPI, LO, true>(a, stream) : launch_ff_ln<EPI, LO, false>(a, stream);
 }
 
 }  // namespace

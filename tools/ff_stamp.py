@@ -40,7 +40,7 @@ def main():
     x, r1 = r(M, C).bfloat16(), r(M, C).bfloat16()
     out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
     b2 = r(C)
-    stamps = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=DEV)
+    stamps = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=DEV)   # [workgroup][wave][GEMM1, GEGLU, DMA, B, barrier, slot loop]
     d = _lib.GemmDesc()
     d.out, d.bias, d.R1 = out.data_ptr(), b2.data_ptr(), r1.data_ptr()
     d.M, d.N, d.Cin, d.taps, d.mode = M, 320, 1280, 1, 0
@@ -53,13 +53,25 @@ def main():
                                vp(w1f.data_ptr()), vp(w2f.data_ptr()), ctypes.byref(d), st)
     torch.cuda.synchronize()
     print("rc", rc)
-    s = stamps.view(-1, 8, 4).double()
+    s = stamps.view(-1, 8, 8).double()
     s = s[s[:, 0, 0] > 0]
-    nchunk = 80 * 8
-    print(f"{s.shape[0]} workgroups; cycles per chunk (8 tiles x 80 chunks per workgroup):  GEMM1 | vmcnt wait | barrier | DMA issue | (sum)")
+    nslot = 40 * 15                                         # A segments per wave: 40 per 128-row tile x 15 tiles per workgroup
+    print(f"{s.shape[0]} workgroups; cycles per A segment / DMA issue / B segment / slot barriers, per wave and slot PAIR;")
+    print("last column: the whole slot loop of a tile / 40 (what a slot pair takes, the closing slots included)")
+    print("            GEMM1 | GEGLU+h | DMA issue |   B   | barriers | (sum) | slot loop / 40")
     for w in range(8):
-        v = [s[:, w, i].mean().item() / nchunk for i in range(4)]
-        print(f"  wave {w}: " + " ".join(f"{x_:7.0f}" for x_ in v) + f"   {sum(v):7.0f}")
+        v = [s[:, w, i].mean().item() / nslot for i in range(8)]
+        print(f"  wave {w}: " + " ".join(f"{x_:8.0f}" for x_ in v[:5]) + f"   {sum(v[:5]):7.0f}   {v[5]:7.0f}" +
+              f"   per tile: prologue {v[6] * 40:7.0f}  slot loop {v[5] * 40:8.0f}  epilogue (stores drained) {v[7] * 40:7.0f}")
+    ms = []
+    for _ in range(3):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        lib.ctrlv_ff_fused_ln(vp(x.data_ptr()), 320, None, None, ctypes.c_float(0), vp(stamps.data_ptr()), 1, 1, 320,
+                              vp(w1f.data_ptr()), vp(w2f.data_ptr()), ctypes.byref(d), st)
+        t1.record(); torch.cuda.synchronize()
+        ms.append(t0.elapsed_time(t1))
+    print("stamped launch: " + " ".join(f"{m_ * 1e3:.0f}" for m_ in ms) + " us")
 
 
 if __name__ == "__main__":
