@@ -76,7 +76,11 @@ __device__ __forceinline__ void unpack_elx8(const uint4& v, float* f) {
 __device__ __forceinline__ float el_to_f32(el_t v) { return bf16_to_f32(v); }
 __device__ __forceinline__ el_t f32_to_el(float f) { return f32_to_bf16(f); }
 __device__ __forceinline__ uint32_t pack_elx2(float lo, float hi) {
-  return (uint32_t)f32_to_el(lo) | ((uint32_t)f32_to_el(hi) << 16);
+  // (as ONE two-element conversion: v_cvt_pk_bf16_f32 d, lo, hi.  Written as two scalar conversions joined by shift and or
+  //  it compiled to two v_cvt_pk_bf16_f32 x, 0 plus v_lshlrev + v_or_sdwa: four instructions per pair in every epilogue)
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ void unpack_elx8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
