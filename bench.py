@@ -511,6 +511,34 @@ def main():
                 pmc["_source"] = os.path.relpath(cands[-1], ROOT)
     except Exception as ex:       # noqa: BLE001
         pmc_note = f"PMC summary unreadable: {ex}"
+    # Matrix-pipe utilisation and clock per MFMA family from the committed counter pass (tools/pmc_mfma_pass.sh:
+    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), clock = GRBM_GUI_ACTIVE / 8 / dispatch time; plus the
+    # in-kernel clock of the probe kernels of a diagnostic build): same build-id rule as the HBM traffic above.
+    mfma, mfma_note = {}, None
+    try:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_busy_summary.json")))
+        if not cands:
+            mfma_note = "no MFMA-busy summary under profiles/"
+        else:
+            raw = json.load(open(cands[-1]))
+            if raw.get("_build_id") != _lib.build_id(lib) or args.dtype != "bf16" or not default_shape:
+                mfma_note = (f"{os.path.relpath(cands[-1], ROOT)} was collected from library build "
+                             f"{raw.get('_build_id', 'unstamped')} (bf16, default shape), running {_lib.build_id(lib)} "
+                             f"({args.dtype}): mfma_busy / clock_ghz = null")
+            else:
+                for fam in ("gemm_linear", "gemm_conv3x3", "gemm_conv_temporal", "attention_spatial"):
+                    parts = {k.split(".", 1)[1]: v for k, v in raw.items() if k.startswith(fam + ".") and isinstance(v, dict)}
+                    if parts:
+                        busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in parts.values())
+                        act = sum(v["GRBM_GUI_ACTIVE"] for v in parts.values())
+                        ms = sum(v["ms"] for v in parts.values())
+                        mfma[fam] = {"mfma_busy": round(busy / (act / 8 * 1024), 4), "clock_ghz": round(act / 8 / (ms * 1e-3) / 1e9, 3),
+                                     "mfma_busy_by_kernel": {k: v["mfma_busy"] for k, v in parts.items()}}
+                mfma["_source"] = os.path.relpath(cands[-1], ROOT)
+                if isinstance(raw.get("in_kernel_clock"), (dict, list)):
+                    mfma["_in_kernel_clock"] = raw["in_kernel_clock"]
+    except Exception as ex:       # noqa: BLE001
+        mfma_note = f"MFMA-busy summary unreadable: {ex}"
     rooflines = {}
     for fam, d in fams.items():
         sec = d["ms"] * 1e-3
@@ -520,7 +548,9 @@ def main():
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                               "traffic": pmc.get(fam), "traffic_launches": pmc_launches.get(fam),
                               "ms_per_step": round(d["ms"], 3), "launches": d["calls"],
-                              "avg_launch_ms": round(d["ms"] / d["calls"], 4)}
+                              "avg_launch_ms": round(d["ms"] / d["calls"], 4),
+                              "mfma_busy": mfma.get(fam, {}).get("mfma_busy"), "clock_ghz": mfma.get(fam, {}).get("clock_ghz"),
+                              "mfma_busy_by_kernel": mfma.get(fam, {}).get("mfma_busy_by_kernel")}
         else:
             ach = d["bytes"] / sec / 1e9
             rooflines[fam] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -559,6 +589,7 @@ def main():
         "lib_build_id": _lib.build_id(lib),
         "roofline": roofline, "rooflines": rooflines,
         "traffic_source": pmc.get("_source"), "traffic_note": pmc_note,
+        "mfma_busy_source": mfma.get("_source"), "mfma_busy_note": mfma_note, "in_kernel_clock": mfma.get("_in_kernel_clock"),
     }
     if world == 1 and not args.no_cpu_baseline:
         del st
