@@ -28,8 +28,6 @@
 // rounding of u as the two-launch path; GEMM 2 sums its K = 1280 in chunk order with the permuted slot assignment, so
 // its fp32 sums differ from ctrlv_gemm's in the last bits.  Every C = 320 feed-forward of the inference path goes through
 // this kernel whatever M is (the training forward keeps the two launches: it needs u and the raw projection).
-#include <type_traits>
-
 #include "common.h"
 #include "gemm_pp_kernel.h"
 
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
     }
 #ifdef CTRLV_FF_STAMP      // diagnostic build (tools/ff_stamp.py): cycles per phase, summed per wave, written to a.lnv
 #define FSTAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-    unsigned long long st_g1 = 0, st_ge = 0, st_b = 0, st_bar = 0, st_dma = 0, st_tile0;
+    unsigned long long st_g1 = 0, st_ge = 0, st_b = 0, st_bar = 0, st_dma = 0, st_mid = 0, st_tile0;
     { FSTAMP(tt0); st_tile0 = tt0; }
 #else
 #define FSTAMP(v)
@@ -220,41 +218,14 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       const uint4 z = make_uint4(0, 0, 0, 0);
       hcur = hprev = __builtin_bit_cast(elx8, z);
     }
-    // GEGLU of elements E0..E1-1 of the chain's result, in the result layout: accumulators 0..7 are the 8 value columns of
-    // this lane, 8..15 their gates.  (Table reads as asm statements with their own wait: the compiler puts a vmcnt(0) in
-    // front of an LDS read it knows of when LDS-DMA of this wave is in flight, and the wave stood there.)
-    auto geglu_part = [&](auto e0c, auto e1c, const float* av, const float* gv, float* h) {
-      constexpr int E0 = decltype(e0c)::value, E1 = decltype(e1c)::value, NE = E1 - E0;
-      float fr[NE];
-      f32x2_t te[NE];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-#pragma clang fp contract(off)
-        float tq = __builtin_fmaf(gv[E0 + e], 100.0f, 512.0f);
-        tq = __builtin_amdgcn_fmed3f(tq, 0.0f, 1023.99994f);
-        fr[e] = __builtin_amdgcn_fractf(tq);
-        const unsigned addr = tab_lds + (unsigned)((int)tq) * 8u;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(te[e]) : "v"(addr));
-      }
-      static_assert(NE == 4, "four columns per part");
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]));
-#pragma unroll
-      for (int e = 0; e < NE; ++e) h[E0 + e] = geglu_tab_finish(av[E0 + e], gv[E0 + e], fr[e], make_float2(te[e].x, te[e].y));
-    };
-    // The slot's SECOND barrier: between the A half's MFMA chain and its GEGLU columns, and between the B half's DMA issue,
-    // GEGLU columns, fragment prefetch and its 10 MFMAs -- so that those MFMAs run beside the partner's GEGLU, not inside
-    // its chain (without it the chain took 31 x 32 cycles, the partner's MFMAs in it, and the pipe idled through the GEGLU).
+    // The slot's SECOND barrier: between the A half's MFMA chain and its GEGLU, and between the B half's DMA issue +
+    // fragment prefetch and its 10 MFMAs -- so that those MFMAs run beside the partner's GEGLU, not inside its chain
+    // (without it the chain took 31 x 32 cycles, the partner's MFMAs in it, and the pipe idled through the GEGLU)
     auto mid_barrier = [&]() { lds_done_barrier(); };
-    // ---- A slot of chunk t (this half's turn): GEMM 1 (21 chained MFMAs) | mid barrier | the GEGLU of four of the lane's
-    // eight columns.  The other four wait for the wave's NEXT slot (its B role), in front of that slot's mid barrier, where
-    // the B half has slack under the partner's chain: the second half of a slot is then as long as the 10 MFMAs, not as
-    // the whole GEGLU.  (Whole GEGLU here: 1.17 ms at M = 460 800.  One barrier per slot with the GEGLU, or six of its
-    // eight columns, and the DMA issue moved between the roles: 1.25-1.27 ms -- the partner's MFMAs ran inside the chain.)
-    uint32_t hpk[2];                                         // packed h columns 0..3 of the chunk of this wave's last A slot
-    float ak[4], gk[4];                                      // its raw columns 4..7 (value, gate)
-    auto seg_g1 = [&](int t) {
+    auto seg_a = [&](int t) {
       FSTAMP(t0);
-      // (the chain is the slot's critical path: its wave outranks the partner)
+      // (the A segment is the slot's critical path: its wave outranks the partner, whose 10 MFMAs and DMA issue then take
+      //  the slots it leaves -- without it the younger half's chain took 1250 cycles against the older half's 860)
       __builtin_amdgcn_s_setprio(2);
       const char* s1 = smem + kW1Off + ((gbase + t) % 3) * kW1Slot + lane * 16;
       elx8 wq[kNQ];
@@ -281,37 +252,40 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       FSTAMP(t1);
       mid_barrier();
       FSTAMP(t1b);
-      float av[8], gv[8], h[8];
+      // GEGLU in the result layout: accumulators 0..7 are the 8 value columns of this lane, 8..15 their gates
+      // (table reads as asm statements with their own wait: the compiler puts a vmcnt(0) in front of an LDS read it knows
+      //  of when LDS-DMA of this wave is in flight -- the pieces this wave issued a slot ago -- and the wave stood there)
+      float h[8];
+      {
+        float fr[8];
+        f32x2_t te[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { av[e] = a1[e]; gv[e] = a1[8 + e]; }
-      geglu_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, av, gv, h);
-      hpk[0] = pack_elx2(h[0], h[1]); hpk[1] = pack_elx2(h[2], h[3]);
+        for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)
+          float tq = __builtin_fmaf(a1[8 + e], 100.0f, 512.0f);
+          tq = __builtin_amdgcn_fmed3f(tq, 0.0f, 1023.99994f);
+          fr[e] = __builtin_amdgcn_fractf(tq);
+          const unsigned addr = tab_lds + (unsigned)((int)tq) * 8u;
+          asm volatile("ds_read_b64 %0, %1" : "=v"(te[e]) : "v"(addr));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(te[6]), "+v"(te[7]));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { ak[e] = av[4 + e]; gk[e] = gv[4 + e]; }
-      __builtin_amdgcn_s_setprio(0);
-#ifdef CTRLV_FF_STAMP
-      FSTAMP(t2);
-      st_g1 += t1 - t0; st_bar += t1b - t1; st_ge += t2 - t1b;
-#endif
-    };
-    // ---- the other four columns of chunk t (B slot, in front of its mid barrier): h -> own registers + the exchange buffer the partner reads a slot on
-    auto seg_ge = [&](int t) {
-      FSTAMP(t1b);
-      float av[8], gv[8], h[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { av[4 + e] = ak[e]; gv[4 + e] = gk[e]; }
-      geglu_part(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}, av, gv, h);
-      const uint4 hp = make_uint4(hpk[0], hpk[1], pack_elx2(h[4], h[5]), pack_elx2(h[6], h[7]));
+        for (int e = 0; e < 8; ++e) h[e] = geglu_tab_finish(a1[e], a1[8 + e], fr[e], make_float2(te[e].x, te[e].y));
+      }
+      const uint4 hp = make_uint4(pack_elx2(h[0], h[1]), pack_elx2(h[2], h[3]), pack_elx2(h[4], h[5]),
+                                  pack_elx2(h[6], h[7]));
       *(uint4*)(hfx + (t & 3) * 1024) = hp;
       hprev = hcur;
       hcur = __builtin_bit_cast(elx8, hp);
+      __builtin_amdgcn_s_setprio(0);
 #ifdef CTRLV_FF_STAMP
       FSTAMP(t2);
-      st_ge += t2 - t1b;
+      st_g1 += t1 - t0; st_mid += t1b - t1; st_ge += t2 - t1b;
 #endif
     };
-    // the slot's LDS-DMA issue (the half in its B role, first thing: the W1 chunk read two slots on, in even slots the W2
-    // pair read from two slots on; the ring buffers written here were last read in slot t - 1)
+    // ---- segment B in slot t: the slot's LDS-DMA issue, then this half's 2 x 5 MFMAs of chunk pair j (chunks 2j, 2j + 1)
+    // the slot's LDS-DMA issue (the half in its B segment; the ring buffers written here were last read in slot t - 1)
     auto seg_dma = [&](int t) {
       FSTAMP(t0);
       dma_w1((t + 2) % kChunks, gbase + t + 2);              // chunks 80, 81 = the next tile's 0, 1
@@ -353,7 +327,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       }
 #ifdef CTRLV_FF_STAMP
       FSTAMP(t1);
-      st_b += (t1 - t0c) + (t0b - t0); st_bar += t0c - t0b;
+      st_b += (t1 - t0c) + (t0b - t0); st_mid += t0c - t0b;
 #endif
     };
     auto slot_barrier = [&](bool dma_wave) {
@@ -365,25 +339,24 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       st_bar += b1 - b0;
 #endif
     };
-    // Slot plan, t = 0..81, a slot barrier and a mid barrier per slot: half (t & 1) has its A slot of chunk t (t < 80): the
-    // chain | four columns of the GEGLU; the other half its B slot: the slot's DMA issue, the other four columns of the chunk
-    // of its A slot before, fragment prefetch | 10 MFMAs of a chunk pair.
-    //   half 0: chain(2k) in slot 2k,     h(2k), B(pair k - 1) in slot 2k + 1  (k = 0: the empty pair -1); B(39) in slot 81
-    //   half 1: chain(2k + 1) in slot 2k + 1, h(2k + 1), B(pair k) in slot 2k + 2;                 the empty B(40) in slot 81
-    // Both halves run ONE program, half 1 a slot behind half 0 (with the two roles as branches of one loop, or one loop per
-    // half, the register allocator put the accumulators of the paths into different registers: 40 v_mov_b64 per slot and
-    // spilled x fragments).  h of chunk c is written in slot c + 1 and read by the partner in slot c + 2.  A wave waits for
-    // its own LDS-DMA of slot t (vmcnt) in front of the barrier of slot t + 2, its next B slot.
+    // Slot plan, t = 0..81: half (t & 1) does A(chunk t) (t < 80), the other half the slot's DMA issue and a B segment.
+    // h of chunk c is written in slot c and read by the partner in slot c + 2; a wave's DMA of slot t is waited for (vmcnt)
+    // in front of the barrier of slot t + 2.  (The DMA issue FIRST in the B segment, under the partner's chain: behind the
+    // B MFMAs its 300-570 cycles made the B half the slot's critical path.)  Both halves run ONE program -- 40 x [A | DMA, B] and a closing B -- half 1 a
+    // slot behind half 0 (it opens with the DMA of slot 0, half 0 closes with the barrier of slot 81):
+    //   half 0: A(2k) in slot 2k,     B(pair k - 1) in slot 2k + 1  (k = 0: the empty pair -1), closing B(39) in slot 81
+    //   half 1: A(2k + 1) in slot 2k + 1, B(pair k) in slot 2k + 2,                           closing B(40): empty
+    // With the two roles as branches of one loop (or one loop per half) the register allocator put the accumulators of
+    // the paths into different registers: 40 v_mov_b64 per slot and spilled x fragments.
     if (hh == 1) { slot_barrier(true); seg_dma(0); mid_barrier(); }
     for (int k = 0; k < kChunks / 2; ++k) {
       slot_barrier(false);
-      seg_g1(2 * k + hh);
+      seg_a(2 * k + hh);
       slot_barrier(true);
-      seg_ge(2 * k + hh);                                    // (in front of the DMA issue: the compiler puts a vmcnt(0) before an
-      if (2 * k + 1 + hh < kChunks) seg_dma(2 * k + 1 + hh); //  LDS store -- h -- while LDS-DMA of the wave is in flight)
+      if (2 * k + 1 + hh < kChunks) seg_dma(2 * k + 1 + hh);
       seg_b(k - 1 + hh);
     }
-    tile_loads(tile + G);                                    // (the x registers are free: both halves are past their last chain)
+    tile_loads(tile + G);                                    // (the x registers are free: both halves are past their last A)
     slot_barrier(false);
     if (hh == 0) {
       mid_barrier();
@@ -395,13 +368,13 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FfArgs a) {
       st_bar += b1 - b0;
 #endif
     }
-    hprev = hcur;                                            // (half 0: no GEGLU came after chunk 78's)
+    hprev = hcur;                                            // (half 0: no A segment came after chunk 78's)
     seg_b(kChunks / 2 - 1 + hh);
 #ifdef CTRLV_FF_STAMP
     if (lane == 0 && a.lnv) {
       FSTAMP(tt1);
       unsigned long long* o = (unsigned long long*)a.lnv + ((long)blockIdx.x * 8 + wid) * 8;
-      o[0] += st_g1; o[1] += st_ge; o[2] += st_dma; o[3] += st_b; o[4] += st_bar; o[5] += tt1 - st_tile0;
+      o[0] += st_g1; o[1] += st_ge; o[2] += st_dma; o[3] += st_b; o[4] += st_bar + st_mid; o[5] += tt1 - st_tile0;
       o[6] += st_tile0 - st_tb;
     }
     unsigned long long st_e0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_e0)::"memory");
