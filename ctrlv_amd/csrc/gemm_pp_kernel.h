@@ -45,6 +45,30 @@ namespace {
 #define STAMP_ADD(acc, a, b)
 #endif
 
+// counted LDS wait that "defines" the four registers it covers (the consumer cannot be scheduled above it)
+template <int N>
+__device__ __forceinline__ void wait_lgkm_tied(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));
+}
+// the TN x 4 strip reads of a tile's bias start (one address register, the displacement as the instruction's offset)
+template <int TN, int N = 0>
+__device__ __forceinline__ void bias_read_blocks(f32x4 (&bq)[TN][4], unsigned base) {
+  if constexpr (N < TN) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[N][0]) : "v"(base), "n"(N * 128) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[N][1]) : "v"(base), "n"(N * 128 + 32) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[N][2]) : "v"(base), "n"(N * 128 + 64) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[N][3]) : "v"(base), "n"(N * 128 + 96) : "memory");
+    bias_read_blocks<TN, N + 1>(bq, base);
+  }
+}
+// sub-tile n of TN bias blocks (four reads each, issued in order n = 0..TN-1): wait until block n has landed
+template <int TN, int N = 0>
+__device__ __forceinline__ void bias_wait_blocks(f32x4 (&bq)[TN][4]) {
+  if constexpr (N < TN) {
+    wait_lgkm_tied<4 * (TN - 1 - N)>(bq[N][0], bq[N][1], bq[N][2], bq[N][3]);
+    bias_wait_blocks<TN, N + 1>(bq);
+  }
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -53,6 +77,41 @@ __device__ __forceinline__ void lds_done_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// Epilogue staging accesses as asm statements.  While LDS-DMA of a wave is in flight the compiler puts an `s_waitcnt
+// vmcnt(0)` in front of the first LDS store (and of LDS reads it cannot tell apart from the DMA's targets) it knows of --
+// and at the top of an epilogue the next tile's first pieces AND the residual rows just requested are in flight: every tile
+// began its epilogue by waiting for all of them (HBM latency), the prefetch window of the residuals defeated for its first
+// sub-tiles.  The staging pieces are never a DMA target while the epilogue runs (the just-consumed ring slot / a strip of
+// the wave's own), so no wait is needed; LDS operations of one wave execute in order, the reads carry their own lgkmcnt
+// wait.  -DCTRLV_PP_ASM_STAGING=0: plain C++ accesses (A/B handle for tools/ab_build.py).
+#ifndef CTRLV_PP_ASM_STAGING
+#define CTRLV_PP_ASM_STAGING 1
+#endif
+__device__ __forceinline__ void stg_write16(char* p, float a, float b, float c, float d) {
+#if CTRLV_PP_ASM_STAGING
+  const f32x4 v = {a, b, c, d};
+  asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(unsigned long)LDS_PTR(p)), "v"(v) : "memory");
+#else
+  *(float4*)p = make_float4(a, b, c, d);
+#endif
+}
+// the four 16-byte reads of a sub-tile's two passes (issued together, one wait)
+__device__ __forceinline__ void stg_read4x16(const char* a0, const char* a1, const char* b0, const char* b1, float4 (&img)[2][2]) {
+#if CTRLV_PP_ASM_STAGING
+  f32x4 r0, r1, r2, r3;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"((unsigned)(unsigned long)LDS_PTR(a0)) : "memory");
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r1) : "v"((unsigned)(unsigned long)LDS_PTR(a1)) : "memory");
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r2) : "v"((unsigned)(unsigned long)LDS_PTR(b0)) : "memory");
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r3) : "v"((unsigned)(unsigned long)LDS_PTR(b1)) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory");
+  img[0][0] = make_float4(r0.x, r0.y, r0.z, r0.w); img[0][1] = make_float4(r1.x, r1.y, r1.z, r1.w);
+  img[1][0] = make_float4(r2.x, r2.y, r2.z, r2.w); img[1][1] = make_float4(r3.x, r3.y, r3.z, r3.w);
+#else
+  img[0][0] = *(const float4*)a0; img[0][1] = *(const float4*)a1;
+  img[1][0] = *(const float4*)b0; img[1][1] = *(const float4*)b1;
+#endif
+}
 
 // Epilogue through a per-wave LDS transpose.  In the MFMA result layout a lane owns one output ROW of a 32x32
 // sub-tile, so direct stores are 8 bytes per lane at a row stride: every store / residual-load instruction touches
@@ -129,7 +188,12 @@ __device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_
 
 template <int WTN>
 __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, int lane) {
+  // (asm for the reason given at stg_write16: the refill behind an epilogue runs with the next tile's LDS-DMA in flight)
+#if CTRLV_PP_ASM_STAGING
+  if (lane < WTN / 4) asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(unsigned long)LDS_PTR(bias_lds + lane * 16)), "v"(v) : "memory");
+#else
   if (lane < WTN / 4) *(u32x4_t*)(bias_lds + lane * 16) = v;
+#endif
 }
 
 // GNS (producer-side GroupNorm statistics, round 4): the launch also writes, per 64-row wave tile and group of N / 32
@@ -278,17 +342,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int c = (2 * qd + hsel) ^ (r32 & 7);
-        *(float4*)(wrow + c * 16) =
-            make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+        stg_write16(wrow + c * 16, acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
       }
       __builtin_amdgcn_wave_barrier();     // compiler-only: the image is exchanged between lanes of this wave
       float4 img[2][2];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const char* rp = pass ? rp_b : rp_a;
-        img[pass][0] = *(const float4*)(rp + rx0);
-        img[pass][1] = *(const float4*)(rp + rx1);
-      }
+      stg_read4x16(rp_a + rx0, rp_a + rx1, rp_b + rx0, rp_b + rx1, img);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -433,17 +491,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const int c = (2 * qd + hsel) ^ (r32 & 7);
-          *(float4*)(wrow + c * 16) =
-              make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+          stg_write16(wrow + c * 16, acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
         }
         __builtin_amdgcn_wave_barrier();
         float4 img[2][2];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const char* rp = pass ? rp_b : rp_a;
-          img[pass][0] = *(const float4*)(rp + rx0);
-          img[pass][1] = *(const float4*)(rp + rx1);
-        }
+        stg_read4x16(rp_a + rx0, rp_a + rx1, rp_b + rx0, rp_b + rx1, img);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -507,7 +559,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
         for (int qd = 0; qd < 2; ++qd) {
           const int c = (half * 4 + 2 * qd + hsel) ^ (r32 & 7), k = half * 8 + qd * 4;
-          *(float4*)(wrow + c * 16) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+          stg_write16(wrow + c * 16, o[k], o[k + 1], o[k + 2], o[k + 3]);
         }
       }
       const int ocol = ((wbase_n + j * 32) >> 1) + l4 * 8;
@@ -515,12 +567,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       const bool col_ok = ocol < d.n_store && (l4 < 2 || (j + 1 < TN && wbase_n + (j + 1) * 32 < d.N));
       __builtin_amdgcn_wave_barrier();   // compiler-only: the image is exchanged between lanes of this wave
       float4 img[2][2];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const char* rp = pass ? rp_b : rp_a;
-        img[pass][0] = *(const float4*)(rp + rx0);
-        img[pass][1] = *(const float4*)(rp + rx1);
-      }
+      stg_read4x16(rp_a + rx0, rp_a + rx1, rp_b + rx0, rp_b + rx1, img);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -976,6 +1023,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
     for (int grpi = 0; grpi < 4; ++grpi) {
       const int ks = grpi >> 1, i0 = (grpi & 1) * HM;
       if (MAY_BE_FIRST && j == 0 && ks == 0) {
+#if CTRLV_PP_ASM_STAGING
+        // (the strip reads as asm statements: see stg_write16 -- the compiler put a vmcnt(0) in front of them, i.e. every
+        //  tile opened by waiting for all of its LDS-DMA in flight, the three half-steps of look-ahead included)
+        f32x4 bq[TN][4];
+        bias_read_blocks<TN>(bq, (unsigned)(unsigned long)LDS_PTR(bias_lds + 16 * hsel));
+        bias_wait_blocks<TN>(bq);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          f32x16 bc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { bc[4 * q] = bq[n][q].x; bc[4 * q + 1] = bq[n][q].y; bc[4 * q + 2] = bq[n][q].z; bc[4 * q + 3] = bq[n][q].w; }
+#pragma unroll
+          for (int i = i0; i < i0 + HM; ++i)
+            acc[i][n] = mfma_32x32x16(wf[n][0], af[i][0], bc);
+        }
+#else
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           const f32x16 bc = bias_c(n);
@@ -983,6 +1046,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
           for (int i = i0; i < i0 + HM; ++i)
             acc[i][n] = mfma_32x32x16(wf[n][0], af[i][0], bc);
         }
+#endif
       } else {
 #pragma unroll
         for (int i = i0; i < i0 + HM; ++i)
