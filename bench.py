@@ -480,6 +480,9 @@ def main():
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_summary.json")))
+        match = [c for c in cands if json.load(open(c)).get("_build_id") == _lib.build_id(lib)]
+        if match:
+            cands = match
         default_shape = args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25)
         if not cands:
             pmc_note = "no PMC summary under profiles/"
@@ -517,6 +520,10 @@ def main():
     mfma, mfma_note = {}, None
     try:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_busy_summary.json")))
+        # (several may be committed -- e.g. a build before and after a rewrite: take the one collected from this library)
+        match = [c for c in cands if json.load(open(c)).get("_build_id") == _lib.build_id(lib)]
+        if match:
+            cands = match
         if not cands:
             mfma_note = "no MFMA-busy summary under profiles/"
         else:
