@@ -16,13 +16,14 @@ CSRC = os.path.join(ROOT, "ctrlv_amd", "csrc")
 
 
 def test_no_unguarded_store_data_hazard():
-    """No buffer_store_dwordx4 with an SGPR soffset is followed within two wait states by a VALU write of its data
+    """(Also: no MFMA result reaches an LDS store within 19 issue slots -- tools/hazard_scan.py scan_mfma_to_lds_store.)
+    No buffer_store_dwordx4 with an SGPR soffset is followed within two wait states by a VALU write of its data
     registers -- the hazard LLVM exempts and gfx950 has (csrc/gemm_pp_kernel.h store_data_hazard_guard; the root cause of
     the round-3 "zero dwords" defect and of raw fp32 dwords in fp16 tiles) -- in any kernel of either element type."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import __graft_entry__ as g
-    from hazard_scan import scan
+    from hazard_scan import scan, scan_mfma_to_lds_store
     procs = []
     with tempfile.TemporaryDirectory() as td:
         for defs in ([], ["-DCTRLV_ELEM_F16=1"]):
@@ -43,6 +44,10 @@ def test_no_unguarded_store_data_hazard():
             n_stores += text.count("buffer_store_dwordx4")
             hits = scan(text)
             assert not hits, (unit, hits[:3])
+            # the asm staging stores of round 5 (stg_write16): no MFMA result is stored to LDS within the wait states LLVM
+            # would have inserted for an instruction of its own
+            near = scan_mfma_to_lds_store(text)
+            assert not near, (unit, near[:3])
         assert n_stores > 500          # the scan really saw the epilogues
 
 

@@ -860,7 +860,8 @@ def test_time_conv_rows_to_nchw(ops):
 
 
 @pytest.mark.parametrize("M,epi", [(256, "r1"), (1000, "r1"), (2048 + 72, "r1r2"), (777, "r1v"), (512, "none"), (256 * 70, "r1v"),
-                                   (777, "r1v_epi"), (256 * 9 + 5, "v_epi"), (1500, "r1v2_epi")])
+                                   (777, "r1v_epi"), (256 * 9 + 5, "v_epi"), (1500, "r1v2_epi"),
+                                   (128 * 300 + 37, "r1"), (128 * 513 + 1, "r1r2")])   # persistent grid (2 / 3 tiles per workgroup), ragged last tile
 def test_ff_fused_matches_the_two_launch_path(ops, M, epi):
     """ctrlv_ff_fused (C = 320 feed-forward with the 4C-wide intermediate on chip) against the two ctrlv_gemm launches it
     replaces, same packed weights: GEMM 1, the GELU table and the bf16 rounding of u are the same operations, GEMM 2 sums in
@@ -965,10 +966,10 @@ def test_ff_fused_with_the_layernorm_folded_in(ops, M, with_v):
 
 @pytest.mark.parametrize("epi", ["r1", "r1r2", "r1v", "r1v_epi"])
 def test_ff_fused_full_size_is_stable_run_to_run(ops, epi):
-    """The fused feed-forward at the benchmark's own size (M = 50 x 9216 rows: 1800 tiles, 8 per workgroup) against the two
+    """The fused feed-forward at the benchmark's own size (M = 50 x 9216 rows: 3600 tiles of 128 rows, 15 per workgroup) against the two
     launches, and 12 repeats bit for bit (a race between the wave groups, the LDS rings or the epilogue's staging would
     show as a difference between runs: the kernel has no atomics).  "r1v_epi" = R1 + a row vector through the shared
-    epilogue (EPI = 3 at TM = 1, TN = 10), the instantiation that stored zero dwords intermittently in round 3 (the
+    epilogue (EPI = 3; round 3: TM = 1, TN = 10, now TN = 5), the instantiation that stored zero dwords intermittently in round 3 (the
     store-data hazard, csrc/gemm_pp_kernel.h): 48 repeats."""
     from ctrlv_amd import packing
     C, I, M = 320, 1280, 50 * 9216

@@ -41,11 +41,48 @@ def scan(text, wait_states=2):
     return hits
 
 
+def scan_mfma_to_lds_store(text, wait_states=19):
+    """[(kernel, mfma line, store line, distance)]: a ds_write whose DATA registers were written by a v_mfma fewer than
+    `wait_states` issue slots before it, in program order within a basic block.  Round 5 writes the epilogue staging stores
+    as asm statements (csrc/gemm_pp_kernel.h stg_write16): LLVM's hazard recognizer inserts the wait states of "XDL write
+    VGPR -> LDS / VMEM read of it" (11 for the 8-pass bf16 MFMAs, 19 for 16 passes) for instructions it knows, not inside
+    asm statements -- so the distance is checked here.  Every other instruction counts as one slot (s_nop n as n + 1)."""
+    lines = [ln.strip() for ln in text.split("\n")]
+    kern, hits = "?", []
+    for i, ln in enumerate(lines):
+        if re.match(r"^_Z\S+:", ln):
+            kern = ln.split(":")[0]
+        m = re.match(r"ds_write_b(?:32|64|96|128) v\d+, (v\[\d+:\d+\]|v\d+)", ln)
+        if not m:
+            continue
+        data = _regs(m.group(1))
+        k, j = 0, i - 1
+        while k < wait_states and j >= 0:
+            t = lines[j]
+            j -= 1
+            if not t or t[0] == ";":
+                continue
+            if t[0] == "." or re.match(r"^_Z\S+:", t):      # block / kernel boundary: predecessors unknown, stop
+                break
+            if t.startswith("s_nop"):
+                k += int(t.split()[1]) + 1
+                continue
+            if t.startswith("v_mfma") and _regs(t.split()[1].rstrip(",")) & data:
+                hits.append((kern, t, ln, k))
+                break
+            k += 1
+    return hits
+
+
 if __name__ == "__main__":
     total = 0
     for f in sys.argv[1:]:
-        hits = scan(open(f).read())
-        total += len(hits)
+        text = open(f).read()
+        hits = scan(text)
+        near = scan_mfma_to_lds_store(text)
+        for kern, mf, st, dist in near:
+            print(f"{f}: {kern[:80]}: {mf[:60]}  ->  {st}  ({dist} slots)")
+        total += len(hits) + len(near)
         for kern, st, cl in hits:
             print(f"{f}: {kern[:80]}: {st}  ->  {cl}")
         print(f"{f}: {len(hits)} unguarded stores")
