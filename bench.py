@@ -477,13 +477,13 @@ def main():
     # applied by tools/pmc_summary.py) committed under profiles/.  Only valid for the library it was collected from:
     # the summary carries that library's build id (hash of csrc/ + include/) and is ignored when it differs.
     pmc, pmc_note, pmc_launches = {}, None, {}
+    import glob
+    default_shape = args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25)
     try:
-        import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_summary.json")))
         match = [c for c in cands if json.load(open(c)).get("_build_id") == _lib.build_id(lib)]
         if match:
             cands = match
-        default_shape = args.workload == "box2video" and (args.height, args.width, args.frames) == (576, 1024, 25)
         if not cands:
             pmc_note = "no PMC summary under profiles/"
         elif not default_shape:

@@ -159,8 +159,7 @@ _NO_STATUS = {"ctrlv_abi_version", "ctrlv_elem_dtype", "ctrlv_build_id", "ctrlv_
 def _status_recorder(lib, fn):
     def call(*args):
         rc = fn(*args)
-        if rc < 0:
-            _tls.failed = lib
+        _tls.failed = lib if rc < 0 else None      # (a later success clears the mark: it never names an OLD failure)
         return rc
     call.__name__ = getattr(fn, "__name__", "ctrlv_fn")
     return call
@@ -262,11 +261,13 @@ def last_error(lib=None):
 def check(rc, what, lib=None):
     """Map the C status convention (include/ctrlv_hip.h) onto the reference's exception types: bad shapes /
     arguments -> ValueError (as controlnet.py:80-98, pipeline_video_control.py:51-68), HIP failures -> RuntimeError.
-    The message is the one of the library whose call failed (`lib`, else the library that returned a negative status last
-    on this thread)."""
+    The message is the one of the library whose call failed: `lib` when given (call sites whose entry point does not
+    return a status -- size queries -- pass their own library), else the library whose status-returning call failed LAST on
+    this thread (the mark is consumed here and cleared by any later successful call), else every loaded library's text."""
     if rc == 0:
         return
-    msg = f"{what}: {last_error(lib or getattr(_tls, 'failed', None))} (status {rc})"
+    failed, _tls.failed = getattr(_tls, "failed", None), None
+    msg = f"{what}: {last_error(lib or failed)} (status {rc})"
     if rc in (-1, -2, -4, -5):     # bad argument / shape / dtype / workspace size
         raise ValueError(msg)
     raise CtrlvHipError(msg)

@@ -382,8 +382,12 @@ class GegluProj(torch.autograd.Function):
         two_i, cin = weight.shape
         wp, bp = _pack_fwd(weight, 0, geglu=True), packing.geglu_interleave(bias.detach()).float().contiguous()
         u = _rows(x.shape[0], two_i // 2, x)
-        ckpt = _CKPT[0] and cin >= 128 and cin % 32 == 0
-        raw = _rows(x.shape[0], two_i, x) if (cin >= 128 and cin % 32 == 0 and not ckpt) else None
+        # (a cell only where a backward will run: under torch.no_grad() / with no input requiring grad -- an evaluation pass
+        #  inside a checkpointed training context -- Function.forward still executes, but no consumer ever saves u, so a cell
+        #  registered here would stay unclaimed and _ff_region would report it as leaked.  ADVICE r05.)
+        records = any(ctx.needs_input_grad)
+        ckpt = _CKPT[0] and records and cin >= 128 and cin % 32 == 0
+        raw = _rows(x.shape[0], two_i, x) if (records and cin >= 128 and cin % 32 == 0 and not ckpt) else None
         ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=raw)
         ctx.cell = None
         if ckpt:

@@ -56,42 +56,6 @@ __device__ __forceinline__ f32x16 mfma_keep_c(const elx8& a, const elx8& b, cons
   return d;
 }
 
-// ---- softmax row sums on the matrix pipe (attn_spatial64_kernel, round 4): EXPERIMENT, -DCTRLV_ATTN_MFMA_SUM.
-// Measured (profiles/r04_attention_mfma_rowsum_ab.txt, A/B on one device): 239 instead of 294 instructions per 64-key tile
-// and wave (VALU 186 -> 131), 8 more MFMAs of 4 passes -- and the SAME time (S = 9216: 4.59-4.61 ms both; in the step 39.8
-// ms both).  Halving the VALU stream does not move the kernel: it is not VALU-issue-bound (as DESIGN.md said until round
-// 3) but bound by the matrix pipe at the clock the chip holds under this load (32 + 4 MFMA-passes-equivalents per tile and
-// wave = 2304 pipe cycles per SIMD and tile pair of ~3200).  Both forms pass the same tests; the VALU sums stay the
-// default (three rounds of full-pipeline runs behind them).
-// l += sum_k P[q][k] is a product with a ones vector.  v_mfma_f32_16x16x32 takes the packed P fragment AS IT SITS (the B
-// operand of the P.V MFMAs: lane = (query r32, key half hsel), 8 keys) as its B operand -- lane l supplies column l % 16,
-// K block l / 16 -- and a constant A operand that has ones in row 0 for K blocks 0, 2 and in row 1 for K blocks 1, 3:
-//   D[0][n] = sum over the 16 keys of the fragment for query n,   D[1][n] = the same for query n + 16
-// (a sum does not care which key sits in which K slot).  Four MFMAs of 4 passes per row block and 64-key tile accumulate
-// in a 16 x 16 result of which lanes 0..15 hold, in elements 0 / 1, the running sums of queries n / n + 16: FOUR registers
-// per row block instead of the 72 v_add_f32 per tile of the VALU form -- the loop is bound by VALU issue, not by the matrix
-// pipe.  The sums are those of the ROUNDED P (what P.V multiplies), in the pipe's accumulation order.
-typedef __attribute__((ext_vector_type(4))) float f32x4v;
-__device__ __forceinline__ f32x4v mfma_16x16x32(const elx8& a, const elx8& b, const f32x4v& c) {
-#ifdef CTRLV_ELEM_F16
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-#endif
-}
-// P is kept SCALED by 2^-kPShift (the shift rides in the running-max operand: exp2(s - (m + kPShift))) so that "some
-// P >= 2^(kPShift + 1)" -- the slow-path condition -- is ONE BIT of the packed value: bit 14, the exponent's top bit, is
-// set exactly for |x| >= 2 in bf16 and in fp16 alike (P >= 0; inf / NaN have it too).  The test of a whole tile is then
-// an OR over its 32 packed registers (16 v_or3_b32) instead of a sum or a max over 64 scores.  bf16: shift 11, the 2^12
-// limit of the VALU form.  fp16: shift 4 (limit 32 = a score 5 above the kept max, log2 domain): fp16's normal range
-// ends at 2^-14, so P' = P 2^-4 keeps full precision for P >= 2^-10 and the rest is below 1e-3 of the row's largest term.
-// O and l carry the same factor, O / l does not; L = m + kPShift + log2(l').
-#ifdef CTRLV_ELEM_F16
-constexpr float kPShift = 4.0f;
-#else
-constexpr float kPShift = 11.0f;
-#endif
-
 __device__ __forceinline__ elx8 pack_p(const f32x16& p, int s) {
   elx8 r;
 #pragma unroll

@@ -286,6 +286,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x,
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
   __syncthreads();
+  if (part) {
+    // deterministic mode: a block lies inside ONE table row (rows_per_block divides vdiv), so the four row lanes always fold
+    // -- a lane that saw no row (blocks of fewer than four rows: M < 4, M % rows_per_block in {1, 2, 3}) holds zeros -- and
+    // row lane 0 is the single writer of the block's slot (plain stores from several lanes would overwrite each other)
+    if (ty == 0 && col_ok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        part[(long)blockIdx.y * N + n0 + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+    }
+    return;
+  }
   const bool same = red_idx[0] == red_idx[1] && red_idx[1] == red_idx[2] && red_idx[2] == red_idx[3];
   if (same) {
     if (ty == 0) {

@@ -111,8 +111,8 @@ __global__ void im2col3x3_kernel(const el_t* __restrict__ x, int n_img, int H, i
   *(uint4*)(col + m * Kp + k0) = v;
 }
 
-__global__ void axpby_kernel(const el_t* __restrict__ x, const el_t* __restrict__ r, float a, float b,
-                             el_t* __restrict__ y, size_t n) {
+// (x / y carry no __restrict__: in place -- y == x -- is part of the contract, ctrlv_hip.h; plan.hip add_res uses it)
+__global__ void axpby_kernel(const el_t* x, const el_t* __restrict__ r, float a, float b, el_t* y, size_t n) {
   const size_t nv = n >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     float fx[8], fr[8];
@@ -129,8 +129,9 @@ __global__ void axpby_kernel(const el_t* __restrict__ x, const el_t* __restrict_
 }
 
 // (y, y_lo) = split(a * (x + x_lo) + b * r) on a SPLIT skip tensor (common.h split_lo8); n a multiple of 8
-__global__ void axpby_split_kernel(const el_t* __restrict__ x, const el_t* __restrict__ xlo, const el_t* __restrict__ r,
-                                   float a, float b, el_t* __restrict__ y, el_t* __restrict__ ylo, size_t n) {
+// (in place allowed: y == x and ylo == xlo, so none of the four carries __restrict__)
+__global__ void axpby_split_kernel(const el_t* x, const el_t* xlo, const el_t* __restrict__ r, float a, float b, el_t* y,
+                                   el_t* ylo, size_t n) {
   const size_t nv = n >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     float fx[8], fr[8];

@@ -24,7 +24,7 @@ static int launch_w16_epi(const ctrlv_gemm_desc& d, hipStream_t stream) {
 bool ctrlv_gemm_w16_supports(const ctrlv_gemm_desc& d, int tile) {
   const int bn = tile == 12 ? 256 : 320;
   const long lim = 0xFFFFFFF0L;
-  if (d.A2 || d.raw_out || d.gn_partials || d.ksplit || d.act || (d.out_f32 & 1) || d.R1_lo || d.R2_lo || d.out_lo) return false;
+  if (d.A2 || (d.raw_out && (!d.geglu || d.ld_raw < d.N || d.ld_raw % 8 != 0 || (long)d.M * d.ld_raw * 2 > lim)) || d.gn_partials || d.ksplit || d.act || (d.out_f32 & 1) || d.R1_lo || d.R2_lo || d.out_lo) return false;
   if ((long)d.M * d.ldo * 2 > lim || (d.R1 && (long)d.M * d.ldr1 * 2 > lim) || (d.R2 && (long)d.M * d.ldr2 * 2 > lim)) return false;
   if (d.vmode && pp_vtable_rows(d) * d.ldv * 4 > lim) return false;
   {

@@ -307,15 +307,36 @@ __global__ __launch_bounds__(1024) void gemm_w16_kernel(const ctrlv_gemm_desc d,
         const u32x4_t bg0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)((wrow0 + 16) * 4), 0, 0);
         const u32x4_t bg1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)((wrow0 + 20) * 4), 0, 0);
         const bool col_ok = oc < d.n_store && wbase_n + 32 * (c0 >> 4) < d.N;
+        // training forward (raw_out, wave-uniform): the projection itself also goes out, elements [M][ld_raw] in the packed
+        // column order (= weight-row order) -- the lane's eight value rows wrow0 .. + 7 and its eight gate rows 16 further are
+        // two 16-byte stores.  The ROUTING of a layer must not depend on raw_out (a checkpointed recompute has to
+        // run on the core its forward ran on), so this core writes it like the ping-pong tiles do.
+        const bool raw = d.raw_out != nullptr;
+        const __amdgpu_buffer_rsrc_t rsRaw = __builtin_amdgcn_make_buffer_rsrc(
+            raw ? d.raw_out : (void*)d.W, 0, raw ? (int)((long)d.M * d.ld_raw * 2) : 0, kFlags);
+        const bool raw_ok = wbase_n + 32 * (c0 >> 4) < d.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           float o[8];
+          const int m = m0 + i * 16;
+          if (raw) {
+            float pv_[8], pg_[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pv_[r] = acc[i][0][r] + __uint_as_float(bv0[r]); pv_[4 + r] = acc[i][1][r] + __uint_as_float(bv1[r]);
+              pg_[r] = acc[i][2][r] + __uint_as_float(bg0[r]); pg_[4 + r] = acc[i][3][r] + __uint_as_float(bg1[r]);
+            }
+            const uint4 kv = pack_elx8(pv_), kg = pack_elx8(pg_);
+            const u32x4_t sv = {kv.x, kv.y, kv.z, kv.w}, sg = {kg.x, kg.y, kg.z, kg.w};
+            const unsigned roff = (m < d.M && raw_ok) ? (unsigned)m * (unsigned)(d.ld_raw * 2) + (unsigned)(wrow0 * 2) : kOOB;
+            pp_store_out(sv, rsRaw, roff, 0);
+            pp_store_out(sg, rsRaw, roff, 32);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             o[r] = geglu_tab(acc[i][0][r] + __uint_as_float(bv0[r]), acc[i][2][r] + __uint_as_float(bg0[r]), tab);
             o[4 + r] = geglu_tab(acc[i][1][r] + __uint_as_float(bv1[r]), acc[i][3][r] + __uint_as_float(bg1[r]), tab);
           }
-          const int m = m0 + i * 16;
           const uint4 pk = pack_elx8(o);
           const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
           pp_store_out(pv, rsO, (m < d.M && col_ok) ? (unsigned)m * (unsigned)(d.ldo * 2) + (unsigned)(oc * 2) : kOOB, 0);

@@ -131,7 +131,7 @@ class Plan:
         if key not in self._ws_bytes:
             n = self._lib.ctrlv_plan_workspace_bytes(self._h, B, F, H, W)
             if n == 0:
-                check(-2, "ctrlv_plan_workspace_bytes")
+                check(-2, "ctrlv_plan_workspace_bytes", lib=self._lib)
             self._ws_bytes[key] = n
         return self._ws_bytes[key]
 

@@ -98,6 +98,35 @@ def test_parameter_gradient_reductions_are_bit_reproducible(ops, M, N, K, taps):
         assert parity_err(a, b) < 1e-4
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 65, 66, 259, 1027])
+def test_colsum_deterministic_with_blocks_of_fewer_than_four_rows(ops, M):
+    """the ordered colsum dropped rows when a block held fewer than four rows (M < 4, or a last block of
+    1-3 rows: row lanes without rows kept the 'no table row' mark, the fold was skipped and the lanes' plain stores overwrote
+    each other).  Bias form and per-clip row-vector form, against fp32 torch and against the atomic form."""
+    assert ops.DETERMINISTIC
+    N = 72
+    dY = bf(torch.randn(M, N, generator=g(M))).to(DEV)
+
+    def run():
+        db = torch.zeros(N, dtype=torch.float32, device=DEV)
+        ops.colsum(dY, db, scale=0.5)
+        dV = torch.zeros(1, N, dtype=torch.float32, device=DEV)
+        ops.colsum(dY, dV, vmode=1, vdiv=1 << 20, vmod=1)          # (M = B rows of a per-clip GEMM: one table row)
+        return db, dV
+    db, dV = run()
+    ref = dY.float().sum(0)
+    assert parity_err(db, 0.5 * ref, "bias grad, ragged blocks") < 1e-5
+    assert parity_err(dV[0], ref, "row-vector grad, ragged blocks") < 1e-5
+    prev, ops.DETERMINISTIC = ops.DETERMINISTIC, False
+    try:
+        db_a, dV_a = run()
+    finally:
+        ops.DETERMINISTIC = prev
+    assert parity_err(db, db_a) < 1e-5 and parity_err(dV, dV_a) < 1e-5
+    db2, dV2 = run()
+    assert torch.equal(db, db2) and torch.equal(dV, dV2)
+
+
 @pytest.mark.parametrize("stride,up", [(1, 0), (2, 0), (1, 1)])
 def test_wgrad_conv3x3(ops, stride, up):
     n, cin, cout, H, W = 3, 64, 128, 12, 10

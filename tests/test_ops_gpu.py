@@ -510,6 +510,18 @@ def test_gemm_w16_geglu(ops, M, C, wtile=12):
         assert torch.equal(auto, out)
         ops.gemm(A[:5].to(DEV), Wp.to(DEV), one, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1)
         assert torch.equal(one, out[:5])
+    # raw_out (training forward / checkpoint recompute): the core writes the projection itself too, so the routing of a
+    # layer does not depend on raw_out: u has the SAME BITS with and without it, at every row count
+    raw = torch.full((M, 8 * C), float("nan"), dtype=EL, device=DEV)
+    u2 = torch.empty_like(out)
+    ops.gemm(A.to(DEV), Wp.to(DEV), u2, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, tile=wtile, raw_out=raw)
+    assert torch.equal(u2, out)
+    proj_packed = A.float() @ Wp.float().T + bp.float()          # (packed column order = weight-row order)
+    assert parity_err(raw, proj_packed, "w16 raw projection") < tol(3e-3)
+    if C >= 1280 and wtile == 12:
+        u3, raw3 = torch.empty_like(out), torch.empty_like(raw)
+        ops.gemm(A.to(DEV), Wp.to(DEV), u3, N=8 * C, cin=C, bias=bp.to(DEV), geglu=1, raw_out=raw3)    # the dispatcher's choice
+        assert torch.equal(u3, out) and torch.equal(raw3, raw)
 
 
 @pytest.mark.parametrize("tile", [12, 13])

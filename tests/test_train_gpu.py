@@ -214,3 +214,38 @@ def test_gradient_checkpointing_gives_the_same_step_with_less_memory(hip_lib):
     assert all(torch.equal(a, c) for a, c in zip(g0, g1))
     print(f"  peak above the resident set: plain {m0 / 2**20:.1f} MiB, checkpointed {m1 / 2**20:.1f} MiB")
     assert m1 < 0.9 * m0
+
+
+def test_geglu_checkpointing_is_bit_identical_at_c1280_and_quiet_without_grad(hip_lib):
+    """ADVICE r05.  (1) At Cin = 1280 the GEGLU projection runs on the 16x16x32 core; the checkpoint's recompute launch
+    carries raw_out, the checkpointed forward does not -- the routing must not depend on raw_out, so the recomputed u / raw
+    have the forward's bits and the gradients of the checkpointed and the plain feed-forward are `torch.equal` (the tiny
+    config of the step-level test has no Cin >= 1280 layer).  (2) A forward under torch.no_grad() inside a checkpointed
+    context (the trainer's periodic validation) registers no recompute cell: nothing leaks, nothing raises."""
+    from ctrlv_amd import autograd as A
+    C, M = 1280, 512
+    gen = torch.Generator().manual_seed(11)
+    x0 = (torch.randn(M, C, generator=gen)).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(8 * C, C, generator=gen) / C ** 0.5).to(DEV)
+    b1 = (torch.randn(8 * C, generator=gen) * 0.1).to(DEV)
+    w2 = (torch.randn(C, 4 * C, generator=gen) / (4 * C) ** 0.5).to(DEV)
+    b2 = (torch.randn(C, generator=gen) * 0.1).to(DEV)
+    dy = torch.randn(M, C, generator=gen).to(torch.bfloat16).to(DEV)
+
+    def run(ck):
+        x = x0.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in (w1, b1, w2, b2)]
+        with A.gradient_checkpointing(ck):
+            with A._ff_region():
+                u = A.GegluProj.apply(x, ps[0], ps[1])
+                y = A.FusedLinear.apply(u, ps[2], ps[3], None, None, None, {})
+        y.backward(dy)
+        return [y.detach()] + [t.grad for t in [x] + ps]
+    plain, ckpt = run(False), run(True)
+    for a, c in zip(plain, ckpt):
+        assert torch.equal(a, c)
+    with A.gradient_checkpointing(True), torch.no_grad():
+        with A._ff_region():
+            u = A.GegluProj.apply(x0, w1, b1)
+            y = A.FusedLinear.apply(u, w2, b2, None, None, None, {})
+    assert torch.equal(y, plain[0]) and not A._CELLS
