@@ -74,6 +74,8 @@ SIGNATURES = {
     "ctrlv_gemm_splitk_ws_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
     "ctrlv_groupnorm_from_partials": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                               c_int, c_void_p, c_void_p]),
+    "ctrlv_groupnorm_from_partials_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_void_p, c_void_p]),
     "ctrlv_groupnorm_chunks": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_stats_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                             c_void_p, c_void_p]),
@@ -163,7 +165,7 @@ def _status_recorder(lib, fn):
         return rc
     call.__name__ = getattr(fn, "__name__", "ctrlv_fn")
     return call
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class CtrlvHipError(RuntimeError):

@@ -340,6 +340,7 @@ class _GegluCell:
         return t
 
 
+_REC = [True]        # grad mode of the caller of the current feed-forward region (set by _ff_region)
 _CELLS = {}          # data_ptr of a live checkpointed u -> its cell (only while the feed-forward pair is being built)
 
 
@@ -355,6 +356,14 @@ def _ckpt_unpack(obj):
 @contextlib.contextmanager
 def _ff_region():
     """Around one GEGLU projection + its output projection: under checkpointing the consumer's saved u becomes a cell."""
+    prev, _REC[0] = _REC[0], torch.is_grad_enabled()
+    try:
+        yield from _ff_region_body()
+    finally:
+        _REC[0] = prev
+
+
+def _ff_region_body():
     if not _CKPT[0]:
         yield
         return
@@ -384,8 +393,9 @@ class GegluProj(torch.autograd.Function):
         u = _rows(x.shape[0], two_i // 2, x)
         # (a cell only where a backward will run: under torch.no_grad() / with no input requiring grad -- an evaluation pass
         #  inside a checkpointed training context -- Function.forward still executes, but no consumer ever saves u, so a cell
-        #  registered here would stay unclaimed and _ff_region would report it as leaked.  ADVICE r05.)
-        records = any(ctx.needs_input_grad)
+        #  registered here would stay unclaimed and _ff_region would report it as leaked.  ADVICE r05.  Grad mode is always
+        #  off INSIDE a Function.forward: _ff_region records the caller's.)
+        records = _REC[0] and any(ctx.needs_input_grad)
         ckpt = _CKPT[0] and records and cin >= 128 and cin % 32 == 0
         raw = _rows(x.shape[0], two_i, x) if (records and cin >= 128 and cin % 32 == 0 and not ckpt) else None
         ops.gemm(x, wp, u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=raw)

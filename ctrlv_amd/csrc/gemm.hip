@@ -438,8 +438,8 @@ extern "C" int ctrlv_gemm(const ctrlv_gemm_desc* dp, ctrlv_stream_t stream_) {
     CTRLV_CHECK_ARG(CTRLV_ELEM_DTYPE == 1, "ctrlv_gemm: R1_lo / R2_lo / out_lo (split trunk) are served by the fp16 element "
                                            "library only");
     CTRLV_CHECK_ARG((!d.R1_lo || d.R1) && (!d.R2_lo || d.R2), "ctrlv_gemm: R1_lo / R2_lo need R1 / R2");
-    CTRLV_CHECK_ARG(!d.geglu && !d.act && !d.out_f32 && !d.gn_partials && !d.raw_out && !d.n_scale2,
-                    "ctrlv_gemm: split planes do not combine with GEGLU / SiLU / fp32 output / gn_partials / raw_out / n_scale2");
+    CTRLV_CHECK_ARG(!d.geglu && !d.act && !d.out_f32 && !d.raw_out && !d.n_scale2,
+                    "ctrlv_gemm: split planes do not combine with GEGLU / SiLU / fp32 output / raw_out / n_scale2");
   }
   if (d.splitk_ws) {      // split contraction where the layer's shape calls for it (splitk_plan)
     int tile_s = 0;

@@ -300,7 +300,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     }
     // GNS: this column block's sums (pairs of channels: v_pk_add_f32 / v_pk_fma_f32 -- the epilogue's VALU instructions
     // issue at a fraction of their rate while the other wave group owns the matrix pipe); column sums per block
-    f32x2_t gcs[GNS ? 4 : 1], gcq[GNS ? 4 : 1];
+    // Sums are taken about a per-COLUMN pilot (round 6): the value of the wave tile's first row, broadcast from
+    // lanes 0-3 (row_a == 0) to the lanes that hold the same eight columns -- eight lane exchanges per column block.  With
+    // raw sums, sum x^2 - (sum x)^2 / n loses the variance in fp32 once |mean| >> std; gn_stats_kernel has always shifted.
+    f32x2_t gcs[GNS ? 4 : 1], gcq[GNS ? 4 : 1], gpil[GNS ? 4 : 1];
     // (column sums of the finished blocks: in the wave's strip of LDS where the kernel has one -- gns_strip, [2][TN * 32]
     //  floats -- else in registers until the staging pieces are free)
     float gcol[GNS ? TN : 1];
@@ -308,7 +311,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       const int i = GNS ? s % TM : s / TN, j = GNS ? s / TM : s % TN;
-      if (HAS_RES) {
+      // (GNS + LO: the window advances BEHIND this sub-tile's staging writes -- its 16 accumulators are dead by then and the
+      //  next sub-tile's four residual rows take their registers; ahead of them the kernel went 25 registers over budget)
+      constexpr bool LATE_WINDOW = GNS && LO;
+      if (HAS_RES && !LATE_WINDOW) {
 #pragma unroll
         for (int k = P0 + GROW * s; k < P0 + GROW * (s + 1); ++k)
           if (k < NSUB) load_res(k);
@@ -345,6 +351,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         stg_write16(wrow + c * 16, acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
       }
       __builtin_amdgcn_wave_barrier();     // compiler-only: the image is exchanged between lanes of this wave
+      if (HAS_RES && LATE_WINDOW) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = P0 + GROW * s; k < P0 + GROW * (s + 1); ++k)
+          if (k < NSUB) load_res(k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float4 img[2][2];
       stg_read4x16(rp_a + rx0, rp_a + rx1, rp_b + rx0, rp_b + rx1, img);
       __builtin_amdgcn_wave_barrier();
@@ -397,12 +410,21 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           }
         }
         if (GNS) {      // (rows past M: the whole wave tile is, M being a multiple of 64 -- its partials are not written)
+          if (i == 0 && pass == 0) {
+            const int src = (lane & 3) * 4;                      // byte index of the lane that holds row 0 of these columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c0 = (e >> 1) * 4 + (e & 1);
+              gpil[e] = f32x2_t{__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o[c0]))),
+                                __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o[c0 + 2])))};
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // channel pairs (0,2) (1,3) (4,6) (5,7): the pairing the compiler's own v_pk_mul / v_pk_add of the epilogue
             // arithmetic uses (x,z / y,w of the staged float4) -- any other costs two v_mov per pair
             const int c0 = (e >> 1) * 4 + (e & 1);
-            const f32x2_t o2 = f32x2_t{o[c0], o[c0 + 2]};
+            const f32x2_t o2 = f32x2_t{o[c0], o[c0 + 2]} - gpil[e];
             gcs[e] += o2;
             gcq[e] += o2 * o2;
           }
@@ -417,7 +439,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         }
       }
       if (GNS && i == TM - 1) {
-        // 64 lanes x 16 sums -> 64 column sums.  Value v (0..7: sum of channel v, 8..15: its squares) of lane (row_a, l4)
+        // 64 lanes x 16 sums -> 64 column sums.  Value v (0..7: shifted sum of channel v, 8..15: its squares) of lane (row_a, l4)
         // goes to piece v >> 2 at float (v & 3) * 64 + l4 * 16 + row_a; lane L then adds the 16 consecutive floats of
         // (v = L >> 2, l4 = L & 3): gcol[j] = column 8 * (L & 3) + ((L >> 2) & 7) of block j, kind L >> 5.
         // (lane constants of this block are rebuilt per column block from an opaque copy of the lane id: kept live across
@@ -441,8 +463,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
           const float4 v4 = *(const float4*)(rsrc + k * 16);
           t2 += f32x2_t{v4.x, v4.y} + f32x2_t{v4.z, v4.w};
         }
-        if (gns_strip) *(float*)(gns_strip + ((lj >> 5) * (TN * 32) + j * 32 + 8 * (lj & 3) + ((lj >> 2) & 7)) * 4) = t2.x + t2.y;
-        else gcol[j] = t2.x + t2.y;
+        // lane L < 32 holds a = sum (x - K) of its column, lane L + 32 b = sum (x - K)^2 of the same column: one half-wave
+        // swap brings both to both; the column's pilot is this lane's own gpil entry of channel (L >> 2) & 7 (its l4 is the
+        // column's).  The column's (mean, M2) over the 64 rows are well conditioned whatever the mean is.
+        float colv;
+        {
+          const float t = t2.x + t2.y;
+          const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+          const float oth = __uint_as_float((lj >> 5) ? sw2[0] : sw2[1]);
+          const float a = (lj >> 5) ? oth : t, b = (lj >> 5) ? t : oth;
+          const int ch = (lj >> 2) & 7;
+          float kp = gpil[0].x;
+#pragma unroll
+          for (int c = 1; c < 8; ++c) {
+            const int pi = (c >> 2) * 2 + (c & 1);
+            const float pv_ = ((c >> 1) & 1) ? gpil[pi].y : gpil[pi].x;
+            kp = ch == c ? pv_ : kp;
+          }
+          constexpr float inv_rows = 1.0f / 64.0f;               // (GNS: 64-row wave tiles)
+          colv = (lj >> 5) ? b - a * a * inv_rows : kp + a * inv_rows;
+        }
+        if (gns_strip) *(float*)(gns_strip + ((lj >> 5) * (TN * 32) + j * 32 + 8 * (lj & 3) + ((lj >> 2) & 7)) * 4) = colv;
+        else gcol[j] = colv;
         __builtin_amdgcn_wave_barrier();
       }
       // keep the machine scheduler from hoisting the later sub-tiles' loads up here: the prefetch window is sized to
@@ -465,15 +507,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       const int cpg = d.N >> 5, ng = (TN * 32) / cpg;          // channels per group; groups of this wave's columns
       const int mw = bm + wr * WTM;                            // first row of the wave tile
       if (lane < ng && mw < d.M) {
-        float sa = 0.f, sq = 0.f;
-        for (int c = 0; c < cpg; c += 2) {
-          const float2 a = *(const float2*)(ks + (lane * cpg + c) * 4), q = *(const float2*)(kq + (lane * cpg + c) * 4);
-          sa += a.x + a.y;
-          sq += q.x + q.y;
+        // the group's columns, each (mean_c, M2_c) over WTM rows, merged with Chan's update (gn_stats_kernel's last stage)
+        float mean = 0.f, m2 = 0.f;
+        for (int c = 0; c < cpg; ++c) {
+          const float mc = *(const float*)(ks + (lane * cpg + c) * 4), qc = *(const float*)(kq + (lane * cpg + c) * 4);
+          const float dlt = mc - mean, rk = 1.0f / (float)(c + 1);
+          m2 += qc + dlt * dlt * ((float)WTM * (float)c * rk);
+          mean += dlt * rk;
         }
-        const float cnt = (float)(cpg * WTM), mean = sa / cnt;
         const int g = wbase_n / cpg + lane;
-        *(float2*)(d.gn_partials + (((long)(mw / WTM) * 32 + g) * 2)) = make_float2(mean, sq - sa * mean);
+        *(float2*)(d.gn_partials + (((long)(mw / WTM) * 32 + g) * 2)) = make_float2(mean, m2);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -953,7 +996,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const ctrlv_gemm_desc d, c
   constexpr int HM = TM / 2;
   // buffer stores a wave issues in one epilogue (straight-line code: out-of-range ones are issued and counted too)
   constexpr int NSTORE = EPI == 8 ? TM * TN * 4 : (GEGLU ? ((TN + 1) / 2) * TM * 2 + (RAW ? TM * TN * 2 : 0) : TM * TN * (LO ? 4 : 2));
-  static_assert(!LO || (!GEGLU && !GNS && !RAW && EPI != 8), "split planes: plain epilogues only");
+  static_assert(!LO || (!GEGLU && !RAW && EPI != 8), "split planes: plain epilogues only (with or without GroupNorm partials)");
   static_assert(NPIECE + NPIECE + NSTORE <= 63, "vmcnt is a 6-bit counter");
   bool after_epi = false;                                    // this workgroup has run an epilogue (tile > first)
 #ifdef CTRLV_PP_STAMP
@@ -1292,6 +1335,9 @@ int launch_epi_split(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stre
       }
     } else if constexpr (MODE == 1) {
       if (ctrlv_conv_halo_order(d)) {
+        // (round 6) a trunk writer that also feeds a GroupNorm -- conv2 of a res block -- writes the norm's chunk partials
+        // from the same fp32 values it splits into hi + lo: the split mode no longer costs those norms a statistics pass
+        if (e == 2 && d.gn_partials) return launch_one<BN, WM, WN, MODE, false, 2, false, false, true, true, true>(d, persistent, stream);
         if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, true, false, true>(d, persistent, stream);
         if (e == 0) return launch_one<BN, WM, WN, MODE, false, 0, false, false, true, false, true>(d, persistent, stream);
       } else {
@@ -1299,6 +1345,8 @@ int launch_epi_split(const ctrlv_gemm_desc& d, bool persistent, hipStream_t stre
         if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, false, true>(d, persistent, stream);
       }
     } else {
+      // (temporal conv2 = the res block's AlphaBlender epilogue, in front of a transformer's opening GroupNorm)
+      if (e == 2 && d.gn_partials) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, true, true>(d, persistent, stream);
       if (e == 2) return launch_one<BN, WM, WN, MODE, false, 2, false, false, false, false, true>(d, persistent, stream);
     }
   }

@@ -31,7 +31,9 @@ bool ctrlv_gemm_pp_supports(const ctrlv_gemm_desc& d) {
   const int e = pp_epi_of(d);
   if (e < 0) return false;
   if (pp_split_io(d)) {   // split trunk planes (launch_epi_split): fp16 elements, N a multiple of 320 (tile 6)
-    if (CTRLV_ELEM_DTYPE != 1 || d.N % 320 != 0 || d.gn_partials || d.raw_out || d.n_scale2) return false;
+    if (CTRLV_ELEM_DTYPE != 1 || d.N % 320 != 0 || d.raw_out || d.n_scale2) return false;
+    // (with GroupNorm partials: the two {R1} trunk writers that feed a norm -- row-halo conv2, temporal conv2)
+    if (d.gn_partials) return e == 2 && (d.mode == 2 || (d.mode == 1 && ctrlv_conv_halo_order(d)));
     if (d.mode == 0) return e == 0 || e == 2 || e == 3 || e == 6;
     if (d.mode == 1) return e == 0 || e == 2;
     return e == 2;
@@ -49,7 +51,8 @@ extern "C" int ctrlv_gemm_gn_partials_serves(const ctrlv_gemm_desc* dp) {
   if (!ctrlv_debug().gn_fused) return 0;
   const int cpg = d.N / 32;
   if (d.N <= 0 || d.N % 320 != 0 || !(cpg == 10 || cpg == 20 || cpg == 40)) return 0;      // 160-column wave tiles hold whole groups
-  if (d.n_store != d.N || d.ldo % 8 != 0 || d.geglu || d.A2 || d.raw_out || d.n_scale2 || pp_split_io(d)) return 0;
+  if (d.n_store != d.N || d.ldo % 8 != 0 || d.geglu || d.A2 || d.raw_out || d.n_scale2) return 0;
+  if (pp_split_io(d) && pp_epi_of(d) != 2) return 0;        // split planes: the {R1} writers only (launch_epi_split)
   if ((d.R1 && d.ldr1 % 8 != 0) || (d.vmode && d.ldv % 8 != 0) || d.Cin % 64 != 0) return 0;
   const int e = pp_epi_of(d);
   long S = 0;

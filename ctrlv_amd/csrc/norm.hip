@@ -526,6 +526,11 @@ extern "C" int ctrlv_groupnorm_apply_split(const void* x, const void* x_lo, cons
 extern "C" int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, int C, int imgs_per_stat, float eps,
                                              float* partials, const float* gamma, const float* beta, int silu, void* y,
                                              ctrlv_stream_t stream) {
+  return ctrlv_groupnorm_from_partials_split(x, nullptr, n_img, S, C, imgs_per_stat, eps, partials, gamma, beta, silu, y, stream);
+}
+extern "C" int ctrlv_groupnorm_from_partials_split(const void* x, const void* x_lo, int n_img, int S, int C, int imgs_per_stat,
+                                                   float eps, float* partials, const float* gamma, const float* beta, int silu,
+                                                   void* y, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_from_partials: null pointer");
   CTRLV_CHECK_SHAPE(S > 0 && S % 64 == 0, "groupnorm_from_partials: S=%d must be a multiple of 64", S);
   GnShape s;
@@ -539,8 +544,12 @@ extern "C" int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, in
                      partials, eps, stats);
   CTRLV_LAUNCH_CHECK();
   const int nt = s.CV * s.RPP;
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
-                     (const el_t*)nullptr, GnLo{nullptr, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
+  if (x_lo)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                       (const el_t*)nullptr, GnLo{(const el_t*)x_lo, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
+                       (const el_t*)nullptr, GnLo{nullptr, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

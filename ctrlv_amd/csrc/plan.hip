@@ -569,7 +569,7 @@ int gemm_groupnorm(Ctx& c, ctrlv_gemm_desc d, int n_img, int S, int C, int ips, 
     rc = gemm(c, d);
     if (rc == CTRLV_OK) {
       ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * n_img * (double)S * C, n_img * S, C, 1);   // flags 1: fused statistics
-      rc = ctrlv_groupnorm_from_partials(d.out, n_img, S, C, ips, eps, part, nm.g, nm.b, silu, y, c.st);
+      rc = ctrlv_groupnorm_from_partials_split(d.out, d.out_lo, n_img, S, C, ips, eps, part, nm.g, nm.b, silu, y, c.st);
     }
     c.release(m);
     return rc;
@@ -740,7 +740,7 @@ int run_tr(Ctx& c, const Transformer& t, const Trk& x, int H, int W, Trk* out_) 
   if (c.gn_cross_valid && !c.dry) {     // statistics from the res block's last GEMM (run_res, feeds_norm)
     c.gn_cross_valid = false;
     ProfScope ps(c, CTRLV_FAM_GROUPNORM, 0.0, 2.0 * 2 * N * (double)S * C, N * S, C, 1);
-    TRY(ctrlv_groupnorm_from_partials(x.hi, N, S, C, 1, 1e-6f, c.gn_cross, t.gn.g, t.gn.b, 0, tt, c.st));
+    TRY(ctrlv_groupnorm_from_partials_split(x.hi, x.lo, N, S, C, 1, 1e-6f, c.gn_cross, t.gn.g, t.gn.b, 0, tt, c.st));
   } else {
     TRY(groupnorm(c, x, Trk{}, 0, N, S, C, 1, t.gn, 1e-6f, 0, tt));
   }

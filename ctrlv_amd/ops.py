@@ -322,13 +322,15 @@ def groupnorm_fused_scratch_floats(n_img, S, imgs_per_stat):
     return (n_img * (S // 64) + n_img // imgs_per_stat) * 64
 
 
-def groupnorm_from_partials(x, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials):
-    """GroupNorm(+SiLU) of a tensor whose producing `gemm` wrote the chunk partials: finalize + apply."""
+def groupnorm_from_partials(x, n_img, S, C, imgs_per_stat, gamma, beta, eps, silu, y, partials, x_lo=None):
+    """GroupNorm(+SiLU) of a tensor whose producing `gemm` wrote the chunk partials: finalize + apply.  x_lo: the lo plane of
+    a SPLIT tensor (the launch wrote out_lo and gn_partials together; the normalised value is x + x_lo)."""
     _need_gpu(x, "x")
     assert partials.numel() >= groupnorm_fused_scratch_floats(n_img, S, imgs_per_stat)
     ev = _prof.begin()
-    check(_L(x).ctrlv_groupnorm_from_partials(_p(x), n_img, S, C, imgs_per_stat, eps, _p(partials), _p(gamma), _p(beta),
-                                              1 if silu else 0, _p(y), _stream()), "ctrlv_groupnorm_from_partials")
+    check(_L(x).ctrlv_groupnorm_from_partials_split(_p(x), _p(x_lo), n_img, S, C, imgs_per_stat, eps, _p(partials), _p(gamma),
+                                                    _p(beta), 1 if silu else 0, _p(y), _stream()),
+          "ctrlv_groupnorm_from_partials")
     _prof.end(ev, "groupnorm", 0.0, 2.0 * 2 * n_img * S * C)
     return y
 

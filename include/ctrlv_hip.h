@@ -156,7 +156,12 @@ int ctrlv_groupnorm_apply(const void* x, const void* x2, int c_split, int n_img,
  * imgs_per_stat) * 64 floats (the producer's part first); S must be a multiple of 64. */
 int ctrlv_groupnorm_from_partials(const void* x, int n_img, int S, int C, int imgs_per_stat, float eps, float* partials,
                                   const float* gamma, const float* beta, int silu, void* y, ctrlv_stream_t stream);
-/* The statistics and apply passes on a SPLIT input (ctrlv_gemm_desc.out_lo; a launch with out_lo writes no gn_partials): x_lo / x2_lo are the lo planes of x / x2 (same shapes and
+/* The same on a SPLIT tensor (ABI 18): x_lo = the lo plane the producing launch wrote beside `x` (ctrlv_gemm_desc.out_lo together
+ * with gn_partials: the {R1} row-halo 3x3 and temporal convs, ctrlv_gemm_gn_partials_serves); NULL = plain. */
+int ctrlv_groupnorm_from_partials_split(const void* x, const void* x_lo, int n_img, int S, int C, int imgs_per_stat, float eps,
+                                        float* partials, const float* gamma, const float* beta, int silu, void* y,
+                                        ctrlv_stream_t stream);
+/* The statistics and apply passes on a SPLIT input (ctrlv_gemm_desc.out_lo): x_lo / x2_lo are the lo planes of x / x2 (same shapes and
  * pitches; either may be NULL = that half has no lo plane); the normalised value is x + x_lo.  y is a plain tensor. */
 int ctrlv_groupnorm_stats_split(const void* x, const void* x_lo, const void* x2, const void* x2_lo, int c_split, int n_img,
                                 int S, int C, int imgs_per_stat, float eps, float* partials, ctrlv_stream_t stream);

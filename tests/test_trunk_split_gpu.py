@@ -175,6 +175,63 @@ def test_gemm_split_convs(ops, kind, H, W, n, cin, cout):
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("kind,H,W,n,ips,cout", [("conv_r1", 8, 32, 6, 1, 320), ("conv_r1", 16, 64, 3, 3, 640),
+                                                   ("temporal_r1", 8, 16, 9, 3, 320), ("temporal_r1", 8, 8, 6, 3, 1280)])
+def test_gemm_split_writes_groupnorm_partials(ops, kind, H, W, n, ips, cout):
+    """Round 6: the two trunk writers that feed a GroupNorm -- conv2 of a res block (row-halo 3x3, {R1})
+    and its temporal conv2 (AlphaBlender, {R1}; in front of a transformer's opening norm) -- write the norm's chunk partials
+    in the SAME launch that splits the output into hi + lo (GNS + LO instantiations): both planes are bit-identical to the
+    launch without partials, and GroupNorm(hi + lo) from the partials agrees with fp64 and with the two-pass split norm."""
+    from ctrlv_amd import packing
+    cin, S, M = 64, H * W, n * H * W
+    x = torch.randn(n, cin, H, W, generator=g(1)).to(EL)
+    b = torch.randn(cout, generator=g(3)) + 3.0
+    if kind.startswith("conv"):
+        wt = torch.randn(cout, cin, 3, 3, generator=g(2)) / math.sqrt(9 * cin)
+        wd = packing.pack_conv3x3(wt).to(DEV)
+        kw = dict(N=cout, cin=cin, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=b.to(DEV))
+        ref = rows_from_nchw(F.conv2d(x.double(), wt.to(EL).double(), b.double(), padding=1))
+    else:
+        wt = torch.randn(cout, cin, 3, 1, 1, generator=g(2)) / math.sqrt(3 * cin)
+        wd = packing.pack_conv_temporal(wt).to(DEV)
+        x5 = x.double().reshape(n // ips, ips, cin, H, W).permute(0, 2, 1, 3, 4)
+        ref = F.conv3d(x5, wt.to(EL).double(), b.double(), padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(n, cout, H, W)
+        ref = rows_from_nchw(ref)
+        kw = dict(N=cout, cin=cin, taps=3, mode=2, temporal=(ips, S), bias=b.to(DEV))
+    r1 = torch.randn(M, cout, generator=g(4)) * 2
+    r1h, r1l = split(r1)
+    kw.update(R1=r1h.to(DEV), R1_lo=r1l.to(DEV), s_acc=0.5)
+    ref = 0.5 * ref + (r1h.double() + r1l.double())
+    xd = rows_from_nchw(x).to(DEV)
+    hi0, lo0 = torch.empty(M, cout, dtype=EL, device=DEV), torch.empty(M, cout, dtype=EL, device=DEV)
+    ops.gemm(xd, wd, hi0, out_lo=lo0, **kw)
+    hi = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    lo = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    assert ops.gemm_gn_partials_serves(xd, wd, hi, out_lo=lo, **kw)
+    part = torch.full((ops.groupnorm_fused_scratch_floats(n, S, ips),), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(xd, wd, hi, out_lo=lo, gn_partials=part, **kw)
+    assert torch.equal(hi, hi0) and torch.equal(lo, lo0)
+    assert parity_err(joined(hi, lo), ref.float(), kind) < 2e-5
+    gamma, beta = torch.randn(cout, generator=g(6)), torch.randn(cout, generator=g(7))
+    y = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    ops.groupnorm_from_partials(hi, n, S, cout, ips, gamma.to(DEV), beta.to(DEV), 1e-6, True, y, part, x_lo=lo)
+    xs = ref.reshape(n, H, W, cout).permute(0, 3, 1, 2)
+    if ips == 1:
+        gn = F.group_norm(xs, 32, gamma.double(), beta.double(), 1e-6)
+    else:
+        x5 = xs.reshape(n // ips, ips, cout, H, W).permute(0, 2, 1, 3, 4)
+        gn = F.group_norm(x5, 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 1, 3, 4).reshape(n, cout, H, W)
+    yr = rows_from_nchw(F.silu(gn).float())
+    assert parity_err(y, yr, f"{kind}: GroupNorm from split partials") < 5e-4
+    y2 = torch.empty_like(y)
+    p2 = torch.empty(ops.groupnorm_scratch_floats(n, S, cout, ips), dtype=torch.float32, device=DEV)
+    ops.groupnorm(hi, None, n, S, cout, ips, gamma.to(DEV), beta.to(DEV), 1e-6, True, y2, p2, x_lo=lo)
+    assert rel_l2(y.float().cpu(), y2.float().cpu()) < 2e-4
+    # the {bias} / {R1, V} / {R1, R2} trunk writers feed no GroupNorm: not served with split planes
+    kw2 = {k: v for k, v in kw.items() if k not in ("R1", "R1_lo", "s_acc")}
+    assert not ops.gemm_gn_partials_serves(xd, wd, hi, out_lo=lo, **kw2)
+
+
 def test_gemm_split_rejections(ops):
     from ctrlv_amd import packing
     M, N, K = 2048, 320, 128

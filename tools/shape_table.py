@@ -19,6 +19,10 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     unet, ctrl = bench.build_models(dev, args.workload, args.frames, bench.torch_dtype(args.dtype))
+    if args.trunk != "same":                       # (bench.main's rule: the split planes are fp16 elements)
+        for m in (unet, ctrl):
+            if m is not None:
+                m.trunk_dtype = args.trunk
     args.hip_graph = False
     st = bench.make_stepper(unet, ctrl, dev, args, clip_index=0)
     st.use_hip_graph = False
@@ -31,6 +35,9 @@ def main():
     agg = {}
     for fam, ms, fl, by, (M, N, K, flags) in timer.launches:
         if not fam.startswith("gemm"):
+            if fam in ("groupnorm", "layernorm"):     # one line per shape: where the norm families' time goes
+                d = agg.setdefault((fam, M, N, 0, flags & 1, 0, 0, 0), [0, 0.0, 0.0, 0.0])
+                d[0] += 1; d[1] += ms; d[3] += by
             continue
         det = ("ff_fused" if flags & 0x100 else fam, M, N, K, flags & 1, (flags >> 1) & 3, (flags >> 3) & 3, 0)
         d = agg.setdefault(det, [0, 0.0, 0.0, 0.0])
