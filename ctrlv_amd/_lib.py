@@ -54,7 +54,18 @@ class ProfileRecord(ctypes.Structure):
 
 
 FAMILIES = ("gemm_linear", "gemm_conv3x3", "gemm_conv_temporal", "attention_spatial", "attention_temporal", "groupnorm",
-            "layernorm", "residual_add")
+            "layernorm", "residual_add", "gemm_temporal_block")
+
+
+class TemporalFusedDesc(ctypes.Structure):
+    """Mirror of `ctrlv_temporal_fused_desc`."""
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int), ("wf", c_void_p), ("bias", c_void_p),
+        ("R1", c_void_p), ("R1_lo", c_void_p), ("ldr1", c_int),
+        ("V", c_void_p), ("vmode", c_int), ("vdiv", c_int), ("vmod", c_int), ("vS", c_int), ("ldv", c_int),
+        ("out", c_void_p), ("out_lo", c_void_p), ("ldo", c_int),
+        ("B", c_int), ("F", c_int), ("S", c_int), ("C", c_int),
+    ]
 
 
 class TensorDesc(ctypes.Structure):
@@ -98,6 +109,10 @@ SIGNATURES = {
     "ctrlv_ff_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),
     "ctrlv_ff_fused_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p,
                                   c_void_p, ctypes.POINTER(GemmDesc), c_void_p]),
+    "ctrlv_temporal_fused_weight_bytes": (c_size_t, []),
+    "ctrlv_temporal_fused_pack": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctrlv_temporal_fused": (c_int, [ctypes.POINTER(TemporalFusedDesc), c_void_p]),
+    "ctrlv_temporal_fused_serves": (c_int, [ctypes.POINTER(TemporalFusedDesc)]),
     "ctrlv_attention_spatial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_spatial_prescaled": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ctrlv_attention_temporal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -155,7 +170,8 @@ _libs = {}                # element dtype code (2 bf16 / 1 fp16) -> CDLL
 _tls = threading.local()  # .failed = the library whose call returned a negative status last (this thread)
 # c_int-returning entry points whose value is NOT a status code
 _NO_STATUS = {"ctrlv_abi_version", "ctrlv_elem_dtype", "ctrlv_build_id", "ctrlv_last_error", "ctrlv_ff_fused_w1f_bytes",
-              "ctrlv_gemm_gn_partials_serves", "ctrlv_ff_fused_serves", "ctrlv_plan_num_down_residuals"}
+              "ctrlv_gemm_gn_partials_serves", "ctrlv_ff_fused_serves", "ctrlv_plan_num_down_residuals",
+              "ctrlv_temporal_fused_serves"}
 
 
 def _status_recorder(lib, fn):

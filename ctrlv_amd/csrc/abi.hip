@@ -37,6 +37,7 @@ const ctrlv_debug_t& ctrlv_debug() {
     d.pp_balanced = env("CTRLV_PP_BALANCED", 1);
     d.pp_cgrp = env("CTRLV_PP_CGRP", 0);
     d.attn_rows = env("CTRLV_ATTN_ROWS", 0);
+    d.temporal_fused = env("CTRLV_TEMPORAL_FUSED", 1);
     return d;
   }();
   return dbg;

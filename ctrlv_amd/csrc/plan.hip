@@ -127,6 +127,7 @@ struct Transformer {
   Norm gn, s_ln1, s_ln3, t_lnin, t_ln1, t_ln3;
   Linear pin, pout, s_qkv, s_o, t_qkv, t_o, tpe1, tpe2;
   FeedFwd s_ff, t_ffin, t_ff;
+  el_t* t_wf = nullptr;           // C = 320 only: fragment-major q|k|v + to_out of the temporal attention (temporal_fused.hip)
   int xattn_off[2] = {0, 0};
   float* frame_emb = nullptr;     // [cfg.num_frames][C] fp32, prepared at load time
   std::string name;
@@ -411,6 +412,10 @@ int load_tr(Loader& L, Transformer& t, int cross_dim) {
   TRY(L.qkv(tb + ".attn1", C, t.t_qkv));
   TRY(L.linear(tb + ".attn1.to_out.0", C, C, t.t_o));
   TRY(L.ff(tb + ".ff", C, C, t.t_ff));
+  if (C == 320 && t.t_qkv.n == 960 && t.t_qkv.k == 320 && t.t_o.n == 320 && t.t_o.k == 320) {
+    TRY(L.alloc(ctrlv_temporal_fused_weight_bytes(), (void**)&t.t_wf, false));
+    TRY(ctrlv_temporal_fused_pack(t.t_qkv.w, t.t_qkv.k, t.t_o.w, t.t_o.k, t.t_wf, L.st));
+  }
   TRY(L.linear(t.name + ".time_pos_embed.linear_1", 4 * C, C, t.tpe1));
   TRY(L.linear(t.name + ".time_pos_embed.linear_2", C, 4 * C, t.tpe2));
   TRY(L.mix_alpha(t.name + ".time_mixer.mix_factor", &t.alpha));
@@ -795,21 +800,40 @@ int run_tr(Ctx& c, const Transformer& t, const Trk& x, int H, int W, Trk* out_) 
     TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C, &u));
   }
   TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
-  TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
-  if (!c.dry) {
-    ProfScope ps(c, CTRLV_FAM_ATTENTION_TEMPORAL, 4.0 * B * S * (C / 64) * (double)F * F * 64, 2.0 * 4 * B * F * (double)S * C, B * S,
-                 F, C);
-    TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
-  }
   const Trk g1 = c.trunk(M, C);
   {
-    ctrlv_gemm_desc d = gd(a, C, t.t_o, g1.hi, C, (int)M, C, C, C);
-    set_out(d, g1);
-    set_r1(d, g0, C);
-    d.V = c.xattn + t.xattn_off[1]; d.ldv = c.ldx; d.vdiv = F * S;
-    if (c.quirk && B > 1) { d.vmode = 2; d.vS = S; d.vmod = B; }   // diffusers 0.27.2: context rows (s, b), tokens (b, s)
-    else d.vmode = 1;
-    TRY(gemm(c, d));
+    // attn1 over the frames + residual + the one-key cross-attention vector (attn2): at C = 320 ONE launch -- q|k|v and the
+    // attention output never reach HBM (temporal_fused.hip; CTRLV_TEMPORAL_FUSED=0: the three launches)
+    ctrlv_temporal_fused_desc fd;
+    memset(&fd, 0, sizeof(fd));
+    fd.x = tt; fd.ldx = C; fd.wf = t.t_wf; fd.bias = t.t_o.b;
+    fd.R1 = g0.hi; fd.R1_lo = g0.lo; fd.ldr1 = C;
+    fd.V = c.xattn + t.xattn_off[1]; fd.ldv = c.ldx; fd.vdiv = F * S; fd.vS = 1; fd.vmod = 1 << 30;
+    if (c.quirk && B > 1) { fd.vmode = 2; fd.vS = S; fd.vmod = B; }   // diffusers 0.27.2: context rows (s, b), tokens (b, s)
+    else fd.vmode = 1;
+    fd.out = g1.hi; fd.out_lo = g1.lo; fd.ldo = C;
+    fd.B = B; fd.F = F; fd.S = S; fd.C = C;
+    if (ctrlv_debug().temporal_fused && t.t_wf && ctrlv_temporal_fused_serves(&fd)) {
+      if (!c.dry) {
+        if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
+        ProfScope ps(c, CTRLV_FAM_GEMM_TEMPORAL_BLOCK, 2.0 * M * C * 4.0 * C + 4.0 * B * S * (C / 64) * (double)F * F * 64,
+                     (double)M * C * 2 * (3 + (g0.lo ? 1 : 0) + (g1.lo ? 1 : 0)), (int)M, 4 * C, C);
+        TRY(ctrlv_temporal_fused(&fd, c.st));
+      }
+    } else {
+      TRY(gemm(c, gd(tt, C, t.t_qkv, qkv, 3 * C, (int)M, 3 * C, C, 3 * C)));
+      if (!c.dry) {
+        ProfScope ps(c, CTRLV_FAM_ATTENTION_TEMPORAL, 4.0 * B * S * (C / 64) * (double)F * F * 64, 2.0 * 4 * B * F * (double)S * C, B * S,
+                     F, C);
+        TRY(ctrlv_attention_temporal(qkv, a, B, F, S, C, c.st));
+      }
+      ctrlv_gemm_desc d = gd(a, C, t.t_o, g1.hi, C, (int)M, C, C, C);
+      set_out(d, g1);
+      set_r1(d, g0, C);
+      d.V = fd.V; d.ldv = fd.ldv; d.vdiv = fd.vdiv; d.vmode = fd.vmode;
+      if (fd.vmode == 2) { d.vS = S; d.vmod = B; }
+      TRY(gemm(c, d));
+    }
   }
   const Trk h3 = g0;
   {   // AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)

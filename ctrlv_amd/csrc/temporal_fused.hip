@@ -1,0 +1,398 @@
+// Fused temporal self-attention block at C = 320 (the 72 x 128 level's TemporalBasicTransformerBlock.attn1 with its residual
+// and the one-key cross-attention vector; SURVEY A.4, reference instantiation sites src/ctrlv/models/controlnet.py:157-170), gfx950:
+//
+//     g1 = g0 + to_out( softmax_f( q k^T / 8 ) v ) + b_o + V[clip],      (q | k | v) = tt W_qkv^T,   tt = LayerNorm(g0)
+//
+// per PIXEL over its F <= 32 frames.  The three launches it replaces (q|k|v projection, ctrlv_attention_temporal, output
+// projection) write the 3C-wide q|k|v tensor and the attention output to HBM and read them back: 2.4 GB of the 4.1 GB the
+// block moves per instance at M = 460 800.  Here nothing but tt, g0 and g1 touches HBM.
+//
+// Structure: ONE WAVE = ONE PIXEL.  A pixel's F frames are the 32 columns of every MFMA (rows (b F + f) S + s of the
+// channels-last activation: the (b f) s c <-> (b s) f c permutes are address arithmetic, as everywhere in this library); its
+// 32 x 320 input rows sit in registers as B-operand fragments (80 registers, the pair kernel's form, ff_fused.hip) and
+// everything between them and the output accumulators STAYS IN REGISTERS -- no activation goes through LDS:
+//   * q_h, k_h (per 32-channel block): acc = W . x  (weight block = A operand)  -> lane = frame, 16 channels 8 q + 4 hsel + r.
+//     Both come out in the SAME channel-to-slot assignment, and a contraction does not care which channel sits in which K
+//     slot: rounded to the element type, k is the A operand and q the B operand of S^T = K Q^T as they stand (4 MFMAs / head).
+//   * softmax over the keys of a query = over the lane's 16 scores and its half-wave partner's (one v_permlane32_swap each for
+//     max and sum); keys >= F are masked.  The exponentials, rounded, are the B operand of O^T = V^T P as they stand.
+//   * v_h is computed with the operand ROLES SWAPPED (x = A operand, weight block = B operand: the same registers and the same
+//     LDS fragments, the two arguments of the MFMA exchanged): lane = channel, 16 frames 8 q + 4 hsel + r -- which IS the A
+//     operand V^T of O^T = V^T P with the key-to-slot assignment P has.  No transpose anywhere.
+//   * O^T (lane = frame, channels 8 q + 4 hsel + r) rounded is the B operand of the output projection; its channel-to-slot
+//     assignment is baked into the K order of the packed W_o (ctrlv_temporal_fused_pack), and the ROW order of every W_o block
+//     is chosen so that a lane ends up with 16 CONSECUTIVE output channels: residual reads and stores are 2 x 16 B per lane
+//     and block straight from / to the accumulator registers (no LDS transpose).
+// Weights: 40 chunks of 20 KiB (32 rows x K = 320, fragment-major: one KiB per MFMA, lane-linear) stream through a 3-slot
+// LDS-DMA ring, issued two chunks ahead; the 8 waves of a workgroup (8 consecutive pixels) walk the chunks in step, one
+// barrier per chunk = per 20-MFMA chain.  Order: per head (q b0, k b0, q b1, k b1, v b0, v b1), then the 10 blocks of W_o.
+// Frames are padded to 32 MFMA columns: at F = 25 78 % of the matrix work is real (the attention itself is 5 % of it).
+#include "common.h"
+#include "gemm_pp_kernel.h"      // wait_vmcnt / raw_barrier / pp_store_out (store-data hazard guard) / pp_split_io
+
+namespace {
+
+constexpr int kC = 320, kHeads = kC / 64, kKS = kC / 16;         // 20 K steps of 16
+constexpr int kChunk = kKS * 1024;                               // 20 KiB: 32 weight rows x 320, one KiB per K step
+constexpr int kQkvChunks = 6 * kHeads, kOutChunks = kC / 32, kChunks = kQkvChunks + kOutChunks;   // 30 + 10
+constexpr int kSlots = 3;
+constexpr int kDummyOff = kSlots * kChunk;                       // one KiB for the pieces a wave issues beyond the chunk's 20
+constexpr int kSmem = kDummyOff + 1024;
+constexpr int kNQ = 6;                                           // fragment reads in flight ahead of a chain
+constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // (1 / sqrt(64)) log2(e)
+
+struct TaArgs {
+  const el_t* x; int ldx;                 // LayerNorm output rows [M][ldx]
+  const el_t* wf;                         // kChunks x 20 KiB (ctrlv_temporal_fused_pack)
+  const float* bias;                      // [320] output-projection bias or null
+  const el_t* r1; const el_t* r1_lo; int ldr1;
+  const float* vtab; int vmode, vdiv, vmod, vS, ldv, vrows;     // vrows: table rows the launch can address
+  el_t* out; el_t* out_lo; int ldo;
+  int B, F, S;
+};
+
+__device__ __forceinline__ elx8 pack_half(const f32x16& a, int ks) {          // accumulators 8 ks .. 8 ks + 7 -> one operand
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = a[8 * ks + e];
+  return __builtin_bit_cast(elx8, pack_elx8(f));
+}
+// the value is materialised HERE: left alone, the scheduler sinks the rounding of a head's q / P / attention output (needed
+// only chains later) behind those chains and keeps the fp32 accumulators alive instead -- 64 registers over budget
+__device__ __forceinline__ void pin(elx8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ float swap_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool LO>
+__global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int f32_ = lane & 31, hsel = lane >> 5;
+  const int F = a.F, S = a.S;
+  const long npix = (long)a.B * S;
+  const long ngroups = (npix + 7) / 8;
+  const int G = gridDim.x;
+  constexpr unsigned kOOB = 0xFFFFFFFFu;
+  constexpr int kFlags = 0x00020000;
+  const long M = (long)a.B * F * S;
+
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wf, 0, kChunks * kChunk, kFlags);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(M * a.ldx * 2), kFlags);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(a.r1 ? a.r1 : a.x), 0, a.r1 ? (int)(M * a.ldr1 * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsRL = __builtin_amdgcn_make_buffer_rsrc((void*)((LO && a.r1_lo) ? a.r1_lo : a.x), 0,
+                                                                        (LO && a.r1_lo) ? (int)(M * a.ldr1 * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(M * a.ldo * 2), kFlags);
+  const __amdgpu_buffer_rsrc_t rsOL = __builtin_amdgcn_make_buffer_rsrc((void*)((LO && a.out_lo) ? a.out_lo : a.out), 0,
+                                                                        (LO && a.out_lo) ? (int)(M * a.ldo * 2) : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.wf), 0,
+                                                                       a.bias ? kC * 4 : 0, kFlags);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.vmode ? (const void*)a.vtab : (const void*)a.wf), 0,
+                                                                       a.vmode ? (int)((long)a.vrows * a.ldv * 4) : 0, kFlags);
+
+  // LDS-DMA of chunk `c` (0 .. kChunks - 1, cyclic) into ring slot `g % 3` (g = the workgroup's running chunk count): wave w
+  // takes pieces w, w + 8, w + 16; the last one exists for w < 4 only -- the others issue it out of range (zeros, no memory
+  // traffic) into the dummy KiB, so that every wave has exactly three vector-memory operations per chunk
+  auto dma = [&](int c, int g) {
+    char* slot = smem + (g % kSlots) * kChunk;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int pi = k * 8 + wid;
+      const bool real = pi < kKS;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(real ? slot + pi * 1024 : smem + kDummyOff), 16,
+                                               real ? (unsigned)(lane * 16) : kOOB, c * kChunk + pi * 1024, 0, 0);
+    }
+  };
+  // One chunk = one chain of 20 MFMAs over K = 320 against the wave's x fragments.  W_IS_A: acc = W . x (lane = frame);
+  // else the roles swapped: acc = x . W (lane = channel).  Fragment reads run kNQ MFMAs ahead through rotating registers.
+  int g = 0;                                                     // running chunk count of this workgroup (ring phase)
+  auto slot_begin = [&]() {
+    // every wave's pieces of chunk g have landed (each waited for its own at the end of its previous slot) and every wave is
+    // past its reads of chunk g - 1, whose slot the DMA of chunk g + 2 refills
+    lds_done_barrier();
+    dma((g + 2) % kChunks, g + 2);
+  };
+  auto chain = [&](auto w_is_a, const elx8 (&xb)[kKS], const f32x16& init) {
+    constexpr bool W_IS_A = decltype(w_is_a)::value;
+    const char* s1 = smem + (g % kSlots) * kChunk + lane * 16;
+    elx8 wq[kNQ];
+#pragma unroll
+    for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
+    f32x16 acc = init;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      acc = W_IS_A ? mfma_32x32x16(wq[ks % kNQ], xb[ks], acc) : mfma_32x32x16(xb[ks], wq[ks % kNQ], acc);
+      if (ks + kNQ < kKS) wq[ks % kNQ] = *(const elx8*)(s1 + (ks + kNQ) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: chunks 0 and 1 in flight
+  dma(0, 0);
+  dma(1, 1);
+  wait_vmcnt<3>();                                               // own pieces of chunk 0 (chunk 1's may still fly)
+
+  for (long grp = blockIdx.x; grp < ngroups; grp += G) {
+    const long pix = grp * 8 + wid;
+    const bool live = pix < npix;
+    const int b = live ? (int)(pix / S) : 0, s = live ? (int)(pix - (long)b * S) : 0;
+    const long row = ((long)b * F + f32_) * S + s;               // this lane's frame of this wave's pixel
+    const bool ok = live && f32_ < F;
+    // ---- x rows as B fragments: K step ks = channels 16 ks + 8 hsel .. + 7 of the lane's row (frames >= F: zeros)
+    elx8 xr[kKS];
+    {
+      const unsigned xoff = ok ? (unsigned)(row * a.ldx * 2) + 16u * hsel : kOOB;
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks)
+        xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
+    }
+    elx8 ap[kKS];                                                // attention output, the output projection's B fragments
+#pragma unroll
+    for (int h = 0; h < kHeads; ++h) {
+      f32x16 sacc = zero16;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        slot_begin();
+        elx8 q0, q1;
+        {
+          const f32x16 qa = chain(std::true_type{}, xr, zero16);
+          q0 = pack_half(qa, 0); q1 = pack_half(qa, 1);           // (packed at once: 8 registers across the k chain, not 16)
+          pin(q0); pin(q1);
+        }
+        wait_vmcnt<3>();
+        ++g;
+        slot_begin();
+        const f32x16 ka = chain(std::true_type{}, xr, zero16);
+        wait_vmcnt<3>();
+        ++g;
+        // S^T += K_blk Q_blk^T: both operands as they come out of the chains (same channel-to-slot assignment)
+        sacc = mfma_32x32x16(pack_half(ka, 0), q0, sacc);
+        sacc = mfma_32x32x16(pack_half(ka, 1), q1, sacc);
+      }
+      // ---- softmax over the keys (accumulator e of lane (query, hsel) = key 8 (e >> 2) + 4 hsel + (e & 3))
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * hsel;
+        if (key >= F) sacc[e] = -INFINITY;
+        mx = fmaxf(mx, sacc[e]);
+      }
+      mx = swap_max(mx) * kScaleLog2;
+      float rs_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(sacc[e] * kScaleLog2 - mx);
+        sacc[e] = p;
+        rs_ += p;
+      }
+      const float inv = __builtin_amdgcn_rcpf(swap_sum(rs_));
+      elx8 pf0 = pack_half(sacc, 0), pf1 = pack_half(sacc, 1);
+      pin(pf0); pin(pf1);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        slot_begin();
+        const f32x16 va = chain(std::false_type{}, xr, zero16);   // V^T: lane = channel, frames 8 q + 4 hsel + r
+        wait_vmcnt<3>();
+        ++g;
+        f32x16 oa = mfma_32x32x16(pack_half(va, 0), pf0, zero16);
+        oa = mfma_32x32x16(pack_half(va, 1), pf1, oa);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oa[e] *= inv;
+        ap[h * 4 + blk * 2] = pack_half(oa, 0);
+        ap[h * 4 + blk * 2 + 1] = pack_half(oa, 1);
+        pin(ap[h * 4 + blk * 2]); pin(ap[h * 4 + blk * 2 + 1]);
+      }
+    }
+    // ---- output projection, 10 blocks of 32 channels; lane (frame, hsel) ends with channels 32 nb + 16 hsel .. + 15
+    unsigned vrow = 0;
+    if (a.vmode) {
+      const long m0 = ((long)b * F) * S + s;
+      const long vi = a.vmode == 1 ? (m0 / a.vdiv) % a.vmod : ((m0 / a.vdiv) * a.vS + (m0 % a.vS)) % a.vmod;
+      vrow = (unsigned)(vi * a.ldv * 4);
+    }
+#pragma unroll 1
+    for (int nb = 0; nb < kOutChunks; ++nb) {
+      slot_begin();
+      const int c0 = nb * 32 + 16 * hsel;
+      // start values (bias + the pixel's row vector) and the residual rows: requested in front of the chain
+      u32x4_t bi[4], vi[4], rr[2], rl[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bi[q] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)((c0 + 4 * q) * 4), 0, 0);
+        vi[q] = __builtin_amdgcn_raw_buffer_load_b128(rsV, a.vmode ? vrow + (unsigned)((c0 + 4 * q) * 4) : kOOB, 0, 0);
+      }
+      const unsigned roff = ok ? (unsigned)(row * a.ldr1 * 2) + (unsigned)(c0 * 2) : kOOB;
+      const unsigned ooff = ok ? (unsigned)(row * a.ldo * 2) + (unsigned)(c0 * 2) : kOOB;
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        rr[hq] = __builtin_amdgcn_raw_buffer_load_b128(rsR, roff, hq * 16, 0);
+        if (LO) rl[hq] = __builtin_amdgcn_raw_buffer_load_b128(rsRL, roff, hq * 16, 0);
+      }
+      f32x16 ini;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ini[4 * q + r] = __uint_as_float(bi[q][r]) + __uint_as_float(vi[q][r]);
+      const f32x16 acc = chain(std::true_type{}, ap, ini);
+      ++g;
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        float o[8], rf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = acc[8 * hq + e];
+        unpack_elx8(make_uint4(rr[hq][0], rr[hq][1], rr[hq][2], rr[hq][3]), rf);
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = o[e] + rf[e];
+        }
+        if (LO) add_lo8(o, make_uint4(rl[hq][0], rl[hq][1], rl[hq][2], rl[hq][3]));
+        const uint4 pk = pack_elx8(o);
+        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+        pp_store_out(pv, rsO, ooff, hq * 16);
+        if (LO) {
+          const uint4 pl = split_lo8(o, pk);
+          const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
+          pp_store_out(pvl, rsOL, ooff, hq * 16);
+        }
+      }
+      // (the residual rows were consumed: every older vector-memory operation of this wave -- the DMA of chunk g + 1, issued
+      //  a slot ago, included -- has completed; only this slot's stores and DMA may still be in flight)
+    }
+  }
+  wait_vmcnt<0>();                                               // the look-ahead DMA: nothing may be in flight at exit
+#endif
+}
+
+// fragment-major copy of the packed weights.  Chunk c < 30: head h = c / 6, kind = c % 6 = (q b0, k b0, q b1, k b1, v b0,
+// v b1): rows of the fused [3C][C] projection.  Chunk 30 + nb: block nb of W_o with its rows permuted (A row 8 q + 4 hs + r
+// holds output channel 32 nb + 16 hs + 4 q + r) and its K steps in the order the attention output arrives:
+// step jj = (head, block, ks), slot (hs', s) <-> input channel 64 head + 32 block + 8 (2 ks + (s >> 2)) + 4 hs' + (s & 3).
+__global__ void temporal_pack_kernel(const el_t* __restrict__ wqkv, int ld_qkv, const el_t* __restrict__ wo, int ld_o,
+                                     el_t* __restrict__ wf) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)kChunks * kKS * 512) return;
+  const int e = i & 7, lane = (i >> 3) & 63, ks = (int)((i >> 9) % kKS), c = (int)(i / (kKS * 512));
+  const int i32 = lane & 31, hs = lane >> 5;
+  el_t v;
+  if (c < kQkvChunks) {
+    const int h = c / 6, kind = c % 6;
+    const int which = kind >= 4 ? 2 : (kind & 1), blk = kind >= 4 ? kind - 4 : kind >> 1;
+    const int rowi = which * kC + h * 64 + blk * 32 + i32;
+    v = wqkv[(long)rowi * ld_qkv + ks * 16 + 8 * hs + e];
+  } else {
+    const int nb = c - kQkvChunks;
+    const int q = i32 >> 3, hs_r = (i32 >> 2) & 1, r = i32 & 3;            // A row i32 = 8 q + 4 hs_r + r
+    const int n = nb * 32 + 16 * hs_r + 4 * q + r;
+    const int head = ks >> 2, blk = (ks >> 1) & 1, k2 = ks & 1;
+    const int d = 64 * head + 32 * blk + 8 * (2 * k2 + (e >> 2)) + 4 * hs + (e & 3);
+    v = wo[(long)n * ld_o + d];
+  }
+  wf[i] = v;
+}
+
+}  // namespace
+
+extern "C" size_t ctrlv_temporal_fused_weight_bytes(void) { return (size_t)kChunks * kChunk; }
+
+extern "C" int ctrlv_temporal_fused_pack(const void* wqkv_packed, int ld_qkv, const void* wo_packed, int ld_o, void* wf,
+                                         ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(wqkv_packed && wo_packed && wf, "ctrlv_temporal_fused_pack: null pointer");
+  CTRLV_CHECK_SHAPE(ld_qkv >= kC && ld_o >= kC, "ctrlv_temporal_fused_pack: the packed weights must have K >= 320");
+  const long n = (long)kChunks * kKS * 512;
+  hipLaunchKernelGGL(temporal_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const el_t*)wqkv_packed, ld_qkv, (const el_t*)wo_packed, ld_o, (el_t*)wf);
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}
+
+// the launcher's conditions (one function for it and for the callers' switch, ctrlv_temporal_fused_serves)
+static int ta_check(const ctrlv_temporal_fused_desc& d, bool report) {
+#define TA_REQ(cond, code, ...)                        \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      if (report) ctrlv_set_error(__VA_ARGS__);        \
+      return code;                                     \
+    }                                                  \
+  } while (0)
+  TA_REQ(d.C == kC, CTRLV_E_BAD_SHAPE, "ctrlv_temporal_fused: serves C = 320 only (C=%d)", d.C);
+  TA_REQ(d.B > 0 && d.F > 0 && d.F <= 32 && d.S > 0, CTRLV_E_BAD_SHAPE, "ctrlv_temporal_fused: B, S > 0 and 0 < F <= 32 (F=%d)", d.F);
+  TA_REQ(d.ldx >= kC && d.ldx % 8 == 0 && d.ldo >= kC && d.ldo % 8 == 0 && (!d.R1 || (d.ldr1 >= kC && d.ldr1 % 8 == 0)),
+         CTRLV_E_BAD_SHAPE, "ctrlv_temporal_fused: row pitches must be >= 320 and multiples of 8");
+  const long M = (long)d.B * d.F * d.S, lim = 0xFFFFFFF0L;
+  TA_REQ(M * d.ldx * 2 <= lim && M * d.ldo * 2 <= lim && (!d.R1 || M * d.ldr1 * 2 <= lim), CTRLV_E_BAD_SHAPE,
+         "ctrlv_temporal_fused: operands beyond 32-bit byte offsets");
+  TA_REQ((!d.R1_lo || d.R1) && ((!d.R1_lo && !d.out_lo) || CTRLV_ELEM_DTYPE == 1), CTRLV_E_BAD_ARG,
+         "ctrlv_temporal_fused: split trunk planes need R1 and the fp16 element library");
+  if (d.vmode) {
+    // the row vector must be constant over a pixel's frames: one table row per clip (vmode 1) or per (pixel, clip) (vmode 2)
+    TA_REQ((d.vmode == 1 || d.vmode == 2) && d.V && d.vmod > 0 && d.ldv >= kC && d.ldv % 4 == 0 && d.vdiv == d.F * d.S &&
+               (d.vmode == 1 || d.vS == d.S),
+           CTRLV_E_BAD_ARG, "ctrlv_temporal_fused: the row vector must be per clip (vdiv = F S; vmode 2: vS = S)");
+    const long vrows = d.vmode == 1 ? (long)d.B : (long)d.B * d.S;       // table rows the launch can address (vmod may be "none")
+    TA_REQ((vrows < d.vmod ? vrows : (long)d.vmod) * d.ldv * 4 <= lim, CTRLV_E_BAD_SHAPE, "ctrlv_temporal_fused: row-vector table too large");
+  }
+  return CTRLV_OK;
+#undef TA_REQ
+}
+
+extern "C" int ctrlv_temporal_fused_serves(const ctrlv_temporal_fused_desc* d) {
+  return (d && ta_check(*d, false) == CTRLV_OK) ? 1 : 0;
+}
+
+extern "C" int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* dp, ctrlv_stream_t stream) {
+  CTRLV_CHECK_ARG(dp && dp->x && dp->wf && dp->out, "ctrlv_temporal_fused: null pointer");
+  const ctrlv_temporal_fused_desc& d = *dp;
+  const int rc = ta_check(d, true);
+  if (rc != CTRLV_OK) return rc;
+  TaArgs a;
+  a.x = (const el_t*)d.x; a.ldx = d.ldx; a.wf = (const el_t*)d.wf; a.bias = d.bias;
+  a.r1 = (const el_t*)d.R1; a.r1_lo = (const el_t*)d.R1_lo; a.ldr1 = d.R1 ? d.ldr1 : d.ldx;
+  a.vtab = d.V; a.vmode = d.V ? d.vmode : 0; a.vdiv = d.vdiv > 0 ? d.vdiv : 1; a.vmod = d.vmod > 0 ? d.vmod : 1;
+  a.vS = d.vS > 0 ? d.vS : 1; a.ldv = d.ldv;
+  a.vrows = 0;
+  if (a.vmode) {
+    const long vrows = a.vmode == 1 ? (long)d.B : (long)d.B * d.S;
+    a.vrows = (int)(vrows < a.vmod ? vrows : (long)a.vmod);
+  }
+  a.out = (el_t*)d.out; a.out_lo = (el_t*)d.out_lo; a.ldo = d.ldo;
+  a.B = d.B; a.F = d.F; a.S = d.S;
+  const int dev = ctrlv_current_device();
+  const long groups = ((long)d.B * d.S + 7) / 8;
+  const int num_cu = ctrlv_num_cu(dev);
+  long grid = groups;
+  if (groups > num_cu) {                    // persistent, every workgroup the same number of pixel groups
+    const long rounds = (groups + num_cu - 1) / num_cu;
+    grid = (groups + rounds - 1) / rounds;
+  }
+  const bool lo = d.R1_lo || d.out_lo;
+  static bool attr_set[2][CTRLV_MAX_DEVICES] = {};
+#define TA_LAUNCH(LOV)                                                                                                  \
+  do {                                                                                                                  \
+    auto kfn = temporal_fused_kernel<LOV>;                                                                              \
+    if (!attr_set[LOV][dev]) {                                                                                          \
+      CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));          \
+      attr_set[LOV][dev] = true;                                                                                        \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), kSmem, (hipStream_t)stream, a);                            \
+  } while (0)
+#ifdef CTRLV_ELEM_F16
+  if (lo) TA_LAUNCH(true); else TA_LAUNCH(false);
+#else
+  (void)lo;
+  TA_LAUNCH(false);
+#endif
+#undef TA_LAUNCH
+  CTRLV_LAUNCH_CHECK();
+  return CTRLV_OK;
+}

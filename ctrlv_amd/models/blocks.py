@@ -128,6 +128,7 @@ def _f32(t):
 
 
 _FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
+_TEMPORAL_FUSED = os.environ.get("CTRLV_TEMPORAL_FUSED", "1") != "0"     # the plan's switch (csrc/plan.hip run_tr)
 
 
 def _ff_pair(ws, x, ffp, ubox, out, C, rows_per_image=0, **epi):
@@ -318,10 +319,13 @@ class TransformerSpatioTemporalModel(nn.Module):
             t_qkv=packing.pack_qkv(tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight),
             t_o=(packing.pack_linear(tb.attn1.to_out[0].weight), _f32(tb.attn1.to_out[0].bias)),
             t_ff=ff(tb.ff),
+            t_wf=None,
             tpe=(packing.pack_linear(self.time_pos_embed.linear_1.weight), _f32(self.time_pos_embed.linear_1.bias),
                  packing.pack_linear(self.time_pos_embed.linear_2.weight), _f32(self.time_pos_embed.linear_2.bias)),
             alpha=_sigmoid(float(self.time_mixer.mix_factor.detach().float().cpu())),
         )
+        if tuple(pk["t_qkv"].shape) == (960, 320) and tuple(pk["t_o"][0].shape) == (320, 320) and pk["t_qkv"].is_cuda:
+            pk["t_wf"] = ops.temporal_fused_pack(pk["t_qkv"].contiguous(), pk["t_o"][0].contiguous())   # (csrc/plan.hip load_tr)
         self._pk = pk
         self._frame_emb = {}
 
@@ -380,15 +384,17 @@ class TransformerSpatioTemporalModel(nn.Module):
         _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, rows_per_image=S, R1=h2, V=emb, vmode=1, vdiv=S,
                vmod=F)
         ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
-        ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
-        ops.attention_temporal(qkv, a, B, F, S, C)
         g1 = ws.alloc((M, C))
         xt_vec = ctx.xattn[:, self.xattn_off[1]:]
-        if ctx.quirk and B > 1:     # diffusers 0.27.2: time_context rows ordered (s, b), tokens ordered (b, s)
-            ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, vmode=2, vdiv=F * S, vS=S,
-                     vmod=B)
+        # diffusers 0.27.2: time_context rows ordered (s, b), tokens ordered (b, s)
+        vkw = dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if (ctx.quirk and B > 1) else dict(vmode=1, vdiv=F * S)
+        if _TEMPORAL_FUSED and ops.temporal_fused_serves(t, pk["t_wf"], g1, B, F, S, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw):
+            # attn1 over the frames + residual + the cross-attention vector in ONE launch (csrc/plan.hip run_tr)
+            ops.temporal_fused(t, pk["t_wf"], g1, B, F, S, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw)
         else:
-            ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, vmode=1, vdiv=F * S)
+            ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
+            ops.attention_temporal(qkv, a, B, F, S, C)
+            ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw)
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0

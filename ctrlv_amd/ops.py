@@ -412,6 +412,46 @@ def attention_temporal(qkv, out, B, F, S, C):
     return out
 
 
+def temporal_fused_pack(wqkv_packed, wo_packed):
+    """Fragment-major weights of `temporal_fused` from the packed [960, >= 320] q|k|v projection and [320, >= 320] to_out."""
+    _need_gpu(wqkv_packed, "wqkv_packed")
+    assert wqkv_packed.shape[0] == 960 and wo_packed.shape[0] == 320 and wqkv_packed.dtype == wo_packed.dtype
+    lib = _L(wqkv_packed)
+    wf = torch.empty(lib.ctrlv_temporal_fused_weight_bytes() // 2, dtype=wqkv_packed.dtype, device=wqkv_packed.device)
+    check(lib.ctrlv_temporal_fused_pack(_p(wqkv_packed), wqkv_packed.stride(0), _p(wo_packed), wo_packed.stride(0), _p(wf),
+                                        _stream()), "ctrlv_temporal_fused_pack")
+    return wf
+
+
+def _temporal_fused_desc(x, wf, out, B, F, S, bias=None, R1=None, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1, R1_lo=None,
+                         out_lo=None):
+    from ._lib import TemporalFusedDesc
+    d = TemporalFusedDesc()
+    d.x, d.ldx, d.wf, d.bias = _p(x), x.stride(0), _p(wf), _p(bias)
+    d.R1, d.R1_lo, d.ldr1 = _p(R1), _p(R1_lo), (R1.stride(0) if R1 is not None else 0)
+    d.V, d.vmode, d.vdiv, d.vmod, d.vS = _p(V), (vmode if V is not None else 0), vdiv, vmod, vS
+    d.ldv = V.stride(0) if V is not None else 0
+    d.out, d.out_lo, d.ldo = _p(out), _p(out_lo), out.stride(0)
+    d.B, d.F, d.S, d.C = B, F, S, x.shape[1]
+    return d
+
+
+def temporal_fused_serves(x, wf, out, B, F, S, **kw):
+    return wf is not None and bool(_L(x).ctrlv_temporal_fused_serves(ctypes.byref(_temporal_fused_desc(x, wf, out, B, F, S, **kw))))
+
+
+def temporal_fused(x, wf, out, B, F, S, **kw):
+    """out = R1 + to_out(softmax_f(q k^T / 8) v) + bias + V[clip], (q|k|v) = x W_qkv^T, over the F frames of every pixel:
+    the temporal self-attention block at C = 320 in one launch (csrc/temporal_fused.hip)."""
+    _need_gpu(x, "x")
+    d = _temporal_fused_desc(x, wf, out, B, F, S, **kw)
+    ev = _prof.begin()
+    check(_L(x).ctrlv_temporal_fused(ctypes.byref(d), _stream()), "ctrlv_temporal_fused")
+    M, C = B * F * S, x.shape[1]
+    _prof.end(ev, "gemm_temporal_block", 2.0 * M * C * 4 * C + 4.0 * B * S * (C // 64) * F * F * 64, 2.0 * 3 * M * C)
+    return out
+
+
 def nchw_to_rows(src, dst, c_off=0):
     """src: contiguous (n_img, C, H, W) fp32/fp16/bf16 -> dst rows [n_img*H*W, ldc] bf16, channels [c_off, c_off+C)."""
     _need_gpu(src, "src")

@@ -203,6 +203,34 @@ int ctrlv_ff_fused_ln(const void* x, int ldx, const float* ln_gamma, const float
  * s_acc == 1) -- 0 = use the two ctrlv_gemm launches.  The launcher applies exactly these conditions. */
 int ctrlv_ff_fused_serves(const ctrlv_gemm_desc* out_desc, int ldx);
 
+/* Fused temporal self-attention block at C = 320 (ABI 18; csrc/temporal_fused.hip):
+ *     out = R1 + to_out( softmax_f( q k^T / 8 ) v ) + bias + V[clip],     (q | k | v) = x . W_qkv^T
+ * over the F <= 32 frames of every pixel -- `TemporalBasicTransformerBlock.attn1` with its residual and the one-key
+ * cross-attention vector [DIFF-0.27.2; instantiated by get_down_block / UNetMidBlockSpatioTemporal,
+ * src/ctrlv/models/controlnet.py:157-170,186-192] in ONE launch instead of ctrlv_gemm (q|k|v) + ctrlv_attention_temporal +
+ * ctrlv_gemm (to_out): neither the 3C-wide q|k|v tensor nor the attention output reaches HBM.  x = LayerNorm(R1) rows
+ * [B F S][ldx] ordered (b, f, s); wf = ctrlv_temporal_fused_weight_bytes() bytes written by ctrlv_temporal_fused_pack from the
+ * packed [3C][ld_qkv] q|k|v weight and the packed [C][ld_o] output projection; bias fp32 [C] or NULL; V: row-vector table
+ * as in ctrlv_gemm_desc (vmode 1: vdiv = F S -- one row per clip; vmode 2: also vS = S); R1_lo / out_lo: SPLIT trunk planes
+ * (fp16 element library).  Results: the arithmetic of the three launches up to summation orders (same rounding points:
+ * q, k, v, P and the attention output are rounded to the element type). */
+typedef struct ctrlv_temporal_fused_desc {
+  const void* x; int32_t ldx;
+  const void* wf;
+  const float* bias;
+  const void* R1; const void* R1_lo; int32_t ldr1;
+  const float* V; int32_t vmode, vdiv, vmod, vS, ldv;
+  void* out; void* out_lo; int32_t ldo;
+  int32_t B, F, S, C;
+} ctrlv_temporal_fused_desc;
+size_t ctrlv_temporal_fused_weight_bytes(void);
+int ctrlv_temporal_fused_pack(const void* wqkv_packed, int ld_qkv, const void* wo_packed, int ld_o, void* wf,
+                              ctrlv_stream_t stream);
+int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* d, ctrlv_stream_t stream);
+/* 1 if ctrlv_temporal_fused serves this descriptor (C = 320, F <= 32, pitches multiples of 8, 32-bit byte offsets, a per-clip
+ * row vector) -- 0 = use the three launches.  The launcher applies exactly these conditions. */
+int ctrlv_temporal_fused_serves(const ctrlv_temporal_fused_desc* d);
+
 /* Row softmax of fp32 scores into bf16 probabilities: probs[r, :cols] = softmax(scores[r, :cols]) (cols a multiple of 4,
  * <= 16384).  The VAE mid block's single-head attention (head dim 512; AutoencoderKLTemporalDecoder, called by
  * pipeline_video_control.py:235,278,346) runs as scores GEMM -> this -> P.V GEMM. */
@@ -428,6 +456,7 @@ int ctrlv_plan_destroy(ctrlv_plan* plan);
 enum {
   CTRLV_FAM_GEMM_LINEAR = 0, CTRLV_FAM_GEMM_CONV3X3 = 1, CTRLV_FAM_GEMM_CONV_TEMPORAL = 2, CTRLV_FAM_ATTENTION_SPATIAL = 3,
   CTRLV_FAM_ATTENTION_TEMPORAL = 4, CTRLV_FAM_GROUPNORM = 5, CTRLV_FAM_LAYERNORM = 6, CTRLV_FAM_RESIDUAL_ADD = 7,
+  CTRLV_FAM_GEMM_TEMPORAL_BLOCK = 8,    /* ctrlv_temporal_fused: q|k|v projection + attention over the frames + output projection */
 };
 typedef struct ctrlv_profile_record {
   int32_t family;             /* CTRLV_FAM_* */

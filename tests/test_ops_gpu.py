@@ -830,6 +830,66 @@ def test_attention_temporal(ops, B, Fr, S, C):
     assert parity_err(out, ref) < tol(5e-3)
 
 
+@pytest.mark.parametrize("B,Fr,S,vm", [(2, 25, 72, 1), (1, 3, 40, 0), (3, 32, 9, 2), (2, 25, 8, 2), (1, 25, 300, 1)])
+def test_temporal_fused(ops, B, Fr, S, vm):
+    """Fused temporal self-attention block at C = 320 (csrc/temporal_fused.hip): q|k|v projection,
+    attention over the frames of every pixel, output projection, residual and the per-clip row vector in ONE launch --
+    against fp32 PyTorch with the three launches' rounding points (q, k, v and the attention output rounded to the element
+    type), against the three launches themselves, bit-stable run to run, and a clip's rows independent of the batch.
+    Cases: pixel counts that are not multiples of the 8-pixel group, F = 3 / 25 / 32, no row vector / per clip / the
+    diffusers-0.27.2 (s, b) context order (vmode 2)."""
+    from ctrlv_amd import packing
+    C, heads, M = 320, 5, B * Fr * S
+    x = bf(torch.randn(M, C, generator=g(1)))
+    r1 = bf(torch.randn(M, C, generator=g(2)) * 2)
+    wq, wk, wv = (torch.randn(C, C, generator=g(3 + i)) / math.sqrt(C) for i in range(3))
+    wo, bo = torch.randn(C, C, generator=g(7)) / math.sqrt(C), torch.randn(C, generator=g(8))
+    vt = torch.randn(B, C, generator=g(9)) if vm else None
+    wqkv = packing.pack_qkv(wq, wk, wv).to(DEV)
+    wop = packing.pack_linear(wo).to(DEV)
+    wf = ops.temporal_fused_pack(wqkv, wop)
+    kw = dict(bias=bo.to(DEV), R1=r1.to(DEV))
+    vkw = {}
+    if vm:
+        vkw = dict(V=vt.to(DEV), vmode=1, vdiv=Fr * S) if vm == 1 else dict(V=vt.to(DEV), vmode=2, vdiv=Fr * S, vS=S, vmod=B)
+    out = torch.full((M, C), float("nan"), dtype=EL, device=DEV)
+    xd = x.to(DEV)
+    assert ops.temporal_fused_serves(xd, wf, out, B, Fr, S, **kw, **vkw)
+    ops.temporal_fused(xd, wf, out, B, Fr, S, **kw, **vkw)
+    # fp32 reference with the same rounding points
+    xf = x.float()
+    q, k, v = (bf(xf @ bf(w).float().T).float() for w in (wq, wk, wv))
+
+    def tok(t):          # rows (b, f, s) -> [B * S, heads, F, 64]
+        return t.reshape(B, Fr, S, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * S, heads, Fr, 64)
+    att = _sdpa_ref(tok(q), tok(k), tok(v)).reshape(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(M, C)
+    ref = bf(att).float() @ bf(wo).float().T + bo + r1.float()
+    if vm:
+        m = torch.arange(M)
+        idx = (m // (Fr * S)) if vm == 1 else ((m // (Fr * S)) * S + m % S) % B
+        ref = ref + vt[idx]
+    assert parity_err(out, ref, f"temporal_fused B{B} F{Fr} S{S}") < tol(5e-3)
+    # the three launches it replaces
+    qkv = torch.empty(M, 3 * C, dtype=EL, device=DEV)
+    a = torch.empty(M, C, dtype=EL, device=DEV)
+    old = torch.empty(M, C, dtype=EL, device=DEV)
+    ops.gemm(xd, wqkv, qkv, N=3 * C, cin=C)
+    ops.attention_temporal(qkv, a, B, Fr, S, C)
+    ops.gemm(a, wop, old, N=C, cin=C, **kw, **vkw)
+    assert rel_l2(out.float().cpu(), old.float().cpu()) < tol(3e-3)
+    out2 = torch.full_like(out, float("nan"))
+    ops.temporal_fused(xd, wf, out2, B, Fr, S, **kw, **vkw)
+    assert torch.equal(out, out2)
+    if B > 1 and vm != 2:                                 # clip 0 alone (vmode 2 couples the clips through the context order)
+        M1 = Fr * S
+        one = torch.full((M1, C), float("nan"), dtype=EL, device=DEV)
+        kw1 = dict(bias=bo.to(DEV), R1=r1[:M1].to(DEV))
+        if vm:
+            kw1.update(V=vt[:1].to(DEV), vmode=1, vdiv=Fr * S)
+        ops.temporal_fused(xd[:M1].contiguous(), wf, one, 1, Fr, S, **kw1)
+        assert torch.equal(one, out[:M1])
+
+
 # ------------------------------------------------------------------------------------------------ element-wise
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C", [4, 8, 320])
