@@ -23,9 +23,10 @@
 //     assignment is baked into the K order of the packed W_o (ctrlv_temporal_fused_pack), and the ROW order of every W_o block
 //     is chosen so that a lane ends up with 16 CONSECUTIVE output channels: residual reads and stores are 2 x 16 B per lane
 //     and block straight from / to the accumulator registers (no LDS transpose).
-// Weights: 40 chunks of 20 KiB (32 rows x K = 320, fragment-major: one KiB per MFMA, lane-linear) stream through a 3-slot
-// LDS-DMA ring, issued two chunks ahead; the 8 waves of a workgroup (8 consecutive pixels) walk the chunks in step, one
-// barrier per chunk = per 20-MFMA chain.  Order: per head (q b0, k b0, q b1, k b1, v b0, v b1), then the 10 blocks of W_o.
+// Weights: 40 chunks of 20 KiB (32 rows x K = 320, fragment-major: one KiB per MFMA, lane-linear) stream in PAIRS through a
+// 3-slot LDS-DMA ring (120 KiB), issued two pairs ahead; the 8 waves of a workgroup (8 consecutive pixels) walk the pairs in
+// step, one barrier per pair = per 40 MFMAs.  Order: per head (q b0, k b0), (q b1, k b1), (v b0, v b1), then the 10 blocks of
+// W_o.  The next pixel group's input rows are requested when the last head is done and land under the output projection.
 // Frames are padded to 32 MFMA columns: at F = 25 78 % of the matrix work is real (the attention itself is 5 % of it).
 #include "common.h"
 #include "gemm_pp_kernel.h"      // wait_vmcnt / raw_barrier / pp_store_out (store-data hazard guard) / pp_split_io
@@ -35,11 +36,23 @@ namespace {
 constexpr int kC = 320, kHeads = kC / 64, kKS = kC / 16;         // 20 K steps of 16
 constexpr int kChunk = kKS * 1024;                               // 20 KiB: 32 weight rows x 320, one KiB per K step
 constexpr int kQkvChunks = 6 * kHeads, kOutChunks = kC / 32, kChunks = kQkvChunks + kOutChunks;   // 30 + 10
+constexpr int kPair = 2 * kChunk, kPairs = kChunks / 2;          // the ring moves PAIRS of chunks: one barrier per 40 MFMAs
 constexpr int kSlots = 3;
-constexpr int kDummyOff = kSlots * kChunk;                       // one KiB for the pieces a wave issues beyond the chunk's 20
-constexpr int kSmem = kDummyOff + 1024;
-constexpr int kNQ = 6;                                           // fragment reads in flight ahead of a chain
+constexpr int kSmem = kSlots * kPair + 8 * kC * 4;                // 120 KiB ring + 10 KiB of start values
+constexpr int kNQ = 6;                                           // fragment reads in flight ahead of the MFMAs
+constexpr int kDmaPerWave = 2 * kKS / 4;                         // 10 one-KiB pieces per ISSUING wave (waves 0..3) and pair
+constexpr int kIniOff = kSlots * kPair;                          // per wave: the pixel's 320 start values (bias + row vector), fp32
 constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // (1 / sqrt(64)) log2(e)
+
+// Diagnostic build only (-DCTRLV_TA_STAMP, tools/ta_bench.py --stamp): per-wave cycle sums of the phases, written to a buffer
+// of their own (TaArgs.stamp; the product build has neither the field's use nor a stamp instruction).
+#ifdef CTRLV_TA_STAMP
+#define TSTAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#define TSTAMP_ADD(acc, t0, t1) acc += (t1) - (t0)
+#else
+#define TSTAMP(v)
+#define TSTAMP_ADD(acc, t0, t1)
+#endif
 
 struct TaArgs {
   const el_t* x; int ldx;                 // LayerNorm output rows [M][ldx]
@@ -49,6 +62,7 @@ struct TaArgs {
   const float* vtab; int vmode, vdiv, vmod, vS, ldv, vrows;     // vrows: table rows the launch can address
   el_t* out; el_t* out_lo; int ldo;
   int B, F, S;
+  unsigned long long* stamp;              // diagnostic build: [workgroup][wave][8] cycle sums (else unused)
 };
 
 __device__ __forceinline__ elx8 pack_half(const f32x16& a, int ks) {          // accumulators 8 ks .. 8 ks + 7 -> one operand
@@ -97,50 +111,83 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.vmode ? (const void*)a.vtab : (const void*)a.wf), 0,
                                                                        a.vmode ? (int)((long)a.vrows * a.ldv * 4) : 0, kFlags);
 
-  // LDS-DMA of chunk `c` (0 .. kChunks - 1, cyclic) into ring slot `g % 3` (g = the workgroup's running chunk count): wave w
-  // takes pieces w, w + 8, w + 16; the last one exists for w < 4 only -- the others issue it out of range (zeros, no memory
-  // traffic) into the dummy KiB, so that every wave has exactly three vector-memory operations per chunk
+  // LDS-DMA of chunk pair `c` (0 .. kPairs - 1, cyclic) into ring slot `g % 3` (g = the workgroup's running pair count), by
+  // waves 0..3 ONLY (pieces w, w + 4, .., w + 36 of the pair's 40).  Waves w and w + 4 share a SIMD and the older one wins the
+  // arbitration for the matrix pipe: stamps showed waves 0..3 running their chains at the full pipe rate and then standing
+  // at the slot barrier for a third of the time, while waves 4..7 -- the critical path -- paid 150 cycles per piece they
+  // issued beside their partners' MFMAs.  The waiting waves issue all of it now.
+  const bool dma_wave = wid < 4;
   auto dma = [&](int c, int g) {
-    char* slot = smem + (g % kSlots) * kChunk;
+    if (!dma_wave) return;
+    char* slot = smem + (g % kSlots) * kPair;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int pi = k * 8 + wid;
-      const bool real = pi < kKS;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(real ? slot + pi * 1024 : smem + kDummyOff), 16,
-                                               real ? (unsigned)(lane * 16) : kOOB, c * kChunk + pi * 1024, 0, 0);
+    for (int k = 0; k < kDmaPerWave; ++k) {
+      const int pi = k * 4 + wid;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(slot + pi * 1024), 16, (unsigned)(lane * 16), c * kPair + pi * 1024, 0, 0);
     }
   };
-  // One chunk = one chain of 20 MFMAs over K = 320 against the wave's x fragments.  W_IS_A: acc = W . x (lane = frame);
-  // else the roles swapped: acc = x . W (lane = channel).  Fragment reads run kNQ MFMAs ahead through rotating registers.
-  int g = 0;                                                     // running chunk count of this workgroup (ring phase)
-  auto slot_begin = [&]() {
-    // every wave's pieces of chunk g have landed (each waited for its own at the end of its previous slot) and every wave is
-    // past its reads of chunk g - 1, whose slot the DMA of chunk g + 2 refills
-    lds_done_barrier();
-    dma((g + 2) % kChunks, g + 2);
+  // own pieces of the pair issued a slot ago have landed (the DMA waves; the others see them through the slot barrier)
+  auto dma_wait = [&]() {
+    if (dma_wave) wait_vmcnt<kDmaPerWave>();
   };
-  auto chain = [&](auto w_is_a, const elx8 (&xb)[kKS], const f32x16& init) {
+  int g = 0;                                                     // running pair count of this workgroup (ring phase)
+#ifdef CTRLV_TA_STAMP
+  unsigned long long c_bar = 0, c_dma = 0, c_chain = 0, c_wait = 0, c_soft = 0, c_epi = 0, c_x = 0;
+  TSTAMP(t_begin);
+#endif
+  auto slot_begin = [&]() {
+    // every wave's pieces of pair g have landed (each waited for its own at the end of its previous slot) and every wave is
+    // past its reads of pair g - 1, whose slot the DMA of pair g + 2 refills
+    TSTAMP(t0);
+    lds_done_barrier();
+    TSTAMP(t1);
+    dma((g + 2) % kPairs, g + 2);
+    TSTAMP(t2);
+    TSTAMP_ADD(c_bar, t0, t1);
+    TSTAMP_ADD(c_dma, t1, t2);
+  };
+  // One pair = 2 x 20 MFMAs over K = 320 against the wave's fragments `xb`: accA takes the pair's first chunk, accB its
+  // second.  W_IS_A: acc = W . x (lane = frame); else the roles swapped: acc = x . W (lane = channel).  Fragment reads run
+  // kNQ MFMAs ahead through rotating registers, straight through the chunk boundary; `mid()` is issued four MFMAs into the
+  // second chunk (the first one's result is complete by then: its rounding / dependent MFMAs ride beside the second chain).
+  auto chain2 = [&](auto w_is_a, const elx8 (&xb)[kKS], f32x16& accA, f32x16& accB, auto&& mid) {
     constexpr bool W_IS_A = decltype(w_is_a)::value;
-    const char* s1 = smem + (g % kSlots) * kChunk + lane * 16;
+    const char* s1 = smem + (g % kSlots) * kPair + lane * 16;
     elx8 wq[kNQ];
 #pragma unroll
     for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
-    f32x16 acc = init;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
-      acc = W_IS_A ? mfma_32x32x16(wq[ks % kNQ], xb[ks], acc) : mfma_32x32x16(xb[ks], wq[ks % kNQ], acc);
-      if (ks + kNQ < kKS) wq[ks % kNQ] = *(const elx8*)(s1 + (ks + kNQ) * 1024);
+    for (int ks = 0; ks < 2 * kKS; ++ks) {
+      if (ks < kKS) accA = W_IS_A ? mfma_32x32x16(wq[ks % kNQ], xb[ks], accA) : mfma_32x32x16(xb[ks], wq[ks % kNQ], accA);
+      else accB = W_IS_A ? mfma_32x32x16(wq[ks % kNQ], xb[ks - kKS], accB) : mfma_32x32x16(xb[ks - kKS], wq[ks % kNQ], accB);
+      if (ks + kNQ < 2 * kKS) wq[ks % kNQ] = *(const elx8*)(s1 + (ks + kNQ) * 1024);
       __builtin_amdgcn_sched_barrier(0);
+      if (ks == kKS + 3) {
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    return acc;
   };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto x_loads = [&](elx8 (&xr)[kKS], long grp) {
+    // x rows as B fragments: K step ks = channels 16 ks + 8 hsel .. + 7 of the lane's row (frames >= F, pixels past the end: zeros)
+    const long pix = grp * 8 + wid;
+    const bool live = pix < npix;
+    const int b = live ? (int)(pix / S) : 0, s = live ? (int)(pix - (long)b * S) : 0;
+    const long row = ((long)b * F + f32_) * S + s;
+    const unsigned xoff = (live && f32_ < F) ? (unsigned)(row * a.ldx * 2) + 16u * hsel : kOOB;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks)
+      xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
+  };
 
-  // ---- prologue: chunks 0 and 1 in flight
+  // ---- prologue: pairs 0 and 1 in flight, the first pixel group's rows requested
   dma(0, 0);
   dma(1, 1);
-  wait_vmcnt<3>();                                               // own pieces of chunk 0 (chunk 1's may still fly)
+  elx8 xr[kKS];
+  x_loads(xr, blockIdx.x);
+  if (dma_wave) wait_vmcnt<kDmaPerWave + kKS>();                 // own pieces of pair 0 (pair 1's and the rows may still fly)
 
   for (long grp = blockIdx.x; grp < ngroups; grp += G) {
     const long pix = grp * 8 + wid;
@@ -148,38 +195,65 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
     const int b = live ? (int)(pix / S) : 0, s = live ? (int)(pix - (long)b * S) : 0;
     const long row = ((long)b * F + f32_) * S + s;               // this lane's frame of this wave's pixel
     const bool ok = live && f32_ < F;
-    // ---- x rows as B fragments: K step ks = channels 16 ks + 8 hsel .. + 7 of the lane's row (frames >= F: zeros)
-    elx8 xr[kKS];
-    {
-      const unsigned xoff = ok ? (unsigned)(row * a.ldx * 2) + 16u * hsel : kOOB;
-#pragma unroll
-      for (int ks = 0; ks < kKS; ++ks)
-        xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
-    }
     elx8 ap[kKS];                                                // attention output, the output projection's B fragments
+    // The output projection's start values (bias + the pixel's row vector; 320 floats per pixel) are requested HERE -- four loads
+    // that return under the first chains -- and parked in this wave's LDS strip.  Requested per block in front of its chain
+    // (first version), they stood behind the previous block's STORES in the in-order vmcnt queue: every out-projection slot
+    // waited for a write acknowledgement before its chain could start (stamps: 6 600 cycles per slot, 27 % of the kernel).
+    u32x4_t ib[2], iv[2];
+    {
+      unsigned vrow = 0;
+      if (a.vmode) {
+        const long m0 = ((long)b * F) * S + s;
+        const long vi = a.vmode == 1 ? (m0 / a.vdiv) % a.vmod : ((m0 / a.vdiv) * a.vS + (m0 % a.vS)) % a.vmod;
+        vrow = (unsigned)(vi * a.ldv * 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c4 = (t * 64 + lane) * 4;                      // floats c4 .. c4 + 3 (t = 1: lanes 0 .. 15)
+        const bool in = c4 < kC;
+        ib[t] = __builtin_amdgcn_raw_buffer_load_b128(rsB, in ? (unsigned)(c4 * 4) : kOOB, 0, 0);
+        iv[t] = __builtin_amdgcn_raw_buffer_load_b128(rsV, (in && a.vmode) ? vrow + (unsigned)(c4 * 4) : kOOB, 0, 0);
+      }
+    }
+    const unsigned ini_lds = (unsigned)(unsigned long)LDS_PTR(smem + kIniOff + wid * (kC * 4));
 #pragma unroll
     for (int h = 0; h < kHeads; ++h) {
       f32x16 sacc = zero16;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         slot_begin();
+        f32x16 qa = zero16, ka = zero16;
         elx8 q0, q1;
-        {
-          const f32x16 qa = chain(std::true_type{}, xr, zero16);
-          q0 = pack_half(qa, 0); q1 = pack_half(qa, 1);           // (packed at once: 8 registers across the k chain, not 16)
+        TSTAMP(t0);
+        chain2(std::true_type{}, xr, qa, ka, [&]() {
+          q0 = pack_half(qa, 0); q1 = pack_half(qa, 1);          // (rounded beside the k chain: 8 registers, not 16)
           pin(q0); pin(q1);
-        }
-        wait_vmcnt<3>();
-        ++g;
-        slot_begin();
-        const f32x16 ka = chain(std::true_type{}, xr, zero16);
-        wait_vmcnt<3>();
+        });
+        TSTAMP(t1);
+        dma_wait();
+        TSTAMP(t2);
+        TSTAMP_ADD(c_chain, t0, t1);
+        TSTAMP_ADD(c_wait, t1, t2);
         ++g;
         // S^T += K_blk Q_blk^T: both operands as they come out of the chains (same channel-to-slot assignment)
         sacc = mfma_32x32x16(pack_half(ka, 0), q0, sacc);
         sacc = mfma_32x32x16(pack_half(ka, 1), q1, sacc);
+        if (h == 0 && blk == 0) {
+          // start values -> the wave's strip, behind the group's first chains (asm: the compiler would put a vmcnt(0) in front
+          // of an LDS store it knows of while LDS-DMA of this wave is in flight, gemm_pp_kernel.h; the strip's last readers
+          // were this wave's own loads of the previous group: LDS operations of one wave execute in order)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f32x4 sum = {__uint_as_float(ib[t][0]) + __uint_as_float(iv[t][0]), __uint_as_float(ib[t][1]) + __uint_as_float(iv[t][1]),
+                               __uint_as_float(ib[t][2]) + __uint_as_float(iv[t][2]), __uint_as_float(ib[t][3]) + __uint_as_float(iv[t][3])};
+            if (t == 0 || lane < 16)
+              asm volatile("ds_write_b128 %0, %1" ::"v"(ini_lds + (unsigned)((t * 64 + lane) * 16)), "v"(sum) : "memory");
+          }
+        }
       }
       // ---- softmax over the keys (accumulator e of lane (query, hsel) = key 8 (e >> 2) + 4 hsel + (e & 3))
+      TSTAMP(ts0);
       float mx = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -198,79 +272,117 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
       const float inv = __builtin_amdgcn_rcpf(swap_sum(rs_));
       elx8 pf0 = pack_half(sacc, 0), pf1 = pack_half(sacc, 1);
       pin(pf0); pin(pf1);
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
+      TSTAMP(ts1);
+      TSTAMP_ADD(c_soft, ts0, ts1);
+      {
         slot_begin();
-        const f32x16 va = chain(std::false_type{}, xr, zero16);   // V^T: lane = channel, frames 8 q + 4 hsel + r
-        wait_vmcnt<3>();
+        f32x16 va = zero16, vb = zero16, oa;                      // V^T blocks: lane = channel, frames 8 q + 4 hsel + r
+        TSTAMP(t0);
+        chain2(std::false_type{}, xr, va, vb, [&]() {
+          oa = mfma_32x32x16(pack_half(va, 0), pf0, zero16);
+          oa = mfma_32x32x16(pack_half(va, 1), pf1, oa);
+        });
+        TSTAMP(t1);
+        dma_wait();
+        TSTAMP(t2);
+        TSTAMP_ADD(c_chain, t0, t1);
+        TSTAMP_ADD(c_wait, t1, t2);
         ++g;
-        f32x16 oa = mfma_32x32x16(pack_half(va, 0), pf0, zero16);
-        oa = mfma_32x32x16(pack_half(va, 1), pf1, oa);
+        f32x16 ob = mfma_32x32x16(pack_half(vb, 0), pf0, zero16);
+        ob = mfma_32x32x16(pack_half(vb, 1), pf1, ob);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oa[e] *= inv;
-        ap[h * 4 + blk * 2] = pack_half(oa, 0);
-        ap[h * 4 + blk * 2 + 1] = pack_half(oa, 1);
-        pin(ap[h * 4 + blk * 2]); pin(ap[h * 4 + blk * 2 + 1]);
+        for (int e = 0; e < 16; ++e) { oa[e] *= inv; ob[e] *= inv; }
+        ap[h * 4] = pack_half(oa, 0); ap[h * 4 + 1] = pack_half(oa, 1);
+        ap[h * 4 + 2] = pack_half(ob, 0); ap[h * 4 + 3] = pack_half(ob, 1);
+        pin(ap[h * 4]); pin(ap[h * 4 + 1]); pin(ap[h * 4 + 2]); pin(ap[h * 4 + 3]);
+        TSTAMP(t3);
+        TSTAMP_ADD(c_soft, t2, t3);
       }
     }
-    // ---- output projection, 10 blocks of 32 channels; lane (frame, hsel) ends with channels 32 nb + 16 hsel .. + 15
-    unsigned vrow = 0;
-    if (a.vmode) {
-      const long m0 = ((long)b * F) * S + s;
-      const long vi = a.vmode == 1 ? (m0 / a.vdiv) % a.vmod : ((m0 / a.vdiv) * a.vS + (m0 % a.vS)) % a.vmod;
-      vrow = (unsigned)(vi * a.ldv * 4);
-    }
+    // the NEXT pixel group's rows: the x registers are free from here on; the loads land under the output projection
+    TSTAMP(tx0);
+    x_loads(xr, grp + G);
+    TSTAMP(tx1);
+    TSTAMP_ADD(c_x, tx0, tx1);
+    // ---- output projection, 10 blocks of 32 channels in pairs; lane (frame, hsel) ends with channels 32 nb + 16 hsel .. + 15
+    const unsigned rbase = ok ? (unsigned)(row * a.ldr1 * 2) + 32u * hsel : kOOB;
+    const unsigned obase = ok ? (unsigned)(row * a.ldo * 2) + 32u * hsel : kOOB;
 #pragma unroll 1
-    for (int nb = 0; nb < kOutChunks; ++nb) {
+    for (int np = 0; np < kOutChunks / 2; ++np) {
       slot_begin();
-      const int c0 = nb * 32 + 16 * hsel;
-      // start values (bias + the pixel's row vector) and the residual rows: requested in front of the chain
-      u32x4_t bi[4], vi[4], rr[2], rl[2];
+      TSTAMP(te0);
+      // start values (bias + the pixel's row vector) and the residual rows of both blocks: requested in front of the chains
+      f32x16 acc[2];
+      u32x4_t rr[2][2], rl[2][2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bi[q] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)((c0 + 4 * q) * 4), 0, 0);
-        vi[q] = __builtin_amdgcn_raw_buffer_load_b128(rsV, a.vmode ? vrow + (unsigned)((c0 + 4 * q) * 4) : kOOB, 0, 0);
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          rr[t][hq] = __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase, (2 * np + t) * 64 + hq * 16, 0);
+          if (LO) rl[t][hq] = __builtin_amdgcn_raw_buffer_load_b128(rsRL, rbase, (2 * np + t) * 64 + hq * 16, 0);
+        }
+      {
+        // the lane's 2 x 16 start values from the strip (channels 32 nb + 16 hsel .. + 15 of the two blocks)
+        f32x4 iq[2][4];
+        const unsigned ia = ini_lds + (unsigned)((2 * np * 32 + 16 * hsel) * 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(iq[t][q]) : "v"(ia), "n"(t * 128 + q * 16) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(iq[0][0]), "+v"(iq[0][1]), "+v"(iq[0][2]), "+v"(iq[0][3]), "+v"(iq[1][0]), "+v"(iq[1][1]), "+v"(iq[1][2]),
+                       "+v"(iq[1][3]));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[t][4 * q] = iq[t][q].x; acc[t][4 * q + 1] = iq[t][q].y; acc[t][4 * q + 2] = iq[t][q].z; acc[t][4 * q + 3] = iq[t][q].w;
+          }
       }
-      const unsigned roff = ok ? (unsigned)(row * a.ldr1 * 2) + (unsigned)(c0 * 2) : kOOB;
-      const unsigned ooff = ok ? (unsigned)(row * a.ldo * 2) + (unsigned)(c0 * 2) : kOOB;
-#pragma unroll
-      for (int hq = 0; hq < 2; ++hq) {
-        rr[hq] = __builtin_amdgcn_raw_buffer_load_b128(rsR, roff, hq * 16, 0);
-        if (LO) rl[hq] = __builtin_amdgcn_raw_buffer_load_b128(rsRL, roff, hq * 16, 0);
-      }
-      f32x16 ini;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ini[4 * q + r] = __uint_as_float(bi[q][r]) + __uint_as_float(vi[q][r]);
-      const f32x16 acc = chain(std::true_type{}, ap, ini);
+      TSTAMP(te1);
+      chain2(std::true_type{}, ap, acc[0], acc[1], []() {});
+      TSTAMP(te2);
+      TSTAMP_ADD(c_epi, te0, te1);
+      TSTAMP_ADD(c_chain, te1, te2);
       ++g;
 #pragma unroll
-      for (int hq = 0; hq < 2; ++hq) {
-        float o[8], rf[8];
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = acc[8 * hq + e];
-        unpack_elx8(make_uint4(rr[hq][0], rr[hq][1], rr[hq][2], rr[hq][3]), rf);
-        {
+        for (int hq = 0; hq < 2; ++hq) {
+          float o[8], rf[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = acc[t][8 * hq + e];
+          unpack_elx8(make_uint4(rr[t][hq][0], rr[t][hq][1], rr[t][hq][2], rr[t][hq][3]), rf);
+          {
 #pragma clang fp contract(off)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = o[e] + rf[e];
+            for (int e = 0; e < 8; ++e) o[e] = o[e] + rf[e];
+          }
+          if (LO) add_lo8(o, make_uint4(rl[t][hq][0], rl[t][hq][1], rl[t][hq][2], rl[t][hq][3]));
+          const uint4 pk = pack_elx8(o);
+          const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+          pp_store_out(pv, rsO, obase, (2 * np + t) * 64 + hq * 16);
+          if (LO) {
+            const uint4 pl = split_lo8(o, pk);
+            const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
+            pp_store_out(pvl, rsOL, obase, (2 * np + t) * 64 + hq * 16);
+          }
         }
-        if (LO) add_lo8(o, make_uint4(rl[hq][0], rl[hq][1], rl[hq][2], rl[hq][3]));
-        const uint4 pk = pack_elx8(o);
-        const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
-        pp_store_out(pv, rsO, ooff, hq * 16);
-        if (LO) {
-          const uint4 pl = split_lo8(o, pk);
-          const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
-          pp_store_out(pvl, rsOL, ooff, hq * 16);
-        }
-      }
-      // (the residual rows were consumed: every older vector-memory operation of this wave -- the DMA of chunk g + 1, issued
-      //  a slot ago, included -- has completed; only this slot's stores and DMA may still be in flight)
+      // (the residual rows were consumed: every older vector-memory operation of this wave -- the DMA of pair g + 1, issued
+      //  a slot ago, and the next group's rows included -- has completed; only this slot's stores and DMA may be in flight)
+      TSTAMP(te3);
+      TSTAMP_ADD(c_epi, te2, te3);
     }
   }
   wait_vmcnt<0>();                                               // the look-ahead DMA: nothing may be in flight at exit
+#ifdef CTRLV_TA_STAMP
+  TSTAMP(t_end);
+  if (lane == 0 && a.stamp) {
+    unsigned long long* o = a.stamp + ((long)blockIdx.x * 8 + wid) * 8;
+    o[0] = t_end - t_begin; o[1] = c_bar; o[2] = c_dma; o[3] = c_chain; o[4] = c_wait; o[5] = c_soft; o[6] = c_epi; o[7] = c_x;
+  }
+#endif
 #endif
 }
 
@@ -346,6 +458,11 @@ static int ta_check(const ctrlv_temporal_fused_desc& d, bool report) {
 #undef TA_REQ
 }
 
+#ifdef CTRLV_TA_STAMP
+static unsigned long long* g_ta_stamp = nullptr;
+extern "C" void ctrlv_temporal_fused_set_stamp(unsigned long long* buf) { g_ta_stamp = buf; }
+#endif
+
 extern "C" int ctrlv_temporal_fused_serves(const ctrlv_temporal_fused_desc* d) {
   return (d && ta_check(*d, false) == CTRLV_OK) ? 1 : 0;
 }
@@ -367,6 +484,10 @@ extern "C" int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* dp, ctrlv_s
   }
   a.out = (el_t*)d.out; a.out_lo = (el_t*)d.out_lo; a.ldo = d.ldo;
   a.B = d.B; a.F = d.F; a.S = d.S;
+  a.stamp = nullptr;
+#ifdef CTRLV_TA_STAMP
+  a.stamp = g_ta_stamp;
+#endif
   const int dev = ctrlv_current_device();
   const long groups = ((long)d.B * d.S + 7) / 8;
   const int num_cu = ctrlv_num_cu(dev);
