@@ -25,7 +25,7 @@
 //     and block straight from / to the accumulator registers (no LDS transpose).
 // Weights: 40 chunks of 20 KiB (32 rows x K = 320, fragment-major: one KiB per MFMA, lane-linear) stream in PAIRS through a
 // 3-slot LDS-DMA ring (120 KiB), issued two pairs ahead; the 8 waves of a workgroup (8 consecutive pixels) walk the pairs in
-// step, one barrier per pair = per 40 MFMAs.  Order: per head (q b0, k b0), (q b1, k b1), (v b0, v b1), then the 10 blocks of
+// two groups half a slot apart (ping-pong: one group's 40 MFMAs beside the other's roundings / softmax / stores / loads).  Order: per head (q b0, k b0), (q b1, k b1), (v b0, v b1), then the 10 blocks of
 // W_o.  The next pixel group's input rows are requested when the last head is done and land under the output projection.
 // Frames are padded to 32 MFMA columns: at F = 25 78 % of the matrix work is real (the attention itself is 5 % of it).
 #include "common.h"
@@ -40,7 +40,7 @@ constexpr int kPair = 2 * kChunk, kPairs = kChunks / 2;          // the ring mov
 constexpr int kSlots = 3;
 constexpr int kSmem = kSlots * kPair + 8 * kC * 4;                // 120 KiB ring + 10 KiB of start values
 constexpr int kNQ = 6;                                           // fragment reads in flight ahead of the MFMAs
-constexpr int kDmaPerWave = 2 * kKS / 4;                         // 10 one-KiB pieces per ISSUING wave (waves 0..3) and pair
+constexpr int kDmaPerWave = 2 * kKS / 8;                         // 5 one-KiB pieces per wave and pair
 constexpr int kIniOff = kSlots * kPair;                          // per wave: the pixel's 320 start values (bias + row vector), fp32
 constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // (1 / sqrt(64)) log2(e)
 
@@ -111,40 +111,63 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.vmode ? (const void*)a.vtab : (const void*)a.wf), 0,
                                                                        a.vmode ? (int)((long)a.vrows * a.ldv * 4) : 0, kFlags);
 
-  // LDS-DMA of chunk pair `c` (0 .. kPairs - 1, cyclic) into ring slot `g % 3` (g = the workgroup's running pair count), by
-  // waves 0..3 ONLY (pieces w, w + 4, .., w + 36 of the pair's 40).  Waves w and w + 4 share a SIMD and the older one wins the
-  // arbitration for the matrix pipe: stamps showed waves 0..3 running their chains at the full pipe rate and then standing
-  // at the slot barrier for a third of the time, while waves 4..7 -- the critical path -- paid 150 cycles per piece they
-  // issued beside their partners' MFMAs.  The waiting waves issue all of it now.
-  const bool dma_wave = wid < 4;
+  // LDS-DMA of chunk pair `c` (0 .. kPairs - 1, cyclic) into ring slot `g % 3` (g = the workgroup's running pair count): wave w
+  // takes pieces w, w + 8, .., w + 32 of the pair's 40
   auto dma = [&](int c, int g) {
-    if (!dma_wave) return;
+#ifdef CTRLV_TA_NODMA       // (diagnostic build: timing without the weight stream; results are garbage)
+    return;
+#endif
     char* slot = smem + (g % kSlots) * kPair;
 #pragma unroll
     for (int k = 0; k < kDmaPerWave; ++k) {
-      const int pi = k * 4 + wid;
+      const int pi = k * 8 + wid;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(slot + pi * 1024), 16, (unsigned)(lane * 16), c * kPair + pi * 1024, 0, 0);
     }
   };
-  // own pieces of the pair issued a slot ago have landed (the DMA waves; the others see them through the slot barrier)
-  auto dma_wait = [&]() {
-    if (dma_wave) wait_vmcnt<kDmaPerWave>();
-  };
-  int g = 0;                                                     // running pair count of this workgroup (ring phase)
+  int g = 0;                                                     // finished slots of this workgroup (ring phase)
 #ifdef CTRLV_TA_STAMP
   unsigned long long c_bar = 0, c_dma = 0, c_chain = 0, c_wait = 0, c_soft = 0, c_epi = 0, c_x = 0;
   TSTAMP(t_begin);
 #endif
-  auto slot_begin = [&]() {
-    // every wave's pieces of pair g have landed (each waited for its own at the end of its previous slot) and every wave is
-    // past its reads of pair g - 1, whose slot the DMA of pair g + 2 refills
+  // PING-PONG (the schedule of gemm_pp_kernel.h): the two waves of a SIMD (w, w + 4) are in different GROUPS and group 1 runs
+  // HALF A SLOT behind group 0.  A slot is  [barrier] X: the pair's 40 MFMAs  [barrier] Y: everything else -- the roundings /
+  // softmax / epilogue stores of the pair, the next pair's loads, the LDS-DMA issue --  and both groups run the SAME program,
+  // group 1 behind one extra barrier: while one group's chain has the matrix pipe to itself (36 cycles per MFMA), the other
+  // does its Y work beside it.  In lockstep (first versions) both waves of a SIMD were in the same phase: the chains shared
+  // the pipe and NOTHING ran beside the Y work -- 47 % of the critical path (stamps, tools/ta_bench.py --stamp).
+  // Ring: pair t is read in X(t) -- group 0 in interval 2t, group 1 in 2t + 1 --; DMA(t + 2) refills the slot of pair t - 1
+  // and is the LAST thing of Y(t) (interval >= 2t + 1 > every read of pair t - 1); a wave waits for its own pieces (and for
+  // everything else it has in flight: vmcnt(0)) at the end of X(t + 1), two barriers in front of the first read of pair t + 2.
+  // (the chain's first kNQ fragments are requested IN FRONT of the slot's barrier -- pair g is complete in LDS one barrier
+  //  earlier, see the ring protocol above -- so the first MFMA does not wait for the LDS behind the barrier)
+  elx8 wq[kNQ];
+  auto chain_prefetch = [&]() {
+    const char* s1 = smem + (g % kSlots) * kPair + lane * 16;
+#pragma unroll
+    for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
+  };
+  auto x_begin = [&]() {
     TSTAMP(t0);
+    chain_prefetch();
     lds_done_barrier();
     TSTAMP(t1);
-    dma((g + 2) % kPairs, g + 2);
-    TSTAMP(t2);
     TSTAMP_ADD(c_bar, t0, t1);
-    TSTAMP_ADD(c_dma, t1, t2);
+  };
+  auto y_begin = [&]() {
+    TSTAMP(t0);
+    wait_vmcnt<0>();
+    TSTAMP(t1);
+    lds_done_barrier();
+    TSTAMP(t2);
+    TSTAMP_ADD(c_wait, t0, t1);
+    TSTAMP_ADD(c_bar, t1, t2);
+  };
+  auto y_end = [&]() {                                           // the slot's DMA issue; g counts finished slots
+    TSTAMP(t0);
+    dma((g + 2) % kPairs, g + 2);
+    ++g;
+    TSTAMP(t1);
+    TSTAMP_ADD(c_dma, t0, t1);
   };
   // One pair = 2 x 20 MFMAs over K = 320 against the wave's fragments `xb`: accA takes the pair's first chunk, accB its
   // second.  W_IS_A: acc = W . x (lane = frame); else the roles swapped: acc = x . W (lane = channel).  Fragment reads run
@@ -153,9 +176,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   auto chain2 = [&](auto w_is_a, const elx8 (&xb)[kKS], f32x16& accA, f32x16& accB, auto&& mid) {
     constexpr bool W_IS_A = decltype(w_is_a)::value;
     const char* s1 = smem + (g % kSlots) * kPair + lane * 16;
-    elx8 wq[kNQ];
-#pragma unroll
-    for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2 * kKS; ++ks) {
@@ -170,15 +190,17 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
     }
   };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto x_loads = [&](elx8 (&xr)[kKS], long grp) {
-    // x rows as B fragments: K step ks = channels 16 ks + 8 hsel .. + 7 of the lane's row (frames >= F, pixels past the end: zeros)
+  // x rows as B fragments: K step ks = channels 16 ks + 8 hsel .. + 7 of the lane's row (frames >= F, pixels past the end: zeros)
+  auto x_offset = [&](long grp) {
     const long pix = grp * 8 + wid;
     const bool live = pix < npix;
     const int b = live ? (int)(pix / S) : 0, s = live ? (int)(pix - (long)b * S) : 0;
     const long row = ((long)b * F + f32_) * S + s;
-    const unsigned xoff = (live && f32_ < F) ? (unsigned)(row * a.ldx * 2) + 16u * hsel : kOOB;
+    return (live && f32_ < F) ? (unsigned)(row * a.ldx * 2) + 16u * hsel : kOOB;
+  };
+  auto x_loads = [&](elx8 (&xr)[kKS], unsigned xoff, int k0, int k1) {
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks)
+    for (int ks = k0; ks < k1; ++ks)
       xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
   };
 
@@ -186,8 +208,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   dma(0, 0);
   dma(1, 1);
   elx8 xr[kKS];
-  x_loads(xr, blockIdx.x);
-  if (dma_wave) wait_vmcnt<kDmaPerWave + kKS>();                 // own pieces of pair 0 (pair 1's and the rows may still fly)
+  x_loads(xr, x_offset(blockIdx.x), 0, kKS);
+  wait_vmcnt<0>();
+  if (wid >= 4) raw_barrier();                                   // group 1 starts half a slot behind
 
   for (long grp = blockIdx.x; grp < ngroups; grp += G) {
     const long pix = grp * 8 + wid;
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
       f32x16 sacc = zero16;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        slot_begin();
+        x_begin();
         f32x16 qa = zero16, ka = zero16;
         elx8 q0, q1;
         TSTAMP(t0);
@@ -231,11 +254,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           pin(q0); pin(q1);
         });
         TSTAMP(t1);
-        dma_wait();
-        TSTAMP(t2);
         TSTAMP_ADD(c_chain, t0, t1);
-        TSTAMP_ADD(c_wait, t1, t2);
-        ++g;
+        y_begin();
+        TSTAMP(t2);
         // S^T += K_blk Q_blk^T: both operands as they come out of the chains (same channel-to-slot assignment)
         sacc = mfma_32x32x16(pack_half(ka, 0), q0, sacc);
         sacc = mfma_32x32x16(pack_half(ka, 1), q1, sacc);
@@ -250,6 +271,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
             if (t == 0 || lane < 16)
               asm volatile("ds_write_b128 %0, %1" ::"v"(ini_lds + (unsigned)((t * 64 + lane) * 16)), "v"(sum) : "memory");
           }
+        }
+        if (blk == 0) {
+          TSTAMP(t3);
+          TSTAMP_ADD(c_soft, t2, t3);
+          y_end();
         }
       }
       // ---- softmax over the keys (accumulator e of lane (query, hsel) = key 8 (e >> 2) + 4 hsel + (e & 3))
@@ -274,8 +300,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
       pin(pf0); pin(pf1);
       TSTAMP(ts1);
       TSTAMP_ADD(c_soft, ts0, ts1);
+      y_end();
       {
-        slot_begin();
+        x_begin();
         f32x16 va = zero16, vb = zero16, oa;                      // V^T blocks: lane = channel, frames 8 q + 4 hsel + r
         TSTAMP(t0);
         chain2(std::false_type{}, xr, va, vb, [&]() {
@@ -283,11 +310,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           oa = mfma_32x32x16(pack_half(va, 1), pf1, oa);
         });
         TSTAMP(t1);
-        dma_wait();
-        TSTAMP(t2);
         TSTAMP_ADD(c_chain, t0, t1);
-        TSTAMP_ADD(c_wait, t1, t2);
-        ++g;
+        y_begin();
+        TSTAMP(t2);
         f32x16 ob = mfma_32x32x16(pack_half(vb, 0), pf0, zero16);
         ob = mfma_32x32x16(pack_half(vb, 1), pf1, ob);
 #pragma unroll
@@ -297,21 +322,20 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
         pin(ap[h * 4]); pin(ap[h * 4 + 1]); pin(ap[h * 4 + 2]); pin(ap[h * 4 + 3]);
         TSTAMP(t3);
         TSTAMP_ADD(c_soft, t2, t3);
+        y_end();
       }
     }
-    // the NEXT pixel group's rows: the x registers are free from here on; the loads land under the output projection
-    TSTAMP(tx0);
-    x_loads(xr, grp + G);
-    TSTAMP(tx1);
-    TSTAMP_ADD(c_x, tx0, tx1);
     // ---- output projection, 10 blocks of 32 channels in pairs; lane (frame, hsel) ends with channels 32 nb + 16 hsel .. + 15
     const unsigned rbase = ok ? (unsigned)(row * a.ldr1 * 2) + 32u * hsel : kOOB;
     const unsigned obase = ok ? (unsigned)(row * a.ldo * 2) + 32u * hsel : kOOB;
-#pragma unroll 1
+    // the NEXT pixel group's rows: the x registers are free from here on; four loads per slot (the CU's vector-memory path
+    // takes 64 B per clock: all twenty in one Y phase made that phase six times as long as the chain beside it)
+    const unsigned xoff_next = x_offset(grp + G);
+#pragma unroll
     for (int np = 0; np < kOutChunks / 2; ++np) {
-      slot_begin();
       TSTAMP(te0);
-      // start values (bias + the pixel's row vector) and the residual rows of both blocks: requested in front of the chains
+      // start values (bias + the pixel's row vector) and the residual rows of both blocks: requested in the Y phase in front of
+      // the chains' barrier
       f32x16 acc[2];
       u32x4_t rr[2][2], rl[2][2];
 #pragma unroll
@@ -341,11 +365,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           }
       }
       TSTAMP(te1);
+      TSTAMP_ADD(c_epi, te0, te1);
+      x_begin();
+      TSTAMP(tc1);
       chain2(std::true_type{}, ap, acc[0], acc[1], []() {});
       TSTAMP(te2);
-      TSTAMP_ADD(c_epi, te0, te1);
-      TSTAMP_ADD(c_chain, te1, te2);
-      ++g;
+      TSTAMP_ADD(c_chain, tc1, te2);
+      y_begin();
+      TSTAMP(te2b);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -362,19 +389,26 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           if (LO) add_lo8(o, make_uint4(rl[t][hq][0], rl[t][hq][1], rl[t][hq][2], rl[t][hq][3]));
           const uint4 pk = pack_elx8(o);
           const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
+#ifndef CTRLV_TA_NOSTORE
           pp_store_out(pv, rsO, obase, (2 * np + t) * 64 + hq * 16);
+#else
+          asm volatile("" ::"v"(pv));
+#endif
           if (LO) {
             const uint4 pl = split_lo8(o, pk);
             const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
             pp_store_out(pvl, rsOL, obase, (2 * np + t) * 64 + hq * 16);
           }
         }
-      // (the residual rows were consumed: every older vector-memory operation of this wave -- the DMA of pair g + 1, issued
-      //  a slot ago, and the next group's rows included -- has completed; only this slot's stores and DMA may be in flight)
       TSTAMP(te3);
-      TSTAMP_ADD(c_epi, te2, te3);
+      TSTAMP_ADD(c_epi, te2b, te3);
+      x_loads(xr, xoff_next, np * 4, np * 4 + 4);
+      TSTAMP(te4);
+      TSTAMP_ADD(c_x, te3, te4);
+      y_end();
     }
   }
+  if (wid < 4) raw_barrier();                                    // group 0's closing barrier (pairs with group 1's last one)
   wait_vmcnt<0>();                                               // the look-ahead DMA: nothing may be in flight at exit
 #ifdef CTRLV_TA_STAMP
   TSTAMP(t_end);

@@ -54,7 +54,7 @@ def timeit(name, fn):
     print(f"{name:14s} {ms * 1e3:8.1f} us   {fl / ms / 1e9:6.0f} TFLOP/s", flush=True)
 
 
-if "--stamp" not in sys.argv:
+if "--stamp" not in sys.argv and "--variant" not in sys.argv:
     for name, fn in (("three launches", three), ("fused", fused), ("three launches", three), ("fused", fused)):
         timeit(name, fn)
 else:
@@ -65,11 +65,23 @@ else:
     for src in ("temporal_fused.hip", "abi.hip"):
         o = os.path.join(ROOT, "gpurun_out", src + ".tastamp.o")
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-                                       "-DCTRLV_TA_STAMP", "-c", os.path.join(ge.CSRC, src), "-o", o]))
+                                       *(["-DCTRLV_TA_STAMP"] if "--stamp" in sys.argv else []), *os.environ.get("TA_FLAGS", "").split(),
+                                       "-c", os.path.join(ge.CSRC, src), "-o", o]))
         objs.append(o)
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     lib = ctypes.CDLL(out)
+    lib.ctrlv_temporal_fused.restype = ctypes.c_int
+    if "--variant" in sys.argv:          # an unstamped variant build (TA_FLAGS), timed like the product kernel
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i, b in enumerate(sets):
+            b["desc"] = ops._temporal_fused_desc(b["x"], wf, b["out"], B, F, S, R1=b["r1"], **kw)
+
+        def var(b):
+            lib.ctrlv_temporal_fused(ctypes.byref(b["desc"]), st)
+        timeit("variant " + os.environ.get("TA_FLAGS", ""), var)
+        timeit("variant " + os.environ.get("TA_FLAGS", ""), var)
+        sys.exit(0)
     stamps = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=DEV)
     lib.ctrlv_temporal_fused_set_stamp(ctypes.c_void_p(stamps.data_ptr()))
     b = sets[0]
@@ -79,7 +91,12 @@ else:
     for _ in range(2):
         rc = lib.ctrlv_temporal_fused(ctypes.byref(d), st)
     torch.cuda.synchronize()
-    print("rc", rc)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(4):
+        lib.ctrlv_temporal_fused(ctypes.byref(d), st)
+    ev1.record(); torch.cuda.synchronize()
+    print("rc", rc, f"stamped launch {ev0.elapsed_time(ev1) / 4 * 1e3:.0f} us  flags {os.environ.get('TA_FLAGS', '')}")
     s = stamps.view(-1, 8, 8).double()
     s = s[s[:, 0, 0] > 0]
     rounds = (B * S + 7) // 8 / s.shape[0]
