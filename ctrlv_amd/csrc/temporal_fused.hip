@@ -138,18 +138,24 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   // Ring: pair t is read in X(t) -- group 0 in interval 2t, group 1 in 2t + 1 --; DMA(t + 2) refills the slot of pair t - 1
   // and is the LAST thing of Y(t) (interval >= 2t + 1 > every read of pair t - 1); a wave waits for its own pieces (and for
   // everything else it has in flight: vmcnt(0)) at the end of X(t + 1), two barriers in front of the first read of pair t + 2.
-  // (the chain's first kNQ fragments are requested IN FRONT of the slot's barrier -- pair g is complete in LDS one barrier
-  //  earlier, see the ring protocol above -- so the first MFMA does not wait for the LDS behind the barrier)
+  // (the chain's first kNQ fragments: requested in front of the slot's barrier where pair g is known to be complete by then
+  //  -- see x_begin -- so that the first MFMA does not wait for the LDS behind the barrier)
   elx8 wq[kNQ];
   auto chain_prefetch = [&]() {
     const char* s1 = smem + (g % kSlots) * kPair + lane * 16;
 #pragma unroll
     for (int i = 0; i < kNQ; ++i) wq[i] = *(const elx8*)(s1 + i * 1024);
   };
+  // (group 1 only: its X(t) follows the barrier that ends interval 2t, and every wave has waited for its pieces of pair t by
+  //  the barrier that ends interval 2t - 1 -- a whole interval earlier.  Group 0's X(t) opens interval 2t itself: group 1's
+  //  pieces are only guaranteed behind THAT barrier, so group 0 reads after it.  Reading early in group 0 was a race: seen as
+  //  run-to-run differences at the full 72 x 128 size, tests/test_fullsize_gpu.py.)
+  const bool early_frags = wid >= 4;
   auto x_begin = [&]() {
     TSTAMP(t0);
-    chain_prefetch();
+    if (early_frags) chain_prefetch();
     lds_done_barrier();
+    if (!early_frags) chain_prefetch();
     TSTAMP(t1);
     TSTAMP_ADD(c_bar, t0, t1);
   };
