@@ -497,7 +497,8 @@ def main():
                 alias = {"attention_spatial": ["attn_spatial_kernel"], "attention_temporal": ["attn_temporal_kernel"],
                          "groupnorm": ["gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel"], "layernorm": ["ln_kernel"],
                          "residual_add": ["axpby_kernel"], "gemm_linear": ["gemm_linear"],
-                         "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"]}
+                         "gemm_conv3x3": ["gemm_conv3x3"], "gemm_conv_temporal": ["gemm_conv_temporal"],
+                         "gemm_temporal_block": ["temporal_fused_kernel"]}
                 for fam, keys in alias.items():
                     keys = [k for k in keys if k in raw]
                     if keys:
@@ -533,7 +534,7 @@ def main():
                              f"{raw.get('_build_id', 'unstamped')} (bf16, default shape), running {_lib.build_id(lib)} "
                              f"({args.dtype}): mfma_busy / clock_ghz = null")
             else:
-                for fam in ("gemm_linear", "gemm_conv3x3", "gemm_conv_temporal", "attention_spatial"):
+                for fam in ("gemm_linear", "gemm_conv3x3", "gemm_conv_temporal", "attention_spatial", "gemm_temporal_block"):
                     parts = {k.split(".", 1)[1]: v for k, v in raw.items() if k.startswith(fam + ".") and isinstance(v, dict)}
                     if parts:
                         busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in parts.values())

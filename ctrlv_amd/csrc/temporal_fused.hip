@@ -87,6 +87,7 @@ template <bool LO>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  CTRLV_CLOCK_BEGIN();
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int f32_ = lane & 31, hsel = lane >> 5;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   }
   if (wid < 4) raw_barrier();                                    // group 0's closing barrier (pairs with group 1's last one)
   wait_vmcnt<0>();                                               // the look-ahead DMA: nothing may be in flight at exit
+  CTRLV_CLOCK_END();
 #ifdef CTRLV_TA_STAMP
   TSTAMP(t_end);
   if (lane == 0 && a.stamp) {
@@ -454,6 +456,8 @@ __global__ void temporal_pack_kernel(const el_t* __restrict__ wqkv, int ld_qkv, 
 }
 
 }  // namespace
+
+CTRLV_CLOCK_READER(temporal_fused)
 
 extern "C" size_t ctrlv_temporal_fused_weight_bytes(void) { return (size_t)kChunks * kChunk; }
 

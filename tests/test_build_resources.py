@@ -98,3 +98,35 @@ def test_pingpong_gemm_register_budget():
         # 26 + two raw-output GEGLU variants + six 256x128 conv variants + nine row-halo 3x3 variants + four with producer-side
         # GroupNorm statistics (3x3 row-halo {V}, {R1}; temporal {V}, {R1}) + six K-slice variants (linear / 3x3 / temporal x 256 / 320 wide)
         assert n_kernels == 53
+
+
+def test_temporal_fused_register_budget():
+    """The fused temporal self-attention block (csrc/temporal_fused.hip) keeps a pixel's 32 x 320 input rows (80 registers) and
+    the attention output (80) in registers beside the chains' accumulators: 240-256 VGPRs at two waves per SIMD.  The plain
+    kernel must not spill at all (a spilled fragment is a scratch reload -- and a vmcnt(0) that drains the LDS-DMA ring -- inside
+    a chain); the split-trunk instantiation of the fp16 library (two more residual / output planes in the epilogue) may park a
+    few epilogue values."""
+    procs = []
+    with tempfile.TemporaryDirectory() as td:
+        for defs in ([], ["-DCTRLV_ELEM_F16=1"]):
+            asm = os.path.join(td, "tf" + ("16" if defs else "") + ".s")
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                   "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", *defs, os.path.join(CSRC, "temporal_fused.hip"), "-o", asm]
+            procs.append((defs, asm, subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)))
+        for defs, asm, p in procs:
+            err = p.communicate()[1]
+            assert p.returncode == 0, err[-2000:]
+            names = re.findall(r"Function Name: (\S+)", err)
+            vg = [int(x) for x in re.findall(r" VGPRs: (\d+)", err)]
+            sp = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", err)]
+            occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", err)]
+            kern = [(n, v, s, o) for n, v, s, o in zip(names, vg, sp, occ) if "temporal_fused_kernel" in n]
+            assert len(kern) == (2 if defs else 1), (defs, names)
+            for n, v, s, o in kern:
+                lo = "ILb1E" in n                      # temporal_fused_kernel<true>: split trunk planes
+                assert v <= 256 and o >= 2, (n, v, o)
+                assert s <= (32 if lo else 0), (n, s)
+            # no scratch access between the MFMAs of a chain in the plain kernel
+            text = open(asm).read()
+            body = [k for k in re.split(r"\n(?=_ZN\S*temporal_fused_kernelILb0E\S*:)", text)[1:]][0].split("s_endpgm")[0]
+            assert "v_mfma" in body and "scratch_" not in body

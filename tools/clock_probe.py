@@ -85,6 +85,16 @@ def main():
     b2 = torch.randn(320, generator=g, device=dev)
     probes.append(("ff_fused C=320 +R1 @72x128", "ff_fused", lambda: ops.ff_fused(xff, w1f, w2f, off, bias=b2, R1=r1ff),
                    2.0 * M0 * 320 * (2560 + 1280)))
+    # fused temporal self-attention block at C = 320 (2 clips x 25 frames x 72 x 128)
+    with packing.element_dtype(torch.bfloat16):
+        wqkv_t = packing.pack_qkv(*(torch.randn(320, 320) / 320 ** 0.5 for _ in range(3))).to(dev)
+        wo_t = packing.pack_linear(torch.randn(320, 320) / 320 ** 0.5).to(dev)
+    wf_t = ops.temporal_fused_pack(wqkv_t, wo_t)
+    Mt = 2 * 25 * 9216
+    xt, rt, ot = rnd(Mt, 320), rnd(Mt, 320), torch.empty(Mt, 320, dtype=torch.bfloat16, device=dev)
+    probes.append(("temporal_fused C=320 +R1 @72x128", "temporal_fused",
+                   lambda: ops.temporal_fused(xt, wf_t, ot, 2, 25, 9216, bias=b2, R1=rt),
+                   2.0 * Mt * 320 * 1280 + 4.0 * 2 * 9216 * 5 * 25 * 25 * 64))
     # spatial attention at S = 9216 (the 64-rows-per-wave kernel), pre-scaled q
     qkv, ao = rnd(10 * 9216, 960), torch.empty(10 * 9216, 320, dtype=torch.bfloat16, device=dev)
     probes.append(("attn_spatial64 S=9216, 10 images x 5 heads", "attention",

@@ -32,6 +32,8 @@ def family(name):
         return {"0": "gemm_linear.w16", "1": "gemm_conv3x3.w16", "2": "gemm_conv_temporal.w16"}[m.group(1)]
     if "ff_fused_kernel" in name:
         return "gemm_linear.ff_fused"
+    if "temporal_fused_kernel" in name:
+        return "gemm_temporal_block.fused"
     if "attn_spatial64" in name:
         return "attention_spatial.rows64"
     if "attn_spatial" in name:

@@ -26,7 +26,7 @@ def family(name):
         return "ln_kernel"
     if "attn_spatial" in name:      # 32- and 64-rows-per-wave variants
         return "attn_spatial_kernel"
-    for k in ("gemm_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel",
+    for k in ("gemm_kernel", "temporal_fused_kernel", "attn_temporal_kernel", "gn_stats_kernel", "gn_finalize_kernel", "gn_apply_kernel",
               "ln_kernel", "axpby_kernel", "im2col3x3_kernel", "cfg_euler_kernel"):
         if k in name:
             return k
