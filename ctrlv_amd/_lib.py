@@ -65,6 +65,7 @@ class TemporalFusedDesc(ctypes.Structure):
         ("V", c_void_p), ("vmode", c_int), ("vdiv", c_int), ("vmod", c_int), ("vS", c_int), ("ldv", c_int),
         ("out", c_void_p), ("out_lo", c_void_p), ("ldo", c_int),
         ("B", c_int), ("F", c_int), ("S", c_int), ("C", c_int),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
     ]
 
 

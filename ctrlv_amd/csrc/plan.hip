@@ -799,25 +799,33 @@ int run_tr(Ctx& c, const Transformer& t, const Trk& x, int H, int W, Trk* out_) 
     d.V = emb; d.ldv = C; d.vmode = 1; d.vdiv = S; d.vmod = F;
     TRY(ln_ff(c, t.t_ffin, t.t_lnin, h2, emb, S, F, C, tt, dp, d, C, &u));
   }
-  TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
   const Trk g1 = c.trunk(M, C);
   {
-    // attn1 over the frames + residual + the one-key cross-attention vector (attn2): at C = 320 ONE launch -- q|k|v and the
-    // attention output never reach HBM (temporal_fused.hip; CTRLV_TEMPORAL_FUSED=0: the three launches)
+    // norm1 + attn1 over the frames + residual + the one-key cross-attention vector (attn2): at C = 320 ONE launch -- the
+    // normalised rows, q|k|v and the attention output never reach HBM (temporal_fused.hip; CTRLV_TEMPORAL_FUSED=0: the four
+    // launches).  With split trunk planes the LayerNorm stays a launch of its own (it reads hi + lo).
     ctrlv_temporal_fused_desc fd;
     memset(&fd, 0, sizeof(fd));
     fd.x = tt; fd.ldx = C; fd.wf = t.t_wf; fd.bias = t.t_o.b;
+    const bool fuse = ctrlv_debug().temporal_fused && t.t_wf;
+    bool ln_in = fuse && !g0.lo;
+    if (ln_in) { fd.x = g0.hi; fd.ln_gamma = t.t_ln1.g; fd.ln_beta = t.t_ln1.b; fd.ln_eps = 1e-5f; }
     fd.R1 = g0.hi; fd.R1_lo = g0.lo; fd.ldr1 = C;
     fd.V = c.xattn + t.xattn_off[1]; fd.ldv = c.ldx; fd.vdiv = F * S; fd.vS = 1; fd.vmod = 1 << 30;
     if (c.quirk && B > 1) { fd.vmode = 2; fd.vS = S; fd.vmod = B; }   // diffusers 0.27.2: context rows (s, b), tokens (b, s)
     else fd.vmode = 1;
     fd.out = g1.hi; fd.out_lo = g1.lo; fd.ldo = C;
     fd.B = B; fd.F = F; fd.S = S; fd.C = C;
-    if (ctrlv_debug().temporal_fused && t.t_wf && ctrlv_temporal_fused_serves(&fd)) {
+    const bool fused = fuse && ctrlv_temporal_fused_serves(&fd);
+    if (!fused || !ln_in) {
+      if (ln_in) { ln_in = false; fd.x = tt; fd.ln_gamma = fd.ln_beta = nullptr; }
+      TRY(layernorm(c, g0, (int)M, C, t.t_ln1, tt));
+    }
+    if (fused) {
       if (!c.dry) {
         if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
         ProfScope ps(c, CTRLV_FAM_GEMM_TEMPORAL_BLOCK, 2.0 * M * C * 4.0 * C + 4.0 * B * S * (C / 64) * (double)F * F * 64,
-                     (double)M * C * 2 * (3 + (g0.lo ? 1 : 0) + (g1.lo ? 1 : 0)), (int)M, 4 * C, C);
+                     (double)M * C * 2 * ((ln_in ? 2 : 3) + (g0.lo ? 1 : 0) + (g1.lo ? 1 : 0)), (int)M, 4 * C, C, ln_in ? 1 : 0);
         TRY(ctrlv_temporal_fused(&fd, c.st));
       }
     } else {

@@ -38,10 +38,11 @@ constexpr int kChunk = kKS * 1024;                               // 20 KiB: 32 w
 constexpr int kQkvChunks = 6 * kHeads, kOutChunks = kC / 32, kChunks = kQkvChunks + kOutChunks;   // 30 + 10
 constexpr int kPair = 2 * kChunk, kPairs = kChunks / 2;          // the ring moves PAIRS of chunks: one barrier per 40 MFMAs
 constexpr int kSlots = 3;
-constexpr int kSmem = kSlots * kPair + 8 * kC * 4;                // 120 KiB ring + 10 KiB of start values
+constexpr int kIniOff = kSlots * kPair;                          // per wave: the pixel's 320 start values (bias + row vector), fp32
+constexpr int kLnOff = kIniOff + 8 * kC * 4;                      // LayerNorm prologue: gamma | beta (fp32)
+constexpr int kSmem = kLnOff + 2 * kC * 4;                        // 120 KiB ring + 10 KiB of start values + 2.5 KiB
 constexpr int kNQ = 6;                                           // fragment reads in flight ahead of the MFMAs
 constexpr int kDmaPerWave = 2 * kKS / 8;                         // 5 one-KiB pieces per wave and pair
-constexpr int kIniOff = kSlots * kPair;                          // per wave: the pixel's 320 start values (bias + row vector), fp32
 constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // (1 / sqrt(64)) log2(e)
 
 // Diagnostic build only (-DCTRLV_TA_STAMP, tools/ta_bench.py --stamp): per-wave cycle sums of the phases, written to a buffer
@@ -62,6 +63,7 @@ struct TaArgs {
   const float* vtab; int vmode, vdiv, vmod, vS, ldv, vrows;     // vrows: table rows the launch can address
   el_t* out; el_t* out_lo; int ldo;
   int B, F, S;
+  const float* ln_g; const float* ln_b; float ln_eps;     // LN: x holds the RAW rows, normalised in the kernel (else null)
   unsigned long long* stamp;              // diagnostic build: [workgroup][wave][8] cycle sums (else unused)
 };
 
@@ -83,7 +85,11 @@ __device__ __forceinline__ float swap_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool LO>
+// LN: the block's LayerNorm (norm1 of TemporalBasicTransformerBlock) in the kernel -- x holds the raw rows, a row's 320 values
+// sit in its two lanes (hsel = 0 / 1, 160 each: the B fragments as loaded), the two-pass arithmetic of ln_rows_kernel
+// (norm.hip: mean, then sum (x - mean)^2; o = (x - mean) rstd gamma + beta, rounded to the element type like that kernel's
+// output) runs on them in the Y phase in front of a pixel group's first chain, one half-wave exchange per sum.
+template <bool LO, bool LN>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -211,6 +217,66 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
       xr[ks] = __builtin_bit_cast(elx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff, ks * 32, 0));
   };
 
+  const unsigned ln_lds = (unsigned)(unsigned long)LDS_PTR(smem + kLnOff);
+  if constexpr (LN) {
+    for (int i = threadIdx.x; i < kC; i += 512) {
+      *(float*)(smem + kLnOff + i * 4) = a.ln_g[i];
+      *(float*)(smem + kLnOff + (kC + i) * 4) = a.ln_b[i];
+    }
+    __syncthreads();                                             // (before any LDS-DMA is in flight)
+  }
+  auto layer_norm = [&](elx8 (&xr)[kKS], bool keep) {
+    float sm = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      float f[8];
+      unpack_elx8(__builtin_bit_cast(uint4, xr[ks]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += f[e];
+      __builtin_amdgcn_sched_barrier(0);                         // (one K step's eight values alive at a time)
+    }
+    float mean = swap_sum(sm) * (1.0f / kC);
+    asm volatile("" : "+v"(mean));
+    float sq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      // (opaque between the passes: the compiler otherwise keeps the 160 unpacked values of the pass before alive -- 345
+      //  spilled registers -- instead of unpacking again)
+      pin(xr[ks]);
+      float f[8];
+      unpack_elx8(__builtin_bit_cast(uint4, xr[ks]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dl = f[e] - mean; sq += dl * dl; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float rstd = rsqrtf(swap_sum(sq) * (1.0f / kC) + a.ln_eps);
+    asm volatile("" : "+v"(rstd));
+    const unsigned ga = ln_lds + 32u * hsel;                     // gamma of channels 16 ks + 8 hsel .. + 7 at ga + 64 ks
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      // (asm reads with their own wait: the compiler puts a vmcnt(0) in front of an LDS read it knows of while LDS-DMA of this
+      //  wave is in flight, gemm_pp_kernel.h)
+      f32x4 g0, g1, b0, b1;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g0) : "v"(ga), "n"(ks * 64) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g1) : "v"(ga), "n"(ks * 64 + 16) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(ga), "n"(kC * 4 + ks * 64) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(ga), "n"(kC * 4 + ks * 64 + 16) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      pin(xr[ks]);
+      float f[8], o[8];
+      unpack_elx8(__builtin_bit_cast(uint4, xr[ks]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
+      uint4 pk = pack_elx8(o);
+      if (!keep) pk = make_uint4(0, 0, 0, 0);                    // frames >= F / pixels past the end stay zero rows
+      xr[ks] = __builtin_bit_cast(elx8, pk);
+      pin(xr[ks]);                                               // (computed HERE, not sunk to the chain that uses it)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   // ---- prologue: pairs 0 and 1 in flight, the first pixel group's rows requested
   dma(0, 0);
   dma(1, 1);
@@ -226,6 +292,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
     const long row = ((long)b * F + f32_) * S + s;               // this lane's frame of this wave's pixel
     const bool ok = live && f32_ < F;
     elx8 ap[kKS];                                                // attention output, the output projection's B fragments
+    unsigned xoff_next = kOOB;
+    if constexpr (LN) layer_norm(xr, ok);
     // The output projection's start values (bias + the pixel's row vector; 320 floats per pixel) are requested HERE -- four loads
     // that return under the first chains -- and parked in this wave's LDS strip.  Requested per block in front of its chain
     // (first version), they stood behind the previous block's STORES in the in-order vmcnt queue: every out-projection slot
@@ -329,15 +397,19 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
         pin(ap[h * 4]); pin(ap[h * 4 + 1]); pin(ap[h * 4 + 2]); pin(ap[h * 4 + 3]);
         TSTAMP(t3);
         TSTAMP_ADD(c_soft, t2, t3);
+        if (h == kHeads - 1) {
+          // the NEXT pixel group's rows: the x registers are free from here on -- four loads per slot over this slot and the
+          // first four of the output projection (the CU's vector-memory path takes 64 B per clock: all twenty in one Y phase
+          // made that phase six times as long as the chain beside it), so that they have landed a slot before the next group
+          xoff_next = x_offset(grp + G);
+          x_loads(xr, xoff_next, 0, 4);
+        }
         y_end();
       }
     }
     // ---- output projection, 10 blocks of 32 channels in pairs; lane (frame, hsel) ends with channels 32 nb + 16 hsel .. + 15
     const unsigned rbase = ok ? (unsigned)(row * a.ldr1 * 2) + 32u * hsel : kOOB;
     const unsigned obase = ok ? (unsigned)(row * a.ldo * 2) + 32u * hsel : kOOB;
-    // the NEXT pixel group's rows: the x registers are free from here on; four loads per slot (the CU's vector-memory path
-    // takes 64 B per clock: all twenty in one Y phase made that phase six times as long as the chain beside it)
-    const unsigned xoff_next = x_offset(grp + G);
 #pragma unroll
     for (int np = 0; np < kOutChunks / 2; ++np) {
       TSTAMP(te0);
@@ -409,7 +481,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
         }
       TSTAMP(te3);
       TSTAMP_ADD(c_epi, te2b, te3);
-      x_loads(xr, xoff_next, np * 4, np * 4 + 4);
+      if (np < kOutChunks / 2 - 1) x_loads(xr, xoff_next, np * 4 + 4, np * 4 + 8);
       TSTAMP(te4);
       TSTAMP_ADD(c_x, te3, te4);
       y_end();
@@ -490,6 +562,9 @@ static int ta_check(const ctrlv_temporal_fused_desc& d, bool report) {
          "ctrlv_temporal_fused: operands beyond 32-bit byte offsets");
   TA_REQ((!d.R1_lo || d.R1) && ((!d.R1_lo && !d.out_lo) || CTRLV_ELEM_DTYPE == 1), CTRLV_E_BAD_ARG,
          "ctrlv_temporal_fused: split trunk planes need R1 and the fp16 element library");
+  TA_REQ((d.ln_gamma == nullptr) == (d.ln_beta == nullptr), CTRLV_E_BAD_ARG, "ctrlv_temporal_fused: LayerNorm needs gamma and beta");
+  TA_REQ(!d.ln_gamma || (!d.R1_lo && !d.out_lo), CTRLV_E_BAD_ARG,
+         "ctrlv_temporal_fused: the in-kernel LayerNorm reads plain rows (split trunk: run ctrlv_layernorm_split in front)");
   if (d.vmode) {
     // the row vector must be constant over a pixel's frames: one table row per clip (vmode 1) or per (pixel, clip) (vmode 2)
     TA_REQ((d.vmode == 1 || d.vmode == 2) && d.V && d.vmod > 0 && d.ldv >= kC && d.ldv % 4 == 0 && d.vdiv == d.F * d.S &&
@@ -528,6 +603,7 @@ extern "C" int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* dp, ctrlv_s
   }
   a.out = (el_t*)d.out; a.out_lo = (el_t*)d.out_lo; a.ldo = d.ldo;
   a.B = d.B; a.F = d.F; a.S = d.S;
+  a.ln_g = d.ln_gamma; a.ln_b = d.ln_beta; a.ln_eps = d.ln_eps;
   a.stamp = nullptr;
 #ifdef CTRLV_TA_STAMP
   a.stamp = g_ta_stamp;
@@ -541,21 +617,24 @@ extern "C" int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* dp, ctrlv_s
     grid = (groups + rounds - 1) / rounds;
   }
   const bool lo = d.R1_lo || d.out_lo;
-  static bool attr_set[2][CTRLV_MAX_DEVICES] = {};
-#define TA_LAUNCH(LOV)                                                                                                  \
+  const bool ln = d.ln_gamma != nullptr;
+  static bool attr_set[2][2][CTRLV_MAX_DEVICES] = {};
+#define TA_LAUNCH(LOV, LNV)                                                                                             \
   do {                                                                                                                  \
-    auto kfn = temporal_fused_kernel<LOV>;                                                                              \
-    if (!attr_set[LOV][dev]) {                                                                                          \
+    auto kfn = temporal_fused_kernel<LOV, LNV>;                                                                         \
+    if (!attr_set[LOV][LNV][dev]) {                                                                                     \
       CTRLV_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));          \
-      attr_set[LOV][dev] = true;                                                                                        \
+      attr_set[LOV][LNV][dev] = true;                                                                                   \
     }                                                                                                                   \
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), kSmem, (hipStream_t)stream, a);                            \
   } while (0)
 #ifdef CTRLV_ELEM_F16
-  if (lo) TA_LAUNCH(true); else TA_LAUNCH(false);
+  if (lo) TA_LAUNCH(true, false);          // (split planes: the LayerNorm stays a launch of its own -- ta_check)
+  else if (ln) TA_LAUNCH(false, true);
+  else TA_LAUNCH(false, false);
 #else
   (void)lo;
-  TA_LAUNCH(false);
+  if (ln) TA_LAUNCH(false, true); else TA_LAUNCH(false, false);
 #endif
 #undef TA_LAUNCH
   CTRLV_LAUNCH_CHECK();

@@ -383,15 +383,16 @@ class TransformerSpatioTemporalModel(nn.Module):
         g0 = h1                                         # h1 is dead
         _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, rows_per_image=S, R1=h2, V=emb, vmode=1, vdiv=S,
                vmod=F)
-        ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
         g1 = ws.alloc((M, C))
         xt_vec = ctx.xattn[:, self.xattn_off[1]:]
         # diffusers 0.27.2: time_context rows ordered (s, b), tokens ordered (b, s)
         vkw = dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if (ctx.quirk and B > 1) else dict(vmode=1, vdiv=F * S)
-        if _TEMPORAL_FUSED and ops.temporal_fused_serves(t, pk["t_wf"], g1, B, F, S, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw):
-            # attn1 over the frames + residual + the cross-attention vector in ONE launch (csrc/plan.hip run_tr)
-            ops.temporal_fused(t, pk["t_wf"], g1, B, F, S, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw)
+        fkw = dict(bias=pk["t_o"][1], R1=g0, V=xt_vec, ln=(pk["t_ln1"][0], pk["t_ln1"][1], 1e-5), **vkw)
+        if _TEMPORAL_FUSED and ops.temporal_fused_serves(g0, pk["t_wf"], g1, B, F, S, **fkw):
+            # norm1 + attn1 over the frames + residual + the cross-attention vector in ONE launch (csrc/plan.hip run_tr)
+            ops.temporal_fused(g0, pk["t_wf"], g1, B, F, S, **fkw)
         else:
+            ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
             ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
             ops.attention_temporal(qkv, a, B, F, S, C)
             ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw)

@@ -424,7 +424,7 @@ def temporal_fused_pack(wqkv_packed, wo_packed):
 
 
 def _temporal_fused_desc(x, wf, out, B, F, S, bias=None, R1=None, V=None, vmode=0, vdiv=1, vmod=1 << 30, vS=1, R1_lo=None,
-                         out_lo=None):
+                         out_lo=None, ln=None):
     from ._lib import TemporalFusedDesc
     d = TemporalFusedDesc()
     d.x, d.ldx, d.wf, d.bias = _p(x), x.stride(0), _p(wf), _p(bias)
@@ -433,6 +433,8 @@ def _temporal_fused_desc(x, wf, out, B, F, S, bias=None, R1=None, V=None, vmode=
     d.ldv = V.stride(0) if V is not None else 0
     d.out, d.out_lo, d.ldo = _p(out), _p(out_lo), out.stride(0)
     d.B, d.F, d.S, d.C = B, F, S, x.shape[1]
+    if ln is not None:                       # (gamma, beta, eps): x holds the raw rows, the kernel normalises them
+        d.ln_gamma, d.ln_beta, d.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
     return d
 
 
@@ -448,7 +450,8 @@ def temporal_fused(x, wf, out, B, F, S, **kw):
     ev = _prof.begin()
     check(_L(x).ctrlv_temporal_fused(ctypes.byref(d), _stream()), "ctrlv_temporal_fused")
     M, C = B * F * S, x.shape[1]
-    _prof.end(ev, "gemm_temporal_block", 2.0 * M * C * 4 * C + 4.0 * B * S * (C // 64) * F * F * 64, 2.0 * 3 * M * C)
+    _prof.end(ev, "gemm_temporal_block", 2.0 * M * C * 4 * C + 4.0 * B * S * (C // 64) * F * F * 64,
+              2.0 * (2 if kw.get("ln") is not None else 3) * M * C)
     return out
 
 

@@ -208,7 +208,8 @@ int ctrlv_ff_fused_serves(const ctrlv_gemm_desc* out_desc, int ldx);
  * over the F <= 32 frames of every pixel -- `TemporalBasicTransformerBlock.attn1` with its residual and the one-key
  * cross-attention vector [DIFF-0.27.2; instantiated by get_down_block / UNetMidBlockSpatioTemporal,
  * src/ctrlv/models/controlnet.py:157-170,186-192] in ONE launch instead of ctrlv_gemm (q|k|v) + ctrlv_attention_temporal +
- * ctrlv_gemm (to_out): neither the 3C-wide q|k|v tensor nor the attention output reaches HBM.  x = LayerNorm(R1) rows
+ * ctrlv_gemm (to_out) [+ ctrlv_layernorm with ln_gamma]: neither the 3C-wide q|k|v tensor nor the attention output (nor the
+ * normalised rows) reaches HBM.  x = LayerNorm(R1) rows -- or, with ln_gamma / ln_beta, the raw rows (= R1) --
  * [B F S][ldx] ordered (b, f, s); wf = ctrlv_temporal_fused_weight_bytes() bytes written by ctrlv_temporal_fused_pack from the
  * packed [3C][ld_qkv] q|k|v weight and the packed [C][ld_o] output projection; bias fp32 [C] or NULL; V: row-vector table
  * as in ctrlv_gemm_desc (vmode 1: vdiv = F S -- one row per clip; vmode 2: also vS = S); R1_lo / out_lo: SPLIT trunk planes
@@ -222,6 +223,9 @@ typedef struct ctrlv_temporal_fused_desc {
   const float* V; int32_t vmode, vdiv, vmod, vS, ldv;
   void* out; void* out_lo; int32_t ldo;
   int32_t B, F, S, C;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;   /* optional: x holds the RAW rows and the kernel normalises them
+                                                                  first (LayerNorm over C, ctrlv_layernorm's arithmetic and
+                                                                  rounding; not with split planes).  NULL: x is used as it is */
 } ctrlv_temporal_fused_desc;
 size_t ctrlv_temporal_fused_weight_bytes(void);
 int ctrlv_temporal_fused_pack(const void* wqkv_packed, int ld_qkv, const void* wo_packed, int ld_o, void* wf,

@@ -121,12 +121,22 @@ def test_temporal_fused_register_budget():
             sp = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", err)]
             occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", err)]
             kern = [(n, v, s, o) for n, v, s, o in zip(names, vg, sp, occ) if "temporal_fused_kernel" in n]
-            assert len(kern) == (2 if defs else 1), (defs, names)
+            assert len(kern) == (3 if defs else 2), (defs, names)        # <LO, LN>: plain, LayerNorm prologue (+ split planes)
             for n, v, s, o in kern:
-                lo = "ILb1E" in n                      # temporal_fused_kernel<true>: split trunk planes
+                lo = "ILb1E" in n                      # temporal_fused_kernel<true, ..>: split trunk planes
                 assert v <= 256 and o >= 2, (n, v, o)
-                assert s <= (32 if lo else 0), (n, s)
-            # no scratch access between the MFMAs of a chain in the plain kernel
+                assert s <= (32 if lo else 8), (n, s)  # (a few once-per-pixel-group values: strip address, next row offset)
+            # ... and no scratch access inside a chain: no basic block with MFMAs of a chain touches scratch
             text = open(asm).read()
-            body = [k for k in re.split(r"\n(?=_ZN\S*temporal_fused_kernelILb0E\S*:)", text)[1:]][0].split("s_endpgm")[0]
-            assert "v_mfma" in body and "scratch_" not in body
+            for k in re.split(r"\n(?=_ZN\S*temporal_fused_kernelILb0E\S*:)", text)[1:]:
+                blocks, cur = [], []
+                for ln in k.split("s_endpgm")[0].split("\n"):
+                    if ln.startswith(".LBB") or ln.startswith("; %bb."):
+                        blocks.append(cur)
+                        cur = []
+                    cur.append(ln)
+                blocks.append(cur)
+                assert sum(ln.count("v_mfma") for b in blocks for ln in b) > 800
+                for b in blocks:
+                    if sum("v_mfma" in ln for ln in b) >= 8:
+                        assert not [ln for ln in b if "scratch_" in ln], k[:80]

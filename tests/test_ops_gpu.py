@@ -880,6 +880,26 @@ def test_temporal_fused(ops, B, Fr, S, vm):
     out2 = torch.full_like(out, float("nan"))
     ops.temporal_fused(xd, wf, out2, B, Fr, S, **kw, **vkw)
     assert torch.equal(out, out2)
+    # with the block's LayerNorm in the kernel (x = the raw rows): against the norm as a launch of its own + the kernel
+    raw = bf(torch.randn(M, C, generator=g(11)) * 1.5 + 0.3)
+    gam, bet = torch.randn(C, generator=g(12)).to(DEV), torch.randn(C, generator=g(13)).to(DEV)
+    xn = torch.empty(M, C, dtype=EL, device=DEV)
+    ops.layernorm(raw.to(DEV), gam, bet, 1e-5, xn)
+    two, one_l = torch.empty_like(out), torch.full_like(out, float("nan"))
+    ops.temporal_fused(xn, wf, two, B, Fr, S, **kw, **vkw)
+    assert ops.temporal_fused_serves(raw.to(DEV), wf, one_l, B, Fr, S, ln=(gam, bet, 1e-5), **kw, **vkw)
+    ops.temporal_fused(raw.to(DEV), wf, one_l, B, Fr, S, ln=(gam, bet, 1e-5), **kw, **vkw)
+    assert rel_l2(one_l.float().cpu(), two.float().cpu()) < tol(2e-3)
+    lnref = F.layer_norm(raw.float(), (C,), gam.cpu(), bet.cpu(), 1e-5)
+    ql, kl, vl = (bf(bf(lnref).float() @ bf(w).float().T).float() for w in (wq, wk, wv))
+    attl = _sdpa_ref(tok(ql), tok(kl), tok(vl)).reshape(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(M, C)
+    refl = bf(attl).float() @ bf(wo).float().T + bo + r1.float()
+    if vm:
+        refl = refl + vt[idx]
+    assert parity_err(one_l, refl, "temporal_fused with the LayerNorm prologue") < tol(5e-3)
+    again = torch.full_like(out, float("nan"))
+    ops.temporal_fused(raw.to(DEV), wf, again, B, Fr, S, ln=(gam, bet, 1e-5), **kw, **vkw)
+    assert torch.equal(one_l, again)
     if B > 1 and vm != 2:                                 # clip 0 alone (vmode 2 couples the clips through the context order)
         M1 = Fr * S
         one = torch.full((M1, C), float("nan"), dtype=EL, device=DEV)

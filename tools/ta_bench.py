@@ -39,6 +39,20 @@ def fused(b):
     ops.temporal_fused(b["x"], wf, b["out"], B, F, S, R1=b["r1"], **kw)
 
 
+gam, bet = r(C), r(C)
+for b_ in sets:
+    b_["tt"] = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+
+
+def ln_then_fused(b):          # the block's LayerNorm as a launch of its own (x = r1: the block normalises its residual input)
+    ops.layernorm(b["r1"], gam, bet, 1e-5, b["tt"])
+    ops.temporal_fused(b["tt"], wf, b["out"], B, F, S, R1=b["r1"], **kw)
+
+
+def fused_ln(b):               # ... inside the kernel
+    ops.temporal_fused(b["r1"], wf, b["out"], B, F, S, R1=b["r1"], ln=(gam, bet, 1e-5), **kw)
+
+
 def timeit(name, fn):
     for b in sets:
         fn(b)
@@ -55,7 +69,7 @@ def timeit(name, fn):
 
 
 if "--stamp" not in sys.argv and "--variant" not in sys.argv:
-    for name, fn in (("three launches", three), ("fused", fused), ("three launches", three), ("fused", fused)):
+    for name, fn in (("three launches", three), ("fused", fused), ("LN + fused", ln_then_fused), ("fused incl. LN", fused_ln)) * 2:
         timeit(name, fn)
 else:
     import __graft_entry__ as ge
