@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           // first four of the output projection (the CU's vector-memory path takes 64 B per clock: all twenty in one Y phase
           // made that phase six times as long as the chain beside it), so that they have landed a slot before the next group
           xoff_next = x_offset(grp + G);
-          x_loads(xr, xoff_next, 0, 4);
+          if constexpr (!LO) x_loads(xr, xoff_next, 0, 4);
         }
         y_end();
       }
@@ -481,7 +481,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
         }
       TSTAMP(te3);
       TSTAMP_ADD(c_epi, te2b, te3);
-      if (np < kOutChunks / 2 - 1) x_loads(xr, xoff_next, np * 4 + 4, np * 4 + 8);
+      // (split planes: two more residual / output planes are alive across the chains and the x registers are needed for them
+      //  -- the rows are requested behind the last epilogue instead, where nothing else is alive)
+      if constexpr (!LO) { if (np < kOutChunks / 2 - 1) x_loads(xr, xoff_next, np * 4 + 4, np * 4 + 8); }
+      else { if (np == kOutChunks / 2 - 1) x_loads(xr, xoff_next, 0, kKS); }
       TSTAMP(te4);
       TSTAMP_ADD(c_x, te3, te4);
       y_end();
@@ -563,8 +566,6 @@ static int ta_check(const ctrlv_temporal_fused_desc& d, bool report) {
   TA_REQ((!d.R1_lo || d.R1) && ((!d.R1_lo && !d.out_lo) || CTRLV_ELEM_DTYPE == 1), CTRLV_E_BAD_ARG,
          "ctrlv_temporal_fused: split trunk planes need R1 and the fp16 element library");
   TA_REQ((d.ln_gamma == nullptr) == (d.ln_beta == nullptr), CTRLV_E_BAD_ARG, "ctrlv_temporal_fused: LayerNorm needs gamma and beta");
-  TA_REQ(!d.ln_gamma || (!d.R1_lo && !d.out_lo), CTRLV_E_BAD_ARG,
-         "ctrlv_temporal_fused: the in-kernel LayerNorm reads plain rows (split trunk: run ctrlv_layernorm_split in front)");
   if (d.vmode) {
     // the row vector must be constant over a pixel's frames: one table row per clip (vmode 1) or per (pixel, clip) (vmode 2)
     TA_REQ((d.vmode == 1 || d.vmode == 2) && d.V && d.vmod > 0 && d.ldv >= kC && d.ldv % 4 == 0 && d.vdiv == d.F * d.S &&
@@ -629,7 +630,8 @@ extern "C" int ctrlv_temporal_fused(const ctrlv_temporal_fused_desc* dp, ctrlv_s
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), kSmem, (hipStream_t)stream, a);                            \
   } while (0)
 #ifdef CTRLV_ELEM_F16
-  if (lo) TA_LAUNCH(true, false);          // (split planes: the LayerNorm stays a launch of its own -- ta_check)
+  if (lo && ln) TA_LAUNCH(true, true);     // (the in-kernel LayerNorm normalises the rows of x: with a split trunk, its hi plane)
+  else if (lo) TA_LAUNCH(true, false);
   else if (ln) TA_LAUNCH(false, true);
   else TA_LAUNCH(false, false);
 #else

@@ -225,7 +225,9 @@ typedef struct ctrlv_temporal_fused_desc {
   int32_t B, F, S, C;
   const float* ln_gamma; const float* ln_beta; float ln_eps;   /* optional: x holds the RAW rows and the kernel normalises them
                                                                   first (LayerNorm over C, ctrlv_layernorm's arithmetic and
-                                                                  rounding; not with split planes).  NULL: x is used as it is */
+                                                                  rounding; with a split trunk x is the hi plane: the branch
+                                                                  input is the element-rounded value, the residual operand
+                                                                  R1 + R1_lo stays exact).  NULL: x is used as it is */
 } ctrlv_temporal_fused_desc;
 size_t ctrlv_temporal_fused_weight_bytes(void);
 int ctrlv_temporal_fused_pack(const void* wqkv_packed, int ld_qkv, const void* wo_packed, int ld_o, void* wf,
