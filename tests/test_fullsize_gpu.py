@@ -38,6 +38,47 @@ def ops(hip_lib):
 
 
 # ------------------------------------------------------------------------------------------------ layer shapes
+def test_temporal_fused_l0_fullsize(ops):
+    """The fused temporal self-attention block (csrc/temporal_fused.hip) at its production shape -- 2 clips x 25 frames x
+    72 x 128 pixels, C = 320: 2304 pixel groups, nine per persistent workgroup, the 3-slot weight ring walked 180 times by two
+    wave groups half a slot apart -- against the launches it replaces (LayerNorm, q|k|v GEMM, temporal attention, output
+    projection), and BIT-IDENTICAL over five runs: the ring's hand-off between the two wave groups is timing-sensitive (a
+    fragment read in front of the wrong barrier passed every small-shape test and failed only here)."""
+    from ctrlv_amd import packing
+    C, B = 320, 2
+    M = B * FR * S0
+    g0 = randn(M, C, seed=21, scale=1.5)
+    gam = torch.randn(C, generator=g(22), device=DEV)
+    bet = torch.randn(C, generator=g(23), device=DEV)
+    wq, wk, wv, wo = (torch.randn(C, C, generator=g(24 + i), device=DEV) / math.sqrt(C) for i in range(4))
+    bo = torch.randn(C, generator=g(28), device=DEV)
+    vt = torch.randn(B, C, generator=g(29), device=DEV)
+    wqkv = packing.pack_qkv(wq.cpu(), wk.cpu(), wv.cpu()).to(DEV)
+    wop = packing.pack_linear(wo.cpu()).to(DEV)
+    wf = ops.temporal_fused_pack(wqkv, wop)
+    kw = dict(bias=bo, R1=g0, V=vt, vmode=1, vdiv=FR * S0)
+    tt = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    qkv = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=DEV)
+    a = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ref = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(g0, gam, bet, 1e-5, tt)
+    ops.gemm(tt, wqkv, qkv, N=3 * C, cin=C)
+    ops.attention_temporal(qkv, a, B, FR, S0, C)
+    ops.gemm(a, wop, ref, N=C, cin=C, **kw)
+    outs = []
+    for ln in (None, (gam, bet, 1e-5)):
+        runs = []
+        for _ in range(5):
+            o = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.temporal_fused(tt if ln is None else g0, wf, o, B, FR, S0, ln=ln, **kw)
+            runs.append(o)
+        assert all(torch.equal(runs[0], r) for r in runs[1:])
+        assert torch.isfinite(runs[0].float()).all()
+        assert rel_l2(runs[0].float(), ref.float()) < 3e-3
+        outs.append(runs[0])
+    assert rel_l2(outs[0].float(), outs[1].float()) < 3e-3
+
+
 def test_conv3x3_l0_fullsize(ops):
     """ResnetBlock2D.conv1 at L0 (50 x 320 x 72 x 128, 9 taps) with the temb broadcast add, vs F.conv2d fp32 on the GPU."""
     from ctrlv_amd import packing
