@@ -38,6 +38,7 @@ const ctrlv_debug_t& ctrlv_debug() {
     d.pp_cgrp = env("CTRLV_PP_CGRP", 0);
     d.attn_rows = env("CTRLV_ATTN_ROWS", 0);
     d.temporal_fused = env("CTRLV_TEMPORAL_FUSED", 1);
+    d.wgrad_pp = env("CTRLV_WGRAD_PP", 1);
     return d;
   }();
   return dbg;

@@ -15,6 +15,7 @@
 // This slice is written for correctness first (parity against torch.autograd on the oracle, tests/test_backward_gpu.py);
 // attention / LayerNorm / GEGLU backward and the tuned (LDS-DMA, persistent) wgrad schedule are the next steps.
 #include "common.h"
+#include "wgrad_pp.h"
 
 namespace {
 
@@ -709,10 +710,19 @@ static int wgrad_slabs(const ctrlv_gemm_desc& d, int* rows_per_slab) {
   return (d.M + rps - 1) / rps;
 }
 
+// (the kernel choice is a function of the layer's shape: the pointer-alignment part of ctrlv_wgrad_pp_serves is checked at the
+//  launch, against buffers the size query has not seen -- the larger of the two decompositions is reserved)
 extern "C" size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* dp) {
   if (!dp || dp->M <= 0 || dp->N <= 0 || dp->Cin <= 0 || dp->taps <= 0) return 0;
   int rps;
-  const int slabs = wgrad_slabs(*dp, &rps);
+  int slabs = wgrad_slabs(*dp, &rps);
+  ctrlv_gemm_desc probe = *dp;
+  if (!probe.A) probe.A = (const void*)16;
+  if (ctrlv_wgrad_pp_serves(probe, (const void*)16, 8)) {
+    ctrlv_wgrad_pp_plan_t p;
+    ctrlv_wgrad_pp_plan(*dp, &p);
+    if (p.slabs > slabs) slabs = p.slabs;
+  }
   return (size_t)slabs * ((size_t)dp->N * dp->taps * dp->Cin + dp->N) * sizeof(float);
 }
 
@@ -733,7 +743,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   a.F = d.F; a.S = d.S;
   const int ktiles = (d.taps * d.Cin + 255) / 256, ntiles = (d.N + 127) / 128;
   int rps;
-  const int slabs = wgrad_slabs(d, &rps);
+  int slabs = wgrad_slabs(d, &rps);
   a.rows_per_slab = rps;
   CTRLV_CHECK_SHAPE((long)ntiles * ktiles * slabs < (1L << 30), "gemm_wgrad: grid too large");
   a.ntiles = ntiles; a.ktiles = ktiles; a.slabs = slabs;
@@ -745,8 +755,16 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
     CTRLV_CHECK_SHAPE((d.taps * d.Cin) % 4 == 0, "gemm_wgrad: K must be a multiple of 4");
     a.part = (float*)scratch;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ntiles * ktiles * slabs)), dim3(256), 0, (hipStream_t)stream, a);
-  CTRLV_LAUNCH_CHECK();
+  if (ctrlv_wgrad_pp_serves(d, dY, ldy)) {        // the LDS-DMA kernel (wgrad_pp.hip): same partial layout, its own slab count
+    ctrlv_wgrad_pp_plan_t p;
+    ctrlv_wgrad_pp_plan(d, &p);
+    slabs = p.slabs;
+    const int rc = ctrlv_wgrad_pp_launch(d, dY, ldy, dW, dbias, scale, torch_layout, a.part, p, stream);
+    if (rc != CTRLV_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ntiles * ktiles * slabs)), dim3(256), 0, (hipStream_t)stream, a);
+    CTRLV_LAUNCH_CHECK();
+  }
   if (a.part) {
     const long ktot = (long)d.taps * d.Cin, n_thr = (long)d.N * (ktot >> 2);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, slabs,

@@ -165,6 +165,69 @@ def test_wgrad_temporal_conv(ops):
     assert parity_err(dWt, w.grad, "temporal wgrad, parameter layout") < 2e-3
 
 
+@pytest.mark.parametrize("case", [
+    dict(M=4100, N=640, K=320),                       # two n tiles, ragged rows (not a multiple of 32), second k tile a quarter full
+    dict(M=33333, N=128, K=1280),                     # dY panels past N read zeros; five k tiles; many slabs
+    dict(M=2048, N=320, K=64, lda=192, ldy=448),      # row-strided views
+    dict(n=4, H=9, W=16, N=320, K=320, taps=9),       # 3x3, rows narrower than a chunk (two image rows per 32)
+    dict(n=3, H=24, W=40, N=64, K=128, taps=9),       # 3x3, W not a power of two
+    dict(B=2, F=5, S=240, N=320, K=320, taps=3),      # temporal conv
+])
+def test_wgrad_lds_dma_kernel(ops, case):
+    """csrc/wgrad_pp.hip (320 x 256 tile on an LDS-DMA ring; serves mode 0 / stride-1 3x3 / temporal with N, Cin multiples of
+    64 and M >= 1024): against fp32 torch on the same 16-bit operands, both weight layouts, fused bias gradient,
+    accumulation into a non-zero dW, and the same bits in every run."""
+    taps = case.get("taps", 1)
+    N, K = case["N"], case["K"]
+    kw = dict(N=N, cin=K, taps=taps)
+    if taps == 9:
+        n, H, W = case["n"], case["H"], case["W"]
+        M = n * H * W
+        kw.update(mode=1, conv=(H, W, H, W, 1, 0))
+    elif taps == 3:
+        B, Fr, S = case["B"], case["F"], case["S"]
+        M = B * Fr * S
+        kw.update(mode=2, temporal=(Fr, S))
+    else:
+        M = case["M"]
+    lda, ldy = case.get("lda", K), case.get("ldy", N)
+    A_full = bf(torch.randn(M, lda, generator=g(11))).to(DEV)
+    Y_full = bf(torch.randn(M, ldy, generator=g(12))).to(DEV)
+    A, dY = A_full[:, :K], Y_full[:, :N]
+    a32, y32 = A.float(), dY.float()
+    if taps == 9:       # reference: autograd of the fp32 conv on the same operands
+        w = torch.zeros(N, K, 3, 3, device=DEV, requires_grad=True)
+        F.conv2d(nchw(a32, n, H, W), w, None, padding=1).backward(nchw(y32, n, H, W))
+        ref_t = w.grad                                                              # [N, K, 3, 3]
+        ref_p = ref_t.permute(0, 2, 3, 1).reshape(N, 9 * K)
+    elif taps == 3:
+        w = torch.zeros(N, K, 3, 1, 1, device=DEV, requires_grad=True)
+        x5 = a32.reshape(B, Fr, S, 1, K).permute(0, 4, 1, 2, 3)
+        y5 = y32.reshape(B, Fr, S, 1, N).permute(0, 4, 1, 2, 3)
+        F.conv3d(x5, w, None, padding=(1, 0, 0)).backward(y5)
+        ref_t = w.grad
+        ref_p = ref_t.reshape(N, K, 3).permute(0, 2, 1).reshape(N, 3 * K)
+    else:
+        ref_p = y32.T @ a32
+        ref_t = ref_p
+    ref_b = y32.sum(0)
+
+    def run(torch_layout):
+        dW = torch.full(ref_t.shape if torch_layout else ref_p.shape, 0.25, dtype=torch.float32, device=DEV)
+        db = torch.full((N,), -1.0, dtype=torch.float32, device=DEV)
+        ops.gemm_wgrad(A, dY, dW, dbias=db, scale=0.5, torch_layout=torch_layout, **kw)
+        return dW, db
+    dW, db = run(False)
+    assert parity_err(dW - 0.25, 0.5 * ref_p, f"wgrad {case}") < 2e-3
+    assert parity_err(db + 1.0, 0.5 * ref_b, "fused bias gradient") < 2e-3
+    dWt, dbt = run(True)
+    assert parity_err(dWt - 0.25, 0.5 * ref_t, "parameter layout") < 2e-3
+    for _ in range(3):
+        dW2, db2 = run(False)
+        assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    assert torch.equal(dbt, db)
+
+
 @pytest.mark.parametrize("C,H,W,n,ips", [(320, 9, 16, 6, 1), (320, 9, 16, 6, 3), (64, 16, 16, 4, 2), (128, 72, 64, 2, 1)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_backward(ops, C, H, W, n, ips, silu):
