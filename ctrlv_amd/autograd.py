@@ -56,6 +56,32 @@ def _packed(weight, kind, fn):
     return out
 
 
+def f32(p):
+    """fp32 form of a parameter for the per-clip torch ops and the norm kernels: trainable / fp32 parameters as they are
+    (autograd sees them), FROZEN 16-bit ones converted once (the UNet of the training step: ~500 small conversion kernels
+    per step otherwise)."""
+    if p.dtype == torch.float32 or p.requires_grad or not isinstance(p, torch.nn.Parameter):
+        return p.float()
+    return _packed(p, "f32", lambda w: w.detach().float().contiguous())
+
+
+def _frozen(key_param, kind, fn):
+    """A tensor derived from FROZEN parameters (fused q|k|v weight, GEGLU row interleave): built once and kept as a frozen
+    Parameter, so that the packed kernel layouts derived from IT are cached as well.  Trainable: rebuilt on every use."""
+    if key_param.requires_grad or not isinstance(key_param, torch.nn.Parameter):
+        return fn()
+    return _packed(key_param, kind, lambda _w: torch.nn.Parameter(fn().detach(), requires_grad=False))
+
+
+def _geglu_bias32(bias):
+    return _packed(bias, "geglu_b32", lambda b: packing.geglu_interleave(b.detach()).float().contiguous())
+
+
+def _bias32(bias):
+    """padded fp32 bias row of a GEMM launch (packing.pad_bias); cached for frozen parameters"""
+    return _packed(bias, "bias32", packing.pad_bias)
+
+
 def _pack_fwd(weight, mode, geglu=False):
     """bf16 forward GEMM layout of a parameter: one kernel (ctrlv_pack_weight) where the shape allows, else packing.py."""
     out = ops.pack_weight(weight, 0, geglu) if weight.is_cuda else None
@@ -88,7 +114,7 @@ class GatherGemm(torch.autograd.Function):
         out = _rows(m_out, N, A)
         ops.gemm(A, GatherGemm._pack(weight, mode), out, N=(N + 31) // 32 * 32, cin=cin, taps=taps, mode=mode,
                  conv=geom.get("conv"), temporal=geom.get("temporal"),
-                 bias=None if bias is None else packing.pad_bias(bias), R1=R1, s_acc=float(s_acc),
+                 bias=None if bias is None else _bias32(bias), R1=R1, s_acc=float(s_acc),
                  V=V, vmode=1 if V is not None else 0, vdiv=geom.get("vdiv", 1))
         ctx.save_for_backward(A, weight)
         ctx.geom, ctx.s_acc, ctx.has = geom, float(s_acc), (bias is not None, R1 is not None, V is not None)
@@ -161,10 +187,12 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
         # Linear weights are written in place; conv weights in the packed tap-major order and permuted afterwards
         # (writing [N, cin, taps] directly scatters the atomics at a 36-byte stride: A/B in DESIGN 3.6)
         direct = taps == 1 or _WGRAD_DIRECT
-        dWp = torch.zeros(weight.shape if direct else (N, taps * cin), dtype=torch.float32, device=A.device)
-        dbp = torch.zeros(N, dtype=torch.float32, device=A.device) if need_db else None
+        # (deterministic form: the ordered slab sum WRITES dW / dbias -- no zero fill; the atomic form accumulates)
+        new = torch.empty if ops.DETERMINISTIC else torch.zeros
+        dWp = new(weight.shape if direct else (N, taps * cin), dtype=torch.float32, device=A.device)
+        dbp = new(N, dtype=torch.float32, device=A.device) if need_db else None
         ops.gemm_wgrad(A, dY, dWp, N=N, cin=cin, taps=taps, mode=mode, conv=geom.get("conv"),
-                       temporal=geom.get("temporal"), dbias=dbp, scale=s_acc, torch_layout=direct)
+                       temporal=geom.get("temporal"), dbias=dbp, scale=s_acc, torch_layout=direct, assign=ops.DETERMINISTIC)
         if direct:
             dW = dWp
         elif mode == 1:
@@ -189,7 +217,7 @@ class GroupNormSiLU(torch.autograd.Function):
         C = x.shape[1]
         part = torch.empty(ops.groupnorm_scratch_floats(n_img, S, C, imgs_per_stat), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        g32, b32 = f32(gamma).detach().contiguous(), f32(beta).detach().contiguous()
         ops.groupnorm(x, None, n_img, S, C, imgs_per_stat, g32, b32, eps, silu, y, part)
         ctx.save_for_backward(x, g32, b32, part)
         ctx.cfg = (n_img, S, C, imgs_per_stat, silu, gamma.dtype)
@@ -266,7 +294,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, V, vdiv, vmod):
         y = torch.empty_like(x)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        g32, b32 = f32(gamma).detach().contiguous(), f32(beta).detach().contiguous()
         ops.layernorm(x, g32, b32, 1e-5, y, V=V, vdiv=vdiv, vmod=vmod)
         ctx.save_for_backward(x, g32, V if V is not None else torch.empty(0, device=x.device))
         ctx.cfg = (V is not None, vdiv, vmod, gamma.dtype)
@@ -322,7 +350,7 @@ class _GegluCell:
         if self.done:
             return
         two_i = self.w.shape[0]
-        wp, bp = _pack_fwd(self.w, 0, geglu=True), packing.geglu_interleave(self.b.detach()).float().contiguous()
+        wp, bp = _packed(self.w, "fwd_geglu", lambda w: _pack_fwd(w, 0, geglu=True)), _geglu_bias32(self.b)
         M = self.x.shape[0]
         self.u, self.raw = _rows(M, two_i // 2, self.x), _rows(M, two_i, self.x)
         ops.gemm(self.x, wp, self.u, N=two_i, cin=wp.shape[1], bias=bp, geglu=1, raw_out=self.raw)
@@ -389,7 +417,7 @@ class GegluProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         two_i, cin = weight.shape
-        wp, bp = _pack_fwd(weight, 0, geglu=True), packing.geglu_interleave(bias.detach()).float().contiguous()
+        wp, bp = _packed(weight, "fwd_geglu", lambda w: _pack_fwd(w, 0, geglu=True)), _geglu_bias32(bias)
         u = _rows(x.shape[0], two_i // 2, x)
         # (a cell only where a backward will run: under torch.no_grad() / with no input requiring grad -- an evaluation pass
         #  inside a checkpointed training context -- Function.forward still executes, but no consumer ever saves u, so a cell
@@ -412,7 +440,7 @@ class GegluProj(torch.autograd.Function):
         x, weight, bias, raw = ctx.saved_tensors
         two_i, cin = weight.shape
         inner = two_i // 2
-        wi = packing.geglu_interleave(weight.detach())                 # rows in the packed (value, gate) block order
+        wi = _frozen(weight, "geglu_il", lambda: packing.geglu_interleave(weight.detach()))   # rows in the packed (value, gate) block order
         if ctx.cell is not None:
             raw = ctx.cell.take("raw")                                 # (recomputed together with u: one launch)
             ctx.cell = None
@@ -485,7 +513,7 @@ class FusedLinear(torch.autograd.Function):
         N, cin = weight.shape
         out = _rows(A.shape[0], N, A)
         ops.gemm(A, _packed(weight, ("fwd", 0), lambda w: _pack_fwd(w, 0)), out, N=(N + 31) // 32 * 32, cin=cin,
-                 bias=None if bias is None else packing.pad_bias(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
+                 bias=None if bias is None else _bias32(bias), s_acc=s_acc, R1=R1, s1=s1, R2=R2, s2=s2,
                  V=V, vmode=vmode, vdiv=vdiv, vmod=vmod, vS=vS)
         ctx.save_for_backward(A, weight)
         ctx.cfg = (s_acc, s1, s2, vdiv, vmod, bias is not None, R1 is not None, R2 is not None,
@@ -525,7 +553,7 @@ class BlendLinear(torch.autograd.Function):
         a = _mix_alpha(mix_factor)
         N, cin = weight.shape
         out = _rows(u.shape[0], N, u)
-        ops.gemm(u, _pack_fwd(weight, 0), out, N=N, cin=cin, bias=packing.pad_bias(bias), s_acc=1.0 - a,
+        ops.gemm(u, _packed(weight, ("fwd", 0), lambda w: _pack_fwd(w, 0)), out, N=N, cin=cin, bias=_bias32(bias), s_acc=1.0 - a,
                  R1=g1, s1=1.0 - a, R2=h2, s2=a)
         ctx.save_for_backward(u, weight, h2, out, mix_factor)
         ctx.a = a
@@ -610,20 +638,20 @@ def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
     quirk = time_context_order == "sb" and B > 1       # diffusers 0.27.2: time_context rows (s, b), tokens (b, s) -- H1
 
     def xvec(attn):
-        return Fn.linear(Fn.linear(ehs.float(), attn.to_v.weight.float()), attn.to_out[0].weight.float(),
-                         attn.to_out[0].bias.float()).contiguous()
+        return Fn.linear(Fn.linear(ehs.float(), f32(attn.to_v.weight)), f32(attn.to_out[0].weight),
+                         f32(attn.to_out[0].bias)).contiguous()
 
     tpe = tr.time_pos_embed
-    emb = Fn.linear(Fn.silu(Fn.linear(sinusoid(torch.arange(F, device=x.device), C), tpe.linear_1.weight.float(),
-                                      tpe.linear_1.bias.float())), tpe.linear_2.weight.float(),
-                    tpe.linear_2.bias.float()).contiguous()                                   # fp32 [F, C]
+    emb = Fn.linear(Fn.silu(Fn.linear(sinusoid(torch.arange(F, device=x.device), C), f32(tpe.linear_1.weight),
+                                      f32(tpe.linear_1.bias))), f32(tpe.linear_2.weight),
+                    f32(tpe.linear_2.bias)).contiguous()                                   # fp32 [F, C]
     big = 1 << 30
 
     def ln(h, n, V=None, vdiv=1, vmod=big):
         return LayerNormFn.apply(h, n.weight, n.bias, V, vdiv, vmod)
 
     def qkv_w(attn):
-        return torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0)
+        return _frozen(attn.to_q.weight, "qkv_cat", lambda: torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0))
 
     t = GroupNormSiLU.apply(x, tr.norm.weight, tr.norm.bias, N, S, 1, 1e-6, False)
     h0 = FusedLinear.apply(t, tr.proj_in.weight, tr.proj_in.bias, None, None, None, {})

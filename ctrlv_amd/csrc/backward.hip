@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // form arrive in a different order every time).  Also does the [N][Cin][taps] scatter of torch_layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int N, long ktot, int Cin,
                                                            int taps, int torch_layout, float scale, float* __restrict__ dW,
-                                                           float* __restrict__ dbias) {
+                                                           float* __restrict__ dbias, int assign) {
   const long k4 = ktot >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx < (long)N * k4) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     if (!torch_layout) {
       float4* o = (float4*)(dW + n * ktot + k);
-      float4 v = *o;
+      float4 v = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *o;
       v.x += a.x * scale; v.y += a.y * scale; v.z += a.z * scale; v.w += a.w * scale;
       *o = v;
     } else {
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) {
         const long kk = k + e;
         const int tp = (int)(kk / Cin);
-        dW[n * ktot + (kk - (long)tp * Cin) * taps + tp] += av[e] * scale;
+        float* o = dW + n * ktot + (kk - (long)tp * Cin) * taps + tp;
+        *o = (assign ? 0.f : *o) + av[e] * scale;
       }
     }
   }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const float* pb = part + (long)slabs * N * ktot;
     float t = 0.f;
     for (int sidx = 0; sidx < slabs; ++sidx) t += pb[(long)sidx * N + idx];
-    dbias[idx] += t * scale;
+    dbias[idx] = (assign ? 0.f : dbias[idx]) + t * scale;
   }
 }
 
@@ -309,18 +310,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const el_t* __restrict__ x,
     flush(cur);
   }
 }
-// out[idx(b)][n] += scale * sum over the blocks b of table row idx, in block order (single writer per element)
+// out[idx(b)][n] += scale * sum over the blocks b of table row idx, in a FIXED order (single writer per element): 32 columns x
+// 8 block lanes per workgroup -- lane l adds blocks l, l + 8, .. in order, the eight lane sums are added in lane order.
+// (The first version walked all blocks in one thread per column, a 64-bit division per block: 125 us per call at M = 230 400,
+// 6 ms of the cfg5 step for 48 calls.)
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int rows_per_block, int N,
                                                             int vmode, int vdiv, int vmod, float scale, float* __restrict__ out,
                                                             int ldo) {
-  const int n = blockIdx.x * 256 + threadIdx.x, idx = blockIdx.y;
-  if (n >= N) return;
+  __shared__ float red[8][32];
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + lx, idx = blockIdx.y;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    const int bi = vmode ? (int)(((long)b * rows_per_block / vdiv) % vmod) : 0;
-    if (bi == idx) t += part[(long)b * N + n];
+  if (n < N) {
+    for (int b = ly; b < nblocks; b += 8) {
+      const int bi = vmode ? (int)(((unsigned)b * (unsigned)rows_per_block / (unsigned)vdiv) % (unsigned)vmod) : 0;
+      if (bi == idx) t += part[(long)b * N + n];
+    }
   }
-  out[(long)idx * ldo + n] += t * scale;
+  red[ly][lx] = t;
+  __syncthreads();
+  if (ly == 0 && n < N) {
+    float v = red[0][lx];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) v += red[l][lx];
+    out[(long)idx * ldo + n] += v * scale;
+  }
 }
 
 // out[0] += scale * sum_i dy[i] * (p[i] - q[i])      (gradient of a folded AlphaBlender's mixing weight)
@@ -729,6 +743,10 @@ extern "C" size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* dp) {
 extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, float* dbias, float scale,
                                 int torch_layout, void* scratch, size_t scratch_bytes, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(dp && dY && dW, "gemm_wgrad: null pointer");
+  CTRLV_CHECK_ARG(torch_layout >= 0 && torch_layout <= 3, "gemm_wgrad: torch_layout=%d (bit 0: parameter layout, bit 1: assign)", torch_layout);
+  const int assign = (torch_layout >> 1) & 1;
+  torch_layout &= 1;
+  CTRLV_CHECK_ARG(!assign || scratch, "gemm_wgrad: assign (torch_layout bit 1) needs the deterministic form (scratch)");
   const ctrlv_gemm_desc& d = *dp;
   CTRLV_CHECK_ARG(d.A != nullptr, "gemm_wgrad: A must be non-null");
   CTRLV_CHECK_SHAPE(d.M > 0 && d.N > 0 && d.Cin > 0 && d.Cin % 64 == 0, "gemm_wgrad: Cin=%d must be a positive multiple of 64", d.Cin);
@@ -768,7 +786,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   if (a.part) {
     const long ktot = (long)d.taps * d.Cin, n_thr = (long)d.N * (ktot >> 2);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, slabs,
-                       d.N, ktot, d.Cin, d.taps, torch_layout, scale, dW, dbias);
+                       d.N, ktot, d.Cin, d.taps, torch_layout, scale, dW, dbias, assign);
     CTRLV_LAUNCH_CHECK();
   }
   return CTRLV_OK;
@@ -802,7 +820,7 @@ extern "C" int ctrlv_colsum(const void* x, int M, int N, int ldx, int vmode, int
   CTRLV_LAUNCH_CHECK();
   if (scratch) {
     const int n_idx = vmode ? (int)(((long)(M - 1) / vdiv + 1) < vmod ? ((long)(M - 1) / vdiv + 1) : vmod) : 1;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256, n_idx), dim3(256), 0, (hipStream_t)stream, scratch, nblocks, rpb, N,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32, n_idx), dim3(256), 0, (hipStream_t)stream, scratch, nblocks, rpb, N,
                        vmode, vdiv, vmod, scale, out, ldo);
     CTRLV_LAUNCH_CHECK();
   }

@@ -26,6 +26,12 @@
 #include "common.h"
 #include "wgrad_pp.h"
 
+// Diagnostic builds only (tools/ab_build.py NAME -DCTRLV_WP_DIAG=bits; results are garbage): 1 = no MFMAs, 2 = no LDS-DMA in
+// the loop, 4 = no fragment reads in the loop -- which resource the loop waits for.  The product library is built with 0.
+#ifndef CTRLV_WP_DIAG
+#define CTRLV_WP_DIAG 0
+#endif
+
 namespace {
 
 constexpr int kBN = 320, kBK = 256, kRows = 32;
@@ -137,11 +143,27 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
     if (p < 4) { pdu[p] = du; pdv[p] = dv; }
   }
   const unsigned ld2 = (unsigned)((is_y ? a.ldy : a.lda) * 2);
+  // running row state of the NEXT chunk to issue (chunks are issued in order): m, and for the A waves the row's position
+  // (MODE 1: image row u, pixel v; MODE 2: frame u, position v inside the frame) -- one division at the start, then
+  // 32 rows further per chunk with a conditional wrap (the serves() conditions make one wrap per axis enough)
+  int dm = m_lo + prow, du_ = 0, dv_ = 0;
+  int step_u = 0, step_v = 0;
+  if (MODE == 1) {
+    const int q1 = fdiv(dm, dim_v, inv_w);
+    dv_ = dm - q1 * dim_v;
+    du_ = q1 - fdiv(q1, dim_u, inv_h) * dim_u;
+    step_u = kRows / dim_v; step_v = kRows - step_u * dim_v;
+  }
+  if (MODE == 2) {
+    const int q1 = fdiv(dm, dim_s, inv_s);
+    dv_ = dm - q1 * dim_s;
+    du_ = q1 - fdiv(q1, dim_u, inv_f) * dim_u;
+  }
+  (void)inv_w; (void)inv_h; (void)inv_s; (void)inv_f;
   auto dma = [&](int c) {                                          // chunk c of this slab into ring slot c & 3
     char* slot = smem + (c & (kSlots - 1)) * kSlot + (wid & 3) * 1024;
-    const int m = m_lo + c * kRows + prow;
-    const bool row_ok = m < m_hi;
-    const unsigned rbase = (unsigned)m * ld2;
+    const bool row_ok = dm < m_hi;
+    const unsigned rbase = (unsigned)dm * ld2;
     if (is_y) {
 #pragma unroll
       for (int p = 0; p < 5; ++p) {
@@ -149,25 +171,28 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(slot + p * kPanel), 16, voff, 0, 0, 0);
       }
     } else {
-      int u = 0, v = 0;                                            // MODE 1: (yo, xo); MODE 2: (frame, -)
-      if (MODE == 1) {
-        const int q1 = fdiv(m, dim_v, inv_w);
-        v = m - q1 * dim_v;
-        u = q1 - fdiv(q1, dim_u, inv_h) * dim_u;
-      }
-      if (MODE == 2) {
-        const int q1 = fdiv(m, dim_s, inv_s);
-        u = q1 - fdiv(q1, dim_u, inv_f) * dim_u;
-      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         bool ok = row_ok & (pbase[p] != (int)kOOB);
-        if (MODE != 0) ok = ok & ((unsigned)(u + pdu[p]) < (unsigned)dim_u);
-        if (MODE == 1) ok = ok & ((unsigned)(v + pdv[p]) < (unsigned)dim_v);
+        if (MODE != 0) ok = ok & ((unsigned)(du_ + pdu[p]) < (unsigned)dim_u);
+        if (MODE == 1) ok = ok & ((unsigned)(dv_ + pdv[p]) < (unsigned)dim_v);
         const unsigned voff = ok ? rbase + (unsigned)pbase[p] : kOOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(slot + kAOff + p * kPanel), 16, voff, 0, 0, 0);
       }
+      if (MODE == 1) {
+        dv_ += step_v; du_ += step_u;
+        const bool wv = dv_ >= dim_v;
+        dv_ -= wv ? dim_v : 0; du_ += wv ? 1 : 0;
+        du_ -= du_ >= dim_u ? dim_u : 0;
+      }
+      if (MODE == 2) {
+        dv_ += kRows;
+        const bool wv = dv_ >= dim_s;
+        dv_ -= wv ? dim_s : 0; du_ += wv ? 1 : 0;
+        du_ = du_ >= dim_u ? 0 : du_;
+      }
     }
+    dm += kRows;
   };
 
   // ---- fragment addresses (backward.hip tr_frag): lane -> row 4 hsel + (i16 >> 2) [+ 8], column 16 ((lane >> 4) & 1) + 4 (i16 & 3)
@@ -190,8 +215,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
-  const bool do_bias = a.dbias != nullptr && by == 0 && kh == 0;
-  float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  // bias gradient: the four kh waves of an n half hold the same dY fragments; wave kh sums fragment kh + 1 (kh = 0: also 0)
+  const bool do_bias = a.dbias != nullptr && by == 0;
+  float bsum0 = 0.f, bsum1 = 0.f;
 
   dma(0); dma(1); dma(2); dma(3);
   if (is_y) wp_wait_vmcnt<15>(); else wp_wait_vmcnt<12>();
@@ -200,9 +226,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
   read_step<0>(f0, a00, a10, yA0, yB0);
   for (int c = 0; c < nchunks; ++c) {
     const unsigned so = (unsigned)((c & (kSlots - 1)) * kSlot);
-    read_step<1>(f1, a00 + so, a10 + so, yA0 + so, yB0 + so);
+    if (!(CTRLV_WP_DIAG & 4)) read_step<1>(f1, a00 + so, a10 + so, yA0 + so, yB0 + so);
     wait_frags<14>(f0);
-    {
+    if (!(CTRLV_WP_DIAG & 1)) {
       const elx8 b0 = as_elx8(f0[5]), b1 = as_elx8(f0[6]);
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
@@ -211,17 +237,20 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
         acc[t][1] = mfma_32x32x16(y, b1, acc[t][1]);
       }
       if (do_bias) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) bsum[t] += frag_sum(f0[t]);
+        if (kh == 0) { bsum0 += frag_sum(f0[0]); bsum1 += frag_sum(f0[1]); }
+        else if (kh == 1) bsum0 += frag_sum(f0[2]);
+        else if (kh == 2) bsum0 += frag_sum(f0[3]);
+        else bsum0 += frag_sum(f0[4]);
       }
     }
     wait_frags<0>(f1);                                     // every read of chunk c has landed in registers ...
-    if (is_y) wp_wait_vmcnt<10>(); else wp_wait_vmcnt<8>();  // ... and this wave's pieces of chunk c + 1 in LDS
+    if (CTRLV_WP_DIAG & 2) wp_wait_vmcnt<0>();
+    else if (is_y) wp_wait_vmcnt<10>(); else wp_wait_vmcnt<8>();  // ... and this wave's pieces of chunk c + 1 in LDS
     asm volatile("s_barrier" ::: "memory");
-    dma(c + 4);                                            // slot of chunk c: no wave reads it any more
+    if (!(CTRLV_WP_DIAG & 2)) dma(c + 4);                  // slot of chunk c: no wave reads it any more
     const unsigned sn = (unsigned)(((c + 1) & (kSlots - 1)) * kSlot);
-    read_step<0>(f0, a00 + sn, a10 + sn, yA0 + sn, yB0 + sn);
-    {
+    if (!(CTRLV_WP_DIAG & 4)) read_step<0>(f0, a00 + sn, a10 + sn, yA0 + sn, yB0 + sn);
+    if (!(CTRLV_WP_DIAG & 1)) {
       const elx8 b0 = as_elx8(f1[5]), b1 = as_elx8(f1[6]);
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
@@ -230,50 +259,52 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
         acc[t][1] = mfma_32x32x16(y, b1, acc[t][1]);
       }
       if (do_bias) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) bsum[t] += frag_sum(f1[t]);
+        if (kh == 0) { bsum0 += frag_sum(f1[0]); bsum1 += frag_sum(f1[1]); }
+        else if (kh == 1) bsum0 += frag_sum(f1[2]);
+        else if (kh == 2) bsum0 += frag_sum(f1[3]);
+        else bsum0 += frag_sum(f1[4]);
       }
     }
   }
   wait_frags<0>(f0);                                       // (the reads issued for the chunk behind the last: discarded)
   wp_wait_vmcnt<0>();
 
-  // ---- results.  D[t][j]: lane holds column k = lane % 32, rows n = (e & 3) + 8 (e >> 2) + 4 (lane / 32)
+  // ---- results.  D[t][j]: lane holds column k = lane % 32, rows n = (e & 3) + 8 (e >> 2) + 4 (lane / 32).  N and K are
+  // multiples of 64 and the 32-wide blocks are aligned: a block is inside or outside as a whole (scalar branches only)
 #pragma unroll
   for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int k = k0 + 64 * kh + 32 * j + (lane & 31);
-      if (k >= ktot) continue;
+      const int kb = k0 + 64 * kh + 32 * j, nbk = n0 + 160 * nh + 32 * t;
+      if (kb >= ktot || nbk >= a.N) continue;
+      const int k = kb + (lane & 31);
       long col = k;                                        // packed (tap-major) K order ...
       if (a.torch_layout) {                                // ... or the parameter's own [N][Cin][taps] layout
         const int tp = k / a.Cin;
         col = (long)(k - tp * a.Cin) * a.taps + tp;
       }
-      const int nb = n0 + 160 * nh + 32 * t + 4 * (lane >> 5);
+      const int nb = nbk + 4 * (lane >> 5);
       if (a.part) {                                        // deterministic: this slab's partial matrix (packed K order, unscaled)
-        float* ps = a.part + (long)bz * a.N * ktot + k;
+        float* ps = a.part + ((long)bz * a.N + nb) * ktot + k;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int n = nb + (e & 3) + 8 * (e >> 2);
-          if (n < a.N) ps[(long)n * ktot] = acc[t][j][e];
-        }
+        for (int e = 0; e < 16; ++e) ps[(long)((e & 3) + 8 * (e >> 2)) * ktot] = acc[t][j][e];
       } else {
+        float* pd = a.dW + (long)nb * ktot + col;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int n = nb + (e & 3) + 8 * (e >> 2);
-          if (n < a.N) atomicAdd(a.dW + (long)n * ktot + col, acc[t][j][e] * a.scale);
-        }
+        for (int e = 0; e < 16; ++e) atomicAdd(pd + (long)((e & 3) + 8 * (e >> 2)) * ktot, acc[t][j][e] * a.scale);
       }
     }
   if (do_bias) {
+    const float s0 = bsum0 + __shfl_xor(bsum0, 32), s1 = bsum1 + __shfl_xor(bsum1, 32);   // the two row halves of a step
+    const int t0 = kh == 0 ? 0 : kh + 1;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const float s = bsum[t] + __shfl_xor(bsum[t], 32);   // the two row halves of the step
+    for (int r = 0; r < 2; ++r) {
+      const int t = r == 0 ? t0 : 1;
       const int n = n0 + 160 * nh + 32 * t + (lane & 31);
-      if (lane < 32 && n < a.N) {
-        if (a.part) a.part[(long)a.slabs * a.N * ktot + (long)bz * a.N + n] = s;
-        else atomicAdd(a.dbias + n, s * a.scale);
+      if ((r == 0 || kh == 0) && lane < 32 && n < a.N) {
+        const float sv = r == 0 ? s0 : s1;
+        if (a.part) a.part[(long)a.slabs * a.N * ktot + (long)bz * a.N + n] = sv;
+        else atomicAdd(a.dbias + n, sv * a.scale);
       }
     }
   }
@@ -291,8 +322,9 @@ bool ctrlv_wgrad_pp_serves(const ctrlv_gemm_desc& d, const void* dY, int ldy) {
   if (((uintptr_t)d.A | (uintptr_t)dY) & 15) return false;
   if (d.M < 1024 || d.M >= (1 << 24)) return false;
   if ((long)d.M * d.lda * 2 >= (1L << 31) || (long)d.M * ldy * 2 >= (1L << 31)) return false;
-  if (d.mode == 1 && (d.H <= 0 || d.Wd <= 0 || d.M % (d.H * d.Wd) != 0)) return false;
-  if (d.mode == 2 && (d.F <= 0 || d.S <= 0 || d.M % (d.F * d.S) != 0)) return false;
+  // (the kernel advances a row's (image row, pixel) / (frame, position) by 32 rows with ONE conditional wrap per axis)
+  if (d.mode == 1 && (d.H <= 0 || d.Wd <= 0 || d.M % (d.H * d.Wd) != 0 || d.H <= kRows / d.Wd + 1)) return false;
+  if (d.mode == 2 && (d.F <= 0 || d.S < kRows || d.M % (d.F * d.S) != 0)) return false;
   return true;
 }
 

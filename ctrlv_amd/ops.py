@@ -49,10 +49,11 @@ def _scratch(device, nbytes, tag):
 
 
 def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=None, temporal=None, dbias=None, scale=1.0,
-               torch_layout=False):
+               torch_layout=False, assign=False):
     """dW[N, taps*cin] (fp32, packed tap-major K order) += scale * dY^T . gather(A) for the forward GEMM of the same
     geometry; dbias[N] (fp32, optional) += scale * column sums of dY.  torch_layout: dW is [N, cin, taps] (the conv
-    parameter's own layout) instead of the packed [N, taps*cin]."""
+    parameter's own layout) instead of the packed [N, taps*cin].  assign (deterministic form only): dW / dbias are
+    written, not accumulated into -- they need no zero fill."""
     _need_gpu(A, "A")
     d = GemmDesc()
     d.A, d.A2 = _p(A), _p(A2)
@@ -71,7 +72,8 @@ def gemm_wgrad(A, dY, dW, *, N, cin, taps=1, mode=0, A2=None, c_split=0, conv=No
         nbytes = lib.ctrlv_gemm_wgrad_scratch_bytes(ctypes.byref(d))
         scratch = _scratch(A.device, nbytes, "wgrad")
     check(lib.ctrlv_gemm_wgrad(ctypes.byref(d), _p(dY), dY.stride(0), _p(dW), _p(dbias), float(scale),
-                               1 if torch_layout else 0, _p(scratch), nbytes, _stream()), "ctrlv_gemm_wgrad")
+                               (1 if torch_layout else 0) | (2 if assign else 0), _p(scratch), nbytes, _stream()),
+          "ctrlv_gemm_wgrad")
     return dW
 
 

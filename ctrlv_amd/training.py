@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as Fn
 
 from . import ops
-from .autograd import (FusedLinear, GatherGemm, GroupNormSiLU, gradient_checkpointing, res_block_train_forward, sinusoid,
+from .autograd import (FusedLinear, GatherGemm, GroupNormSiLU, f32, gradient_checkpointing, res_block_train_forward, sinusoid,
                        transformer_train_forward, zero_conv_train_forward)
 from .models.blocks import TransformerSpatioTemporalModel  # noqa: F401  (documentation anchor)
 
@@ -32,8 +32,8 @@ def clip_embeddings(model, timestep, added_time_ids, B, device):
         t = t.expand(B)
 
     def mlp(e, x):
-        return Fn.linear(Fn.silu(Fn.linear(x, e.linear_1.weight.float(), e.linear_1.bias.float())),
-                         e.linear_2.weight.float(), e.linear_2.bias.float())
+        return Fn.linear(Fn.silu(Fn.linear(x, f32(e.linear_1.weight), f32(e.linear_1.bias))),
+                         f32(e.linear_2.weight), f32(e.linear_2.bias))
 
     emb = mlp(model.time_embedding, sinusoid(t, boc0))
     ids = added_time_ids.to(device=device, dtype=torch.float32)
@@ -43,7 +43,7 @@ def clip_embeddings(model, timestep, added_time_ids, B, device):
 
 
 def _temb_tables(block, emb_s):
-    return [Fn.linear(emb_s, m.time_emb_proj.weight.float(), m.time_emb_proj.bias.float()).contiguous()
+    return [Fn.linear(emb_s, f32(m.time_emb_proj.weight), f32(m.time_emb_proj.bias)).contiguous()
             for m in (block.spatial_res_block, block.temporal_res_block)]
 
 

@@ -320,7 +320,9 @@ int ctrlv_cfg_euler_step(float* latents, const void* noise_pred, int pred_dtype,
  * (the forward's s_acc).
  * scratch (ctrlv_gemm_wgrad_scratch_bytes(fwd) bytes, or NULL): with it the launch is DETERMINISTIC -- the row slabs write
  * fp32 partial matrices with plain stores and a second kernel adds them to dW / dbias in slab order (a single writer per
- * element): the same gradient bits in every run.  Without it the slabs add with fp32 atomics (arrival order). */
+ * element): the same gradient bits in every run.  Without it the slabs add with fp32 atomics (arrival order).
+ * torch_layout bit 1 (value 2; with scratch only): ASSIGN -- dW / dbias = scale * sum instead of +=, their previous contents
+ * are not read (no zero fill in front of the launch). */
 size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* fwd);
 int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* fwd, const void* dY, int ldy, float* dW, float* dbias, float scale,
                      int torch_layout, void* scratch, size_t scratch_bytes, ctrlv_stream_t stream);

@@ -226,6 +226,12 @@ def test_wgrad_lds_dma_kernel(ops, case):
         dW2, db2 = run(False)
         assert torch.equal(dW, dW2) and torch.equal(db, db2)
     assert torch.equal(dbt, db)
+    # assign form (torch_layout bit 1): the previous contents are not read
+    for tl, ref in ((False, ref_p), (True, ref_t)):
+        dWa = torch.full(ref.shape, float("nan"), dtype=torch.float32, device=DEV)
+        dba = torch.full((N,), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_wgrad(A, dY, dWa, dbias=dba, scale=0.5, torch_layout=tl, assign=True, **kw)
+        assert parity_err(dWa, 0.5 * ref, "assign form") < 2e-3 and parity_err(dba, 0.5 * ref_b, "assign form, bias") < 2e-3
 
 
 @pytest.mark.parametrize("C,H,W,n,ips", [(320, 9, 16, 6, 1), (320, 9, 16, 6, 3), (64, 16, 16, 4, 2), (128, 72, 64, 2, 1)])

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--gradient-checkpointing", type=int, default=0,
                     help="1: unet.enable_gradient_checkpointing() + controlnet.enable_gradient_checkpointing() (the GEGLU "
                          "feed-forward intermediates are recomputed in the backward; tools/train_video_controlnet.py:185-186)")
+    ap.add_argument("--mark-steps", type=int, default=0,
+                    help="1: a torch.cuda._sleep kernel in front of every step (tools/trace_last_step.py cuts a rocprofv3 "
+                         "kernel trace at these marks)")
     ap.add_argument("--gpus", type=int, default=0,
                     help="N > 1 without a torchrun environment: start N rank processes (one per GPU) from this GPU-free parent")
     args = ap.parse_args()
@@ -83,6 +86,8 @@ def main():
             dist.barrier()
         t0 = time.time()
         e = [ev() for _ in range(4)]
+        if args.mark_steps:
+            torch.cuda._sleep(2000)
         e[0].record()
         lat, noise, sig = batch["latents"], batch["noise"], batch["sigmas"]
         s5 = sig.reshape(B, 1, 1, 1, 1)

@@ -29,12 +29,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--filter", default="", help="only layers whose name contains this")
     args = ap.parse_args()
     from ctrlv_amd import ops
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     dev = "cuda:0"
     rows, tot = [], 0.0
     for name, M, N, cin, taps, geo in shapes():
+        if args.filter not in name:
+            continue
         A = torch.randn(M, cin, device=dev).to(dt)
         dY = torch.randn(M, N, device=dev).to(dt)
         dW = torch.zeros(N, taps * cin, dtype=torch.float32, device=dev)
