@@ -39,6 +39,7 @@ const ctrlv_debug_t& ctrlv_debug() {
     d.attn_rows = env("CTRLV_ATTN_ROWS", 0);
     d.temporal_fused = env("CTRLV_TEMPORAL_FUSED", 1);
     d.wgrad_pp = env("CTRLV_WGRAD_PP", 1);
+    d.wgrad_slabs = env("CTRLV_WGRAD_SLABS", 0);
     return d;
   }();
   return dbg;

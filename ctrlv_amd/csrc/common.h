@@ -308,6 +308,7 @@ struct ctrlv_debug_t {
   int attn_rows;    // CTRLV_ATTN_ROWS [0]    32 / 64: query rows per wave of the spatial attention (0: by sequence length)
   int temporal_fused;  // CTRLV_TEMPORAL_FUSED [1]  0: q|k|v GEMM + temporal attention + output projection as three launches
   int wgrad_pp;     // CTRLV_WGRAD_PP [1]     0: every weight gradient on the register-staged kernel of backward.hip
+  int wgrad_slabs;  // CTRLV_WGRAD_SLABS [0]  n > 0: that many row slabs per wgrad_pp launch (tools/wgrad_bench.py sweeps)
 };
 const ctrlv_debug_t& ctrlv_debug();
 void ctrlv_set_error(const char* fmt, ...);

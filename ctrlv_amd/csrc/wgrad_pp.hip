@@ -78,6 +78,16 @@ __device__ __forceinline__ void read_step(Frag (&f)[7], unsigned a0, unsigned a1
   TR(f[4].lo, yA, 2 * kPanel + KS * 2048); TR(f[4].hi, yA, 2 * kPanel + KS * 2048 + 1024);
 #undef TR
 }
+// one fragment (two reads) of step KS: I = 5 / 6 the A-operand halves, 0 .. 4 the dY half panels
+template <int KS, int I>
+__device__ __forceinline__ void read_frag(Frag& f, unsigned a0, unsigned a1, unsigned yA, unsigned yB) {
+#define TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+  if constexpr (I == 5) { TR(f.lo, a0, KS * 2048); TR(f.hi, a0, KS * 2048 + 1024); }
+  else if constexpr (I == 6) { TR(f.lo, a1, KS * 2048); TR(f.hi, a1, KS * 2048 + 1024); }
+  else if constexpr ((I & 1) == 0) { TR(f.lo, yA, (I / 2) * kPanel + KS * 2048); TR(f.hi, yA, (I / 2) * kPanel + KS * 2048 + 1024); }
+  else { TR(f.lo, yB, (I / 2) * kPanel + KS * 2048); TR(f.hi, yB, (I / 2) * kPanel + KS * 2048 + 1024); }
+#undef TR
+}
 // wait until at most N LDS operations are outstanding; "defines" the fragment registers, so that no consumer (and no
 // register copy) can be scheduled above it
 template <int N>
@@ -91,11 +101,22 @@ __device__ __forceinline__ elx8 as_elx8(const Frag& f) {
   const i32x4_t v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3);
   return __builtin_bit_cast(elx8, v);
 }
+// sum of a fragment's eight elements: v_dot2c_f32_{bf16,f16} against (1, 1), fp32 accumulate -- 4 instructions
 __device__ __forceinline__ float frag_sum(const Frag& f) {
   float s = 0.f;
   const int w[4] = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s += el_lo_f32((uint32_t)w[i]) + el_hi_f32((uint32_t)w[i]);
+  for (int i = 0; i < 4; ++i) {
+#ifdef CTRLV_ELEM_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, w[i]), ones, s, false);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const b2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, w[i]), ones, s, false);
+#endif
+  }
   return s;
 }
 
@@ -103,6 +124,7 @@ template <int MODE>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  CTRLV_CLOCK_BEGIN();
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lin = xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -224,48 +246,55 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
   asm volatile("s_barrier" ::: "memory");
   Frag f0[7], f1[7];
   read_step<0>(f0, a00, a10, yA0, yB0);
+  // One half chunk: the 10 MFMAs of the fragment set `cur` with the 14 reads of the NEXT set (`nxt`, step KSN at the given
+  // addresses) issued between them, one fragment behind each of the first seven MFMAs -- a wave never sits in a long
+  // read-issue phase with the matrix pipe idle (all eight waves leave the barrier together); sched_barrier pins the order.
+#define WP_HALF(cur, nxt, KSN, A0, A1, YA, YB)                                                                          \
+  do {                                                                                                                  \
+    wait_frags<0>(cur);                                                                                                 \
+    const elx8 b0 = as_elx8(cur[5]), b1 = as_elx8(cur[6]);                                                              \
+    WP_PAIR(cur, nxt, KSN, 0, 5, 6, A0, A1, YA, YB);                                                                    \
+    WP_PAIR(cur, nxt, KSN, 1, 0, 1, A0, A1, YA, YB);                                                                    \
+    WP_PAIR(cur, nxt, KSN, 2, 2, 3, A0, A1, YA, YB);                                                                    \
+    WP_PAIR(cur, nxt, KSN, 3, 4, -1, A0, A1, YA, YB);                                                                   \
+    WP_PAIR(cur, nxt, KSN, 4, -1, -1, A0, A1, YA, YB);                                                                  \
+    if (do_bias) {                                                                                                      \
+      if (kh == 0) { bsum0 += frag_sum(cur[0]); bsum1 += frag_sum(cur[1]); }                                            \
+      else if (kh == 1) bsum0 += frag_sum(cur[2]);                                                                      \
+      else if (kh == 2) bsum0 += frag_sum(cur[3]);                                                                      \
+      else bsum0 += frag_sum(cur[4]);                                                                                   \
+    }                                                                                                                   \
+  } while (0)
+  // the two MFMAs of dY fragment T, the reads of fragments R0 / R1 of the next set behind them
+#define WP_PAIR(cur, nxt, KSN, T, R0, R1, A0, A1, YA, YB)                                                               \
+  do {                                                                                                                  \
+    const elx8 y_ = as_elx8(cur[T]);                                                                                    \
+    if (!(CTRLV_WP_DIAG & 1)) acc[T][0] = mfma_32x32x16(y_, b0, acc[T][0]);                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if constexpr (R0 >= 0) { if (!(CTRLV_WP_DIAG & 4)) read_frag<KSN, (R0 >= 0 ? R0 : 0)>(nxt[R0 >= 0 ? R0 : 0], A0, A1, YA, YB); } \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (!(CTRLV_WP_DIAG & 1)) acc[T][1] = mfma_32x32x16(y_, b1, acc[T][1]);                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if constexpr (R1 >= 0) { if (!(CTRLV_WP_DIAG & 4)) read_frag<KSN, (R1 >= 0 ? R1 : 0)>(nxt[R1 >= 0 ? R1 : 0], A0, A1, YA, YB); } \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  } while (0)
   for (int c = 0; c < nchunks; ++c) {
     const unsigned so = (unsigned)((c & (kSlots - 1)) * kSlot);
-    if (!(CTRLV_WP_DIAG & 4)) read_step<1>(f1, a00 + so, a10 + so, yA0 + so, yB0 + so);
-    wait_frags<14>(f0);
-    if (!(CTRLV_WP_DIAG & 1)) {
-      const elx8 b0 = as_elx8(f0[5]), b1 = as_elx8(f0[6]);
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const elx8 y = as_elx8(f0[t]);
-        acc[t][0] = mfma_32x32x16(y, b0, acc[t][0]);
-        acc[t][1] = mfma_32x32x16(y, b1, acc[t][1]);
-      }
-      if (do_bias) {
-        if (kh == 0) { bsum0 += frag_sum(f0[0]); bsum1 += frag_sum(f0[1]); }
-        else if (kh == 1) bsum0 += frag_sum(f0[2]);
-        else if (kh == 2) bsum0 += frag_sum(f0[3]);
-        else bsum0 += frag_sum(f0[4]);
-      }
-    }
+    WP_HALF(f0, f1, 1, a00 + so, a10 + so, yA0 + so, yB0 + so);
     wait_frags<0>(f1);                                     // every read of chunk c has landed in registers ...
     if (CTRLV_WP_DIAG & 2) wp_wait_vmcnt<0>();
     else if (is_y) wp_wait_vmcnt<10>(); else wp_wait_vmcnt<8>();  // ... and this wave's pieces of chunk c + 1 in LDS
     asm volatile("s_barrier" ::: "memory");
-    if (!(CTRLV_WP_DIAG & 2)) dma(c + 4);                  // slot of chunk c: no wave reads it any more
+    // slot of chunk c: no wave reads it any more.  The two waves of a SIMD (w, w + 4) have different roles: the A wave issues
+    // its pieces (row coordinates, bounds) BEFORE its second MFMA set, the dY wave AFTER -- one wave's address arithmetic
+    // runs under the other's MFMAs instead of both leaving the matrix pipe idle behind the barrier
+    if (!(CTRLV_WP_DIAG & 2) && !is_y) dma(c + 4);
     const unsigned sn = (unsigned)(((c + 1) & (kSlots - 1)) * kSlot);
-    if (!(CTRLV_WP_DIAG & 4)) read_step<0>(f0, a00 + sn, a10 + sn, yA0 + sn, yB0 + sn);
-    if (!(CTRLV_WP_DIAG & 1)) {
-      const elx8 b0 = as_elx8(f1[5]), b1 = as_elx8(f1[6]);
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const elx8 y = as_elx8(f1[t]);
-        acc[t][0] = mfma_32x32x16(y, b0, acc[t][0]);
-        acc[t][1] = mfma_32x32x16(y, b1, acc[t][1]);
-      }
-      if (do_bias) {
-        if (kh == 0) { bsum0 += frag_sum(f1[0]); bsum1 += frag_sum(f1[1]); }
-        else if (kh == 1) bsum0 += frag_sum(f1[2]);
-        else if (kh == 2) bsum0 += frag_sum(f1[3]);
-        else bsum0 += frag_sum(f1[4]);
-      }
-    }
+    WP_HALF(f1, f0, 0, a00 + sn, a10 + sn, yA0 + sn, yB0 + sn);
+    if (!(CTRLV_WP_DIAG & 2) && is_y) dma(c + 4);
   }
+#undef WP_HALF
+#undef WP_PAIR
   wait_frags<0>(f0);                                       // (the reads issued for the chunk behind the last: discarded)
   wp_wait_vmcnt<0>();
 
@@ -308,10 +337,13 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
       }
     }
   }
+  CTRLV_CLOCK_END();
 #endif
 }
 
 }  // namespace
+
+CTRLV_CLOCK_READER(wgrad_pp)
 
 bool ctrlv_wgrad_pp_serves(const ctrlv_gemm_desc& d, const void* dY, int ldy) {
   if (!ctrlv_debug().wgrad_pp) return false;
@@ -348,6 +380,7 @@ void ctrlv_wgrad_pp_plan(const ctrlv_gemm_desc& d, ctrlv_wgrad_pp_plan_t* p) {
     const double t = rounds * (cps * t_chunk + t_tile);
     if (t < best_t * 0.999) { best_t = t; best = s; }
   }
+  if (ctrlv_debug().wgrad_slabs > 0) best = ctrlv_debug().wgrad_slabs < chunks ? ctrlv_debug().wgrad_slabs : chunks;
   const int cps = (chunks + best - 1) / best;
   p->rows_per_slab = cps * kRows;
   p->slabs = (chunks + cps - 1) / cps;

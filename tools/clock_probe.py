@@ -95,6 +95,18 @@ def main():
     probes.append(("temporal_fused C=320 +R1 @72x128", "temporal_fused",
                    lambda: ops.temporal_fused(xt, wf_t, ot, 2, 25, 9216, bias=b2, R1=rt),
                    2.0 * Mt * 320 * 1280 + 4.0 * 2 * 9216 * 5 * 25 * 25 * 64))
+    # weight gradients of the cfg5 training step (csrc/wgrad_pp.hip): L1 3x3 conv 640 -> 640, L0 GEGLU projection
+    Mw = 25 * 36 * 64
+    aw, yw = rnd(Mw, 640), rnd(Mw, 640)
+    dww = torch.zeros(640, 9 * 640, dtype=torch.float32, device=dev)
+    probes.append(("wgrad_pp conv3x3 640->640 @36x64 (25 frames)", "wgrad_pp",
+                   lambda: ops.gemm_wgrad(aw, yw, dww, N=640, cin=640, taps=9, mode=1, conv=(36, 64, 36, 64, 1, 0)),
+                   2.0 * Mw * 640 * 9 * 640))
+    Mg = 25 * 9216
+    ag, yg = rnd(Mg, 320), rnd(Mg, 2560)
+    dwg = torch.zeros(2560, 320, dtype=torch.float32, device=dev)
+    probes.append(("wgrad_pp GEGLU 320->2560 @72x128 (25 frames)", "wgrad_pp",
+                   lambda: ops.gemm_wgrad(ag, yg, dwg, N=2560, cin=320), 2.0 * Mg * 2560 * 320))
     # spatial attention at S = 9216 (the 64-rows-per-wave kernel), pre-scaled q
     qkv, ao = rnd(10 * 9216, 960), torch.empty(10 * 9216, 320, dtype=torch.bfloat16, device=dev)
     probes.append(("attn_spatial64 S=9216, 10 images x 5 heads", "attention",
