@@ -246,6 +246,17 @@ __device__ __forceinline__ float geglu_tab_finish(float a, float g, float fr, fl
   return a * (g * phi);
 }
 
+// acc + a.x + a.y for a packed element pair: v_dot2c_f32_{bf16,f16} against (1, 1) -- one full-rate instruction for two
+// fp32 adds (row sums of packed probabilities / gradients beside MFMAs)
+typedef __attribute__((ext_vector_type(2))) el_native_t elx2n;
+__device__ __forceinline__ float el_pair_sum(elx2n a, float acc) {
+  const elx2n ones = {(el_native_t)1.0f, (el_native_t)1.0f};
+#ifdef CTRLV_ELEM_F16
+  return __builtin_amdgcn_fdot2(a, ones, acc, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(a, ones, acc, false);
+#endif
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -101,22 +101,12 @@ __device__ __forceinline__ elx8 as_elx8(const Frag& f) {
   const i32x4_t v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3);
   return __builtin_bit_cast(elx8, v);
 }
-// sum of a fragment's eight elements: v_dot2c_f32_{bf16,f16} against (1, 1), fp32 accumulate -- 4 instructions
+// sum of a fragment's eight elements: four v_dot2c against (1, 1) (common.h el_pair_sum), fp32 accumulate
 __device__ __forceinline__ float frag_sum(const Frag& f) {
   float s = 0.f;
   const int w[4] = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#ifdef CTRLV_ELEM_F16
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
-    const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
-    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, w[i]), ones, s, false);
-#else
-    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
-    const b2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, w[i]), ones, s, false);
-#endif
-  }
+  for (int i = 0; i < 4; ++i) s = el_pair_sum(__builtin_bit_cast(elx2n, w[i]), s);
   return s;
 }
 

@@ -139,3 +139,43 @@ def test_temporal_fused_register_budget():
                 for b in blocks:
                     if sum("v_mfma" in ln for ln in b) >= 8:
                         assert not [ln for ln in b if "scratch_" in ln], k[:80]
+
+
+def test_wgrad_pp_register_budget():
+    """The LDS-DMA weight-gradient kernel (csrc/wgrad_pp.hip): 160 accumulator registers + two fragment sets of 28 at two
+    waves per SIMD (512 threads, 144 KiB of LDS: one workgroup per CU).  No spill in any of the three gather instantiations,
+    for either element type, and the interleave of the loop survives: between two MFMAs of the K loop there are at most four
+    transposed LDS reads (a long read-issue phase in front of the MFMAs is what the sched_barriers are there to prevent)."""
+    procs = []
+    with tempfile.TemporaryDirectory() as td:
+        for defs in ([], ["-DCTRLV_ELEM_F16=1"]):
+            asm = os.path.join(td, "wp" + ("16" if defs else "") + ".s")
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                   "-Rpass-analysis=kernel-resource-usage", *defs, os.path.join(CSRC, "wgrad_pp.hip"), "-o", asm]
+            procs.append((defs, asm, subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)))
+        for defs, asm, p in procs:
+            err = p.communicate()[1]
+            assert p.returncode == 0, err[-2000:]
+            names = re.findall(r"Function Name: (\S+)", err)
+            vg = [int(x) for x in re.findall(r" VGPRs: (\d+)", err)]
+            sp = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", err)]
+            scr = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
+            occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", err)]
+            kern = [(n, v, s, c, o) for n, v, s, c, o in zip(names, vg, sp, scr, occ) if "wgrad_pp_kernel" in n]
+            assert len(kern) == 3, (defs, names)                         # linear / 3x3 / temporal gather
+            for n, v, s, c, o in kern:
+                assert v <= 256 and o >= 2 and s == 0 and c == 0, (n, v, s, c, o)
+            text = open(asm).read()
+            for k in re.split(r"\n(?=_ZN\S*wgrad_pp_kernel\S*:)", text)[1:]:
+                body = k.split("s_endpgm")[0]
+                assert body.count("v_mfma") == 20                        # one chunk: two sets of 5 x 2
+                run, worst, seen = 0, 0, False
+                for ln in body.split("\n"):
+                    if "v_mfma" in ln:
+                        seen, run = True, 0
+                    elif "ds_read_b64_tr_b16" in ln and seen:
+                        run += 1
+                        worst = max(worst, run)
+                    elif "s_barrier" in ln or "s_cbranch" in ln:
+                        seen, run = False, 0
+                assert 2 <= worst <= 4, worst
