@@ -142,6 +142,10 @@ SIGNATURES = {
     "ctrlv_groupnorm_bwd_scratch_floats": (c_int, [c_int, c_int, c_int, c_int]),
     "ctrlv_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctrlv_groupnorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctrlv_layernorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctrlv_layernorm_bwd_scratch_floats": (ctypes.c_size_t, [c_int, c_int]),
     "ctrlv_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -182,7 +186,7 @@ def _status_recorder(lib, fn):
         return rc
     call.__name__ = getattr(fn, "__name__", "ctrlv_fn")
     return call
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class CtrlvHipError(RuntimeError):

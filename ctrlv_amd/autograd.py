@@ -34,6 +34,7 @@ def _rows(M, C, like):
 # call clear_pack_cache() after editing a frozen model that way.)
 _PACK_CACHE = {}
 _WGRAD_DIRECT = os.environ.get("CTRLV_WGRAD_DIRECT", "0") == "1"     # conv dW straight in [N, cin, taps] (A/B handle)
+_SKIP_FUSE = os.environ.get("CTRLV_SKIP_FUSE", "1") != "0"           # 0: autograd sums the skip gradients itself (A/B handle)
 
 
 def clear_pack_cache():
@@ -210,28 +211,39 @@ def gemm_grads(A, weight, dY, geom, s_acc, need_dA=True, need_dW=True, need_db=T
 
 
 class GroupNormSiLU(torch.autograd.Function):
-    """y = [silu](GroupNorm32(x)) on channels-last rows; imgs_per_stat = 1 (4-D) or F (5-D statistics)."""
+    """y = [silu](GroupNorm32(x)) on channels-last rows; imgs_per_stat = 1 (4-D) or F (5-D statistics).
+    skip=True: returns (y, x_skip) -- x_skip is x again, to be used by the SKIP connection around the branch this norm opens
+    (the residual operand of the branch's last GEMM).  Both gradients of x then arrive in THIS backward, and the norm's
+    backward kernel adds the skip's while it writes dx (ctrlv_groupnorm_bwd_add) instead of autograd summing the two in a
+    separate pass over both tensors (181 such sums, 6.7 ms of the cfg5 step)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, n_img, S, imgs_per_stat, eps, silu):
+    def forward(ctx, x, gamma, beta, n_img, S, imgs_per_stat, eps, silu, *opt):
+        skip = bool(opt[0]) if opt else False
+        ctx.n_opt = len(opt)
         C = x.shape[1]
         part = torch.empty(ops.groupnorm_scratch_floats(n_img, S, C, imgs_per_stat), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         g32, b32 = f32(gamma).detach().contiguous(), f32(beta).detach().contiguous()
         ops.groupnorm(x, None, n_img, S, C, imgs_per_stat, g32, b32, eps, silu, y, part)
         ctx.save_for_backward(x, g32, b32, part)
-        ctx.cfg = (n_img, S, C, imgs_per_stat, silu, gamma.dtype)
-        return y
+        ctx.cfg = (n_img, S, C, imgs_per_stat, silu, gamma.dtype, bool(skip))
+        ctx.set_materialize_grads(False)
+        return (y, x) if skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, g32, b32, part = ctx.saved_tensors
-        n_img, S, C, ips, silu, pdt = ctx.cfg
+        n_img, S, C, ips, silu, pdt, skip = ctx.cfg
+        tail = (None,) * (5 + ctx.n_opt)
+        if dy is None:                    # (only the skip connection carried a gradient)
+            return (dskip, None, None) + tail
         dx = torch.empty_like(x)
         dg = torch.zeros(C, dtype=torch.float32, device=x.device)
         db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        ops.groupnorm_bwd(x, dy.contiguous(), n_img, S, C, ips, part, g32, b32, silu, dx, dg, db)
-        return dx, dg.to(pdt), db.to(pdt), None, None, None, None, None
+        ops.groupnorm_bwd(x, dy.contiguous(), n_img, S, C, ips, part, g32, b32, silu, dx, dg, db,
+                          add=None if dskip is None else dskip.contiguous())
+        return (dx, dg.to(pdt), db.to(pdt)) + tail
 
 
 _MIX_CACHE = {}      # id(mix_factor parameter) -> (version, sigmoid value); filled by prefetch_mix_factors()
@@ -289,31 +301,43 @@ class BlendGemm(torch.autograd.Function):
 
 class LayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x [+ V[(m // vdiv) % vmod]]) over the channel axis (eps 1e-5); V = the frame positional embedding
-    table of TransformerSpatioTemporalModel (fp32 [F, C]) or None."""
+    table of TransformerSpatioTemporalModel (fp32 [F, C]) or None.  skip=True: returns (y, x_skip), see GroupNormSiLU."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, V, vdiv, vmod):
+    def forward(ctx, x, gamma, beta, V, vdiv, vmod, *opt):
+        skip = bool(opt[0]) if opt else False
+        ctx.n_opt = len(opt)
         y = torch.empty_like(x)
         g32, b32 = f32(gamma).detach().contiguous(), f32(beta).detach().contiguous()
         ops.layernorm(x, g32, b32, 1e-5, y, V=V, vdiv=vdiv, vmod=vmod)
         ctx.save_for_backward(x, g32, V if V is not None else torch.empty(0, device=x.device))
         ctx.cfg = (V is not None, vdiv, vmod, gamma.dtype)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x) if skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, g32, V = ctx.saved_tensors
         has_v, vdiv, vmod, pdt = ctx.cfg
+        tail = (None,) * (2 + ctx.n_opt)
+        if dy is None:
+            return (dskip, None, None, None) + tail
         C = x.shape[1]
         dx = torch.empty_like(x)
         dg = torch.zeros(C, dtype=torch.float32, device=x.device)
         db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        ops.layernorm_bwd(x, dy.contiguous(), g32, 1e-5, dx, dg, db, V=V if has_v else None, vdiv=vdiv, vmod=vmod)
         dV = None
         if has_v and ctx.needs_input_grad[3]:
+            # (the table's gradient is the column sum of the NORM's dx: without the skip gradient)
+            ops.layernorm_bwd(x, dy.contiguous(), g32, 1e-5, dx, dg, db, V=V, vdiv=vdiv, vmod=vmod)
             dV = torch.zeros_like(V)
             ops.colsum(dx, dV, vmode=1, vdiv=vdiv, vmod=vmod)
-        return dx, dg.to(pdt), db.to(pdt), dV, None, None
+            if dskip is not None:
+                dx = dx + dskip
+        else:
+            ops.layernorm_bwd(x, dy.contiguous(), g32, 1e-5, dx, dg, db, V=V if has_v else None, vdiv=vdiv, vmod=vmod,
+                              add=None if dskip is None else dskip.contiguous())
+        return (dx, dg.to(pdt), db.to(pdt), dV) + tail
 
 
 # ---- gradient checkpointing of the GEGLU feed-forwards (`enable_gradient_checkpointing()`, reference:
@@ -471,15 +495,22 @@ def res_block_train_forward(block, x, temb_tables, B, F, H, W):
     N, S = B * F, H * W
     g2d = dict(mode=1, conv=(H, W, H, W, 1, 0), vdiv=F * S)
     g3d = dict(mode=2, temporal=(F, S), vdiv=F * S)
-    xn = GroupNormSiLU.apply(x, s.norm1.weight, s.norm1.bias, N, S, 1, block.eps, True)
+    # (x and xs each feed a norm AND the skip connection around the branch it opens: the norm hands the skip its alias, so
+    #  that both gradients meet in the norm's backward kernel -- GroupNormSiLU, skip=True)
+    if s.conv_shortcut is None and _SKIP_FUSE:
+        xn, res = GroupNormSiLU.apply(x, s.norm1.weight, s.norm1.bias, N, S, 1, block.eps, True, True)
+    else:
+        xn, res = GroupNormSiLU.apply(x, s.norm1.weight, s.norm1.bias, N, S, 1, block.eps, True), x
     h = GatherGemm.apply(xn, s.conv1.weight, s.conv1.bias, None, temb_tables[0], 1.0, g2d)
     hn = GroupNormSiLU.apply(h, s.norm2.weight, s.norm2.bias, N, S, 1, block.eps, True)
-    res = x
     if s.conv_shortcut is not None:
         res = GatherGemm.apply(x, s.conv_shortcut.weight.reshape(block.cout, block.cin), s.conv_shortcut.bias, None, None,
                                1.0, dict(mode=0))
     xs = GatherGemm.apply(hn, s.conv2.weight, s.conv2.bias, res, None, 1.0, g2d)
-    hn = GroupNormSiLU.apply(xs, t.norm1.weight, t.norm1.bias, N, S, F, block.eps, True)
+    if _SKIP_FUSE:
+        hn, xs = GroupNormSiLU.apply(xs, t.norm1.weight, t.norm1.bias, N, S, F, block.eps, True, True)
+    else:
+        hn = GroupNormSiLU.apply(xs, t.norm1.weight, t.norm1.bias, N, S, F, block.eps, True)
     h = GatherGemm.apply(hn, t.conv1.weight, t.conv1.bias, None, temb_tables[1], 1.0, g3d)
     hn = GroupNormSiLU.apply(h, t.norm2.weight, t.norm2.bias, N, S, F, block.eps, True)
     return BlendGemm.apply(hn, t.conv2.weight, t.conv2.bias, xs, block.time_mixer.mix_factor, g3d)
@@ -647,35 +678,47 @@ def transformer_train_forward(tr, x, ehs, B, F, H, W, time_context_order="sb"):
                     f32(tpe.linear_2.bias)).contiguous()                                   # fp32 [F, C]
     big = 1 << 30
 
-    def ln(h, n, V=None, vdiv=1, vmod=big):
-        return LayerNormFn.apply(h, n.weight, n.bias, V, vdiv, vmod)
+    def lns(h, n, V=None, vdiv=1, vmod=big):             # (normed rows, the alias of h for the skip connection)
+        if not _SKIP_FUSE:
+            return LayerNormFn.apply(h, n.weight, n.bias, V, vdiv, vmod), h
+        return LayerNormFn.apply(h, n.weight, n.bias, V, vdiv, vmod, True)
 
     def qkv_w(attn):
         return _frozen(attn.to_q.weight, "qkv_cat", lambda: torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0))
 
-    t = GroupNormSiLU.apply(x, tr.norm.weight, tr.norm.bias, N, S, 1, 1e-6, False)
+    # Every trunk tensor (x, h0, h1, h2, g0, g1) feeds the norm that opens a branch AND the skip connection around it: the norm
+    # hands the skip its alias (skip=True), so both gradients meet in the norm's backward kernel instead of a separate sum.
+    if _SKIP_FUSE:
+        t, x = GroupNormSiLU.apply(x, tr.norm.weight, tr.norm.bias, N, S, 1, 1e-6, False, True)
+    else:
+        t = GroupNormSiLU.apply(x, tr.norm.weight, tr.norm.bias, N, S, 1, 1e-6, False)
     h0 = FusedLinear.apply(t, tr.proj_in.weight, tr.proj_in.bias, None, None, None, {})
     # ---- spatial BasicTransformerBlock
-    qkv = FusedLinear.apply(ln(h0, sb.norm1), qkv_w(sb.attn1), None, None, None, None, {})
+    n, h0 = lns(h0, sb.norm1)
+    qkv = FusedLinear.apply(n, qkv_w(sb.attn1), None, None, None, None, {})
     a = SpatialAttention.apply(qkv, N, S, C)
     h1 = FusedLinear.apply(a, sb.attn1.to_out[0].weight, sb.attn1.to_out[0].bias, h0, None, xvec(sb.attn2),
                            dict(vdiv=F * S))
     with _ff_region():
-        u = GegluProj.apply(ln(h1, sb.norm3), sb.ff.net[0].proj.weight, sb.ff.net[0].proj.bias)
+        n, h1 = lns(h1, sb.norm3)
+        u = GegluProj.apply(n, sb.ff.net[0].proj.weight, sb.ff.net[0].proj.bias)
         h2 = FusedLinear.apply(u, sb.ff.net[2].weight, sb.ff.net[2].bias, h1, None, None, {})
     del u
     # ---- temporal block: rows stay ordered (b, f, s); the frame embedding is added inside the consumers
     with _ff_region():
-        u = GegluProj.apply(ln(h2, tb.norm_in, emb, S, F), tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias)
+        n, h2 = lns(h2, tb.norm_in, emb, S, F)
+        u = GegluProj.apply(n, tb.ff_in.net[0].proj.weight, tb.ff_in.net[0].proj.bias)
         g0 = FusedLinear.apply(u, tb.ff_in.net[2].weight, tb.ff_in.net[2].bias, h2, None, emb, dict(vdiv=S, vmod=F))
     del u
-    qkv = FusedLinear.apply(ln(g0, tb.norm1), qkv_w(tb.attn1), None, None, None, None, {})
+    n, g0 = lns(g0, tb.norm1)
+    qkv = FusedLinear.apply(n, qkv_w(tb.attn1), None, None, None, None, {})
     a = TemporalAttention.apply(qkv, B, F, S, C)
     g1 = FusedLinear.apply(a, tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, g0, None, xvec(tb.attn2),
                            dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if quirk else dict(vdiv=F * S))
     with _ff_region():
-        u = GegluProj.apply(ln(g1, tb.norm3), tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
+        n, g1 = lns(g1, tb.norm3)
+        u = GegluProj.apply(n, tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias)
         h3 = BlendLinear.apply(u, tb.ff.net[2].weight, tb.ff.net[2].bias, g1, h2, tr.time_mixer.mix_factor)
-    del u
+    del u, n
     return FusedLinear.apply(h3, tr.proj_out.weight, tr.proj_out.bias, x, None, None, {})
 

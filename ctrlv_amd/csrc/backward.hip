@@ -489,11 +489,12 @@ __global__ __launch_bounds__(256) void affine_fold_kernel(const float* __restric
   out0[c] += a;
   out1[c] += b;
 }
-// pass 3: dx = rstd * (dz * gamma - m1 - xhat * m2)
+// pass 3: dx = rstd * (dz * gamma - m1 - xhat * m2)  [+ add: the gradient arriving at x through its OTHER consumer -- the
+// skip connection around the branch this norm opens -- summed here instead of in a separate pass over both tensors]
 __global__ void gn_bwd_apply_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, GnB s,
                                     const float* __restrict__ stats, const float* __restrict__ gmean,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                    el_t* __restrict__ dx) {
+                                    const el_t* __restrict__ add, el_t* __restrict__ dx) {
   const int CV = s.C / 8, RPP = blockDim.x / CV;
   const int tid = threadIdx.x, col = tid % CV, rsub = tid / CV;
   const int n = blockIdx.y, chunk = blockIdx.x, stat = n / s.ips, cpg = s.C / 32, c0 = col * 8;
@@ -520,6 +521,12 @@ __global__ void gn_bwd_apply_kernel(const el_t* __restrict__ x, const el_t* __re
       const float dz = silu ? fd[e] * dsilu(xh * g[e] + b[e]) : fd[e];
       fx[e] = rstd[e] * (dz * g[e] - m1[e] - xh * m2[e]);
     }
+    if (add) {
+      float fa[8];
+      unpack_elx8(*(const uint4*)(add + row * s.C + c0), fa);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fx[e] += fa[e];
+    }
     *(uint4*)(dx + row * s.C + c0) = pack_elx8(fx);
   }
 }
@@ -533,8 +540,8 @@ __global__ void gn_bwd_apply_kernel(const el_t* __restrict__ x, const el_t* __re
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const el_t* __restrict__ x, const el_t* __restrict__ dy, int M, int C,
                                                      const float* __restrict__ gamma, float eps, const float* __restrict__ V,
-                                                     int vdiv, int vmod, int ldv, el_t* __restrict__ dx,
-                                                     float* __restrict__ part) {
+                                                     int vdiv, int vmod, int ldv, const el_t* __restrict__ add,
+                                                     el_t* __restrict__ dx, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int CV = C >> 3;
   float g[NV][8], ag[NV][8], ab[NV][8];
@@ -600,6 +607,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const el_t* __restrict__ x,
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (fd[k][e] * g[k][e] - m1 - fx[k][e] * m2);
+        if (add) {                                           // (the skip connection's gradient: see gn_bwd_apply_kernel)
+          float fa[8];
+          unpack_elx8(*(const uint4*)(add + m * C + cv * 8), fa);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += fa[e];
+        }
         *(uint4*)(dx + m * C + cv * 8) = pack_elx8(o);
       }
     }
@@ -676,6 +689,11 @@ extern "C" size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C) {
 extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V,
                                    int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch,
                                    ctrlv_stream_t stream) {
+  return ctrlv_layernorm_bwd_add(x, dy, nullptr, M, C, gamma, eps, V, vdiv, vmod, ldv, dx, dgamma, dbeta, scratch, stream);
+}
+extern "C" int ctrlv_layernorm_bwd_add(const void* x, const void* dy, const void* add, int M, int C, const float* gamma, float eps,
+                                       const float* V, int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta,
+                                       float* scratch, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && scratch, "layernorm_bwd: null pointer");
   CTRLV_CHECK_SHAPE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm_bwd: C=%d must be a multiple of 8, <= 2048", C);
   if (V) CTRLV_CHECK_ARG(vdiv > 0 && vmod > 0 && ldv >= C, "layernorm_bwd: bad row-vector table");
@@ -684,7 +702,7 @@ extern "C" int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, 
   hipStream_t st = (hipStream_t)stream;
 #define LNB_LAUNCH(NV)                                                                                                  \
   hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, (const el_t*)dy, M, C, \
-                     gamma, eps, V, vdiv, vmod, ldv, (el_t*)dx, scratch)
+                     gamma, eps, V, vdiv, vmod, ldv, (const el_t*)add, (el_t*)dx, scratch)
   switch (nv) {
     case 1: LNB_LAUNCH(1); break;
     case 2: LNB_LAUNCH(2); break;
@@ -855,6 +873,12 @@ extern "C" int ctrlv_groupnorm_bwd_scratch_floats(int n_img, int S, int C, int i
 extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, int imgs_per_stat,
                                    const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,
                                    float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream) {
+  return ctrlv_groupnorm_bwd_add(x, dy, nullptr, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, silu, dx, dgamma, dbeta,
+                                 scratch, stream);
+}
+extern "C" int ctrlv_groupnorm_bwd_add(const void* x, const void* dy, const void* add, int n_img, int S, int C, int imgs_per_stat,
+                                       const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,
+                                       float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && dy && fwd_partials && gamma && beta && dx && dgamma && dbeta && scratch, "groupnorm_bwd: null pointer");
   const int chunks = ctrlv_groupnorm_chunks(n_img, S, C, imgs_per_stat);
   if (chunks < 0) return chunks;
@@ -882,7 +906,7 @@ extern "C" int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int
   }
   CTRLV_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, n_img), dim3(nt), 0, st, (const el_t*)x, (const el_t*)dy, s, stats,
-                     gmean, gamma, beta, silu, (el_t*)dx);
+                     gmean, gamma, beta, silu, (const el_t*)add, (el_t*)dx);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

@@ -122,27 +122,29 @@ def dot_diff(dy, p, q, out, scale=1.0):
     return out
 
 
-def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, silu, dx, dgamma, dbeta):
+def groupnorm_bwd(x, dy, n_img, S, C, imgs_per_stat, fwd_partials, gamma, beta, silu, dx, dgamma, dbeta, add=None):
+    """add (rows like dy, optional): dx = (norm backward) + add -- the gradient of the skip connection around the branch the norm
+    opens, summed in the same pass (ctrlv_groupnorm_bwd_add)."""
     _need_gpu(x, "x")
     lib = _L(x)
     n = lib.ctrlv_groupnorm_bwd_scratch_floats(n_img, S, C, imgs_per_stat)
     if n < 0:
         check(n, "ctrlv_groupnorm_bwd_scratch_floats")
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)
-    check(lib.ctrlv_groupnorm_bwd(_p(x), _p(dy), n_img, S, C, imgs_per_stat, _p(fwd_partials), _p(gamma), _p(beta),
-                                  1 if silu else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch), _stream()),
-          "ctrlv_groupnorm_bwd")
+    check(lib.ctrlv_groupnorm_bwd_add(_p(x), _p(dy), _p(add), n_img, S, C, imgs_per_stat, _p(fwd_partials), _p(gamma), _p(beta),
+                                      1 if silu else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch), _stream()),
+          "ctrlv_groupnorm_bwd_add")
     return dx
 
 
-def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 << 30):
+def layernorm_bwd(x, dy, gamma, eps, dx, dgamma, dbeta, V=None, vdiv=1, vmod=1 << 30, add=None):
     _need_gpu(x, "x")
     M, C = x.shape
     lib = _L(x)
     scratch = torch.empty(lib.ctrlv_layernorm_bwd_scratch_floats(M, C), dtype=torch.float32, device=x.device)
-    check(lib.ctrlv_layernorm_bwd(_p(x), _p(dy), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
-                                  V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch),
-                                  _stream()), "ctrlv_layernorm_bwd")
+    check(lib.ctrlv_layernorm_bwd_add(_p(x), _p(dy), _p(add), M, C, _p(gamma), eps, _p(V), vdiv, vmod,
+                                      V.stride(0) if V is not None else 0, _p(dx), _p(dgamma), _p(dbeta), _p(scratch),
+                                      _stream()), "ctrlv_layernorm_bwd_add")
     return dx
 
 

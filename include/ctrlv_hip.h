@@ -352,6 +352,12 @@ int ctrlv_groupnorm_bwd_scratch_floats(int n_img, int S, int C, int imgs_per_sta
 int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, int imgs_per_stat,
                         const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,
                         float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
+/* ... + add (element rows like dy, or NULL): dx = (norm backward) + add in the same pass.  x feeds the norm that opens a
+ * residual branch AND the skip connection around it; `add` is the gradient that arrives through the skip (what autograd would
+ * otherwise sum in a separate pass over both tensors: 181 such sums per cfg5 step).  ABI 19. */
+int ctrlv_groupnorm_bwd_add(const void* x, const void* dy, const void* add, int n_img, int S, int C, int imgs_per_stat,
+                            const float* fwd_partials, const float* gamma, const float* beta, int silu, void* dx,
+                            float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
 
 /* LayerNorm backward over [M, C] rows (optionally of x + V[(m / vdiv) % vmod], as the forward): dx bf16; dgamma / dbeta
  * fp32 [C], ACCUMULATED; scratch = ctrlv_layernorm_bwd_scratch_floats(M, C) floats (per-wave column partials, folded by a
@@ -359,6 +365,10 @@ int ctrlv_groupnorm_bwd(const void* x, const void* dy, int n_img, int S, int C, 
 size_t ctrlv_layernorm_bwd_scratch_floats(int M, int C);
 int ctrlv_layernorm_bwd(const void* x, const void* dy, int M, int C, const float* gamma, float eps, const float* V, int vdiv,
                         int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch, ctrlv_stream_t stream);
+/* ... + add: as ctrlv_groupnorm_bwd_add.  ABI 19. */
+int ctrlv_layernorm_bwd_add(const void* x, const void* dy, const void* add, int M, int C, const float* gamma, float eps,
+                            const float* V, int vdiv, int vmod, int ldv, void* dx, float* dgamma, float* dbeta, float* scratch,
+                            ctrlv_stream_t stream);
 /* GEGLU backward.  raw: the projection output [M, 2I] bf16 in the packed (16 value, 16 gate) column-block order, i.e.
  * ctrlv_gemm on the GEGLU-packed weight with geglu = 0; du: [M, I] bf16; draw: [M, 2I] bf16, same layout as raw. */
 int ctrlv_geglu_bwd(const void* raw, const void* du, size_t M, int I, void* draw, ctrlv_stream_t stream);

@@ -283,6 +283,61 @@ def test_layernorm_backward(ops, C, with_v):
         assert parity_err(Vd.grad, V.grad, "LN dV (frame embedding)") < 4e-3
 
 
+@pytest.mark.parametrize("C,with_v", [(64, False), (320, True), (320, False), (1280, False)])
+def test_norm_backward_adds_the_skip_gradient(ops, C, with_v):
+    """skip=True (ctrlv_layernorm_bwd_add / ctrlv_groupnorm_bwd_add): the norm also returns its input for the skip connection
+    around the branch; both gradients of x arrive in the norm's backward and its kernel adds the skip's while it writes dx.
+    Against torch.autograd on y = norm(x) * a + x * b, and against the unfused form (two autograd outputs summed by torch):
+    the fused sum rounds once (fp32 add, one 16-bit rounding) where the unfused rounds dx first."""
+    from ctrlv_amd.autograd import GroupNormSiLU, LayerNormFn
+    n, S = 4, 150
+    M, Fr = n * S, 2
+    x = bf(torch.randn(M, C, generator=g(1)) * 1.3 + 0.2)
+    w1, w2 = bf(torch.randn(M, C, generator=g(2))), bf(torch.randn(M, C, generator=g(3)))
+    gamma = torch.randn(C, generator=g(4))
+    beta = torch.randn(C, generator=g(5))
+    V = torch.randn(Fr, C, generator=g(6)) if with_v else None
+    for kind in ("ln", "gn"):
+        if kind == "gn" and with_v:
+            continue
+        xr = x.float().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        if kind == "ln":
+            xin = xr + V[(torch.arange(M) // (S * n // Fr)) % Fr] if with_v else xr
+            yr = F.layer_norm(xin, (C,), gr, br, 1e-5)
+        else:
+            yr = F.silu(F.group_norm(nchw(xr, n, 10, 15), 32, gr, br, 1e-5))
+            yr = rows(yr)
+        ((yr * w1.float()).sum() + (xr * w2.float()).sum()).backward()
+        res = {}
+        for fused in (True, False):
+            xd = x.to(DEV).requires_grad_(True)
+            gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+            Vd = V.to(DEV).requires_grad_(True) if with_v else None
+            if kind == "ln":
+                args = (xd, gd, bd, Vd, S * n // Fr, Fr if with_v else 1 << 30)
+                y, xs = LayerNormFn.apply(*args, True) if fused else (LayerNormFn.apply(*args), xd)
+            else:
+                args = (xd, gd, bd, n, S, 1, 1e-5, True)
+                y, xs = GroupNormSiLU.apply(*args, True) if fused else (GroupNormSiLU.apply(*args), xd)
+            torch.autograd.backward([y, xs], [w1.to(DEV), w2.to(DEV)])
+            res[fused] = (xd.grad, gd.grad, bd.grad, None if Vd is None else Vd.grad)
+            assert parity_err(xd.grad, xr.grad, f"{kind} dx + skip, fused={fused}") < 4e-3
+            assert parity_err(gd.grad, gr.grad, "dgamma") < 2e-3 and parity_err(bd.grad, br.grad, "dbeta") < 2e-3
+        assert parity_err(res[True][0], res[False][0], "fused vs unfused") < 4e-3
+        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+        if with_v:
+            assert torch.equal(res[True][3], res[False][3])
+        # only the skip connection carries a gradient: passed through untouched
+        xd = x.to(DEV).requires_grad_(True)
+        if kind == "ln":
+            y, xs = LayerNormFn.apply(xd, gamma.to(DEV), beta.to(DEV), None, 1, 1 << 30, True)
+        else:
+            y, xs = GroupNormSiLU.apply(xd, gamma.to(DEV), beta.to(DEV), n, S, 1, 1e-5, True, True)
+        xs.backward(w2.to(DEV))
+        assert torch.equal(xd.grad, w2.to(DEV))
+
+
 @pytest.mark.parametrize("C", [64, 320])
 def test_geglu_feedforward_backward(ops, C):
     """GEGLU projection + output Linear (diffusers FeedForward) through GegluProj / GatherGemm vs torch.autograd."""
