@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // form arrive in a different order every time).  Also does the [N][Cin][taps] scatter of torch_layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int N, long ktot, int Cin,
                                                            int taps, int torch_layout, float scale, float* __restrict__ dW,
-                                                           float* __restrict__ dbias, int assign) {
+                                                           float* __restrict__ dbias, int assign, int bias_rows) {
   const long k4 = ktot >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx < (long)N * k4) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (dbias && idx < N) {
     const float* pb = part + (long)slabs * N * ktot;
     float t = 0.f;
-    for (int sidx = 0; sidx < slabs; ++sidx) t += pb[(long)sidx * N + idx];
+    for (int sidx = 0; sidx < bias_rows; ++sidx) t += pb[(long)sidx * N + idx];      // (wgrad_pp: one row per (slab, k tile))
     dbias[idx] = (assign ? 0.f : dbias[idx]) + t * scale;
   }
 }
@@ -750,12 +750,14 @@ extern "C" size_t ctrlv_gemm_wgrad_scratch_bytes(const ctrlv_gemm_desc* dp) {
   int slabs = wgrad_slabs(*dp, &rps);
   ctrlv_gemm_desc probe = *dp;
   if (!probe.A) probe.A = (const void*)16;
+  size_t bias_rows = (size_t)slabs;
   if (ctrlv_wgrad_pp_serves(probe, (const void*)16, 8)) {
     ctrlv_wgrad_pp_plan_t p;
     ctrlv_wgrad_pp_plan(*dp, &p);
     if (p.slabs > slabs) slabs = p.slabs;
+    if ((size_t)p.slabs * p.ktiles > bias_rows) bias_rows = (size_t)p.slabs * p.ktiles;     // (bias partials per (slab, k tile))
   }
-  return (size_t)slabs * ((size_t)dp->N * dp->taps * dp->Cin + dp->N) * sizeof(float);
+  return ((size_t)slabs * (size_t)dp->N * dp->taps * dp->Cin + bias_rows * dp->N) * sizeof(float);
 }
 
 extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int ldy, float* dW, float* dbias, float scale,
@@ -791,10 +793,12 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
     CTRLV_CHECK_SHAPE((d.taps * d.Cin) % 4 == 0, "gemm_wgrad: K must be a multiple of 4");
     a.part = (float*)scratch;
   }
+  int bias_rows = slabs;
   if (ctrlv_wgrad_pp_serves(d, dY, ldy)) {        // the LDS-DMA kernel (wgrad_pp.hip): same partial layout, its own slab count
     ctrlv_wgrad_pp_plan_t p;
     ctrlv_wgrad_pp_plan(d, &p);
     slabs = p.slabs;
+    bias_rows = p.slabs * p.ktiles;
     const int rc = ctrlv_wgrad_pp_launch(d, dY, ldy, dW, dbias, scale, torch_layout, a.part, p, stream);
     if (rc != CTRLV_OK) return rc;
   } else {
@@ -804,7 +808,7 @@ extern "C" int ctrlv_gemm_wgrad(const ctrlv_gemm_desc* dp, const void* dY, int l
   if (a.part) {
     const long ktot = (long)d.taps * d.Cin, n_thr = (long)d.N * (ktot >> 2);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, slabs,
-                       d.N, ktot, d.Cin, d.taps, torch_layout, scale, dW, dbias, assign);
+                       d.N, ktot, d.Cin, d.taps, torch_layout, scale, dW, dbias, assign, bias_rows);
     CTRLV_LAUNCH_CHECK();
   }
   return CTRLV_OK;

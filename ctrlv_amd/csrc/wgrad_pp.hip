@@ -18,7 +18,11 @@
 //     read of chunk c, waits are counted (vmcnt(2 x pieces per wave)): three chunks (~3800 MFMA cycles) of latency cover;
 //   * LDS accesses are asm statements: the compiler would put vmcnt(0) in front of LDS reads it knows of while LDS-DMA is
 //     in flight (gemm_pp_kernel.h, "Epilogue staging accesses");
-//   * the bias gradient rides along in the k-tile-0 workgroups: their kh = 0 waves add up the dY fragments they hold.
+//   * the bias gradient rides along: the k tiles of a slab take turns (chunk c belongs to tile c mod ktiles) adding up the dY
+//     fragments they hold anyway, with v_dot2c against (1, 1) (with the k-tile-0 workgroups doing all of it they set the
+//     launch time: +5.6 % over the 21 shapes of tools/wgrad_bench.py).
+// Measured and dropped (round 6, same-device A/B): the two-group ping-pong of gemm_pp_kernel.h (load phase / MFMA phase half a
+// chunk apart, two barriers per chunk) is 1.4 % SLOWER than this loop, whose halves already mix 10 MFMAs with 14 reads.
 // Grid: (n tile, k tile, row slab), dealt out XCD-aware like wgrad_kernel (the tiles of one slab share its rows in one L2);
 // slab partials + the ordered sum of wgrad_reduce_kernel (deterministic), or fp32 atomics without scratch.
 // Serves mode 0, stride-1 3x3 without upsampling, the temporal conv; N, Cin multiples of 64; everything else (stride 2,
@@ -31,6 +35,7 @@
 #ifndef CTRLV_WP_DIAG
 #define CTRLV_WP_DIAG 0
 #endif
+
 
 namespace {
 
@@ -227,8 +232,13 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
-  // bias gradient: the four kh waves of an n half hold the same dY fragments; wave kh sums fragment kh + 1 (kh = 0: also 0)
-  const bool do_bias = a.dbias != nullptr && by == 0;
+  // bias gradient (column sums of dY): the four kh waves of an n half hold the same dY fragments; wave kh sums fragment
+  // kh + 1 (kh = 0: also 0).  The k tiles of a slab all stream the same dY rows: tile `by` takes the chunks c = by (mod
+  // ktiles), so that no workgroup carries the whole sum (with the k-tile-0 workgroups doing all of it they finished 10 %
+  // behind the rest and set the launch time).  One partial row per (slab, k tile).
+  const bool has_bias = a.dbias != nullptr;
+  int bias_turn = by;                                       // chunks until this tile's next turn
+  bool do_bias = false;
   float bsum0 = 0.f, bsum1 = 0.f;
 
   dma(0); dma(1); dma(2); dma(3);
@@ -269,6 +279,8 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   } while (0)
   for (int c = 0; c < nchunks; ++c) {
+    do_bias = has_bias && bias_turn == 0;
+    bias_turn = bias_turn == 0 ? a.ktiles - 1 : bias_turn - 1;
     const unsigned so = (unsigned)((c & (kSlots - 1)) * kSlot);
     WP_HALF(f0, f1, 1, a00 + so, a10 + so, yA0 + so, yB0 + so);
     wait_frags<0>(f1);                                     // every read of chunk c has landed in registers ...
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
         for (int e = 0; e < 16; ++e) atomicAdd(pd + (long)((e & 3) + 8 * (e >> 2)) * ktot, acc[t][j][e] * a.scale);
       }
     }
-  if (do_bias) {
+  if (has_bias) {
     const float s0 = bsum0 + __shfl_xor(bsum0, 32), s1 = bsum1 + __shfl_xor(bsum1, 32);   // the two row halves of a step
     const int t0 = kh == 0 ? 0 : kh + 1;
 #pragma unroll
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpArgs a) {
       const int n = n0 + 160 * nh + 32 * t + (lane & 31);
       if ((r == 0 || kh == 0) && lane < 32 && n < a.N) {
         const float sv = r == 0 ? s0 : s1;
-        if (a.part) a.part[(long)a.slabs * a.N * ktot + (long)bz * a.N + n] = sv;
+        if (a.part) a.part[(long)a.slabs * a.N * ktot + ((long)bz * a.ktiles + by) * a.N + n] = sv;
         else atomicAdd(a.dbias + n, sv * a.scale);
       }
     }
