@@ -127,6 +127,22 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def _lo(t):
+    """lo plane of a split trunk tensor (Workspace.trunk), None for plain tensors"""
+    return getattr(t, "lo", None) if t is not None else None
+
+
+def _trk_epi(epi, out):
+    """the lo planes of an epilogue's trunk operands, next to them (ops.gemm / ops.ff_fused / ops.temporal_fused keywords)"""
+    e = dict(epi)
+    for k in ("R1", "R2"):
+        if _lo(e.get(k)) is not None:
+            e[k + "_lo"] = _lo(e[k])
+    if _lo(out) is not None:
+        e["out_lo"] = _lo(out)
+    return e
+
+
 _FF_FUSED = os.environ.get("CTRLV_FF_FUSED", "1") != "0"      # the plan's switch (csrc/plan.hip ff_pair)
 _TEMPORAL_FUSED = os.environ.get("CTRLV_TEMPORAL_FUSED", "1") != "0"     # the plan's switch (csrc/plan.hip run_tr)
 
@@ -136,6 +152,7 @@ def _ff_pair(ws, x, ffp, ubox, out, C, rows_per_image=0, **epi):
     that keeps u on chip (ops.ff_fused, when it serves the epilogue: csrc/ff_fused.hip), else the two GEMMs.  `ubox` = [u or None]: the 4C-wide intermediate of the two-launch path is
     allocated from the arena on first need (csrc/plan.hip ff_pair)."""
     wproj, bproj, wout, bout = ffp[:4]
+    epi = _trk_epi(epi, out)
     if _FF_FUSED and len(ffp) == 6 and ops.ff_fused_serves(x, out, **epi):
         ops.ff_fused(x, ffp[4], ffp[5], out, bias=bout, **epi)
         return
@@ -153,14 +170,14 @@ _FF_LN = os.environ.get("CTRLV_FF_LN", "0") not in ("", "0")   # opt-in, the pla
 def _ln_ff(ws, xraw, ln, t, ffp, ubox, out, C, ln_V=None, ln_vdiv=1, ln_vmod=1 << 30, rows_per_image=0, **epi):
     """out = epilogue(FF(LayerNorm(xraw + ln_V))): with the fused kernel the norm is folded into its prologue, else
     ops.layernorm into `t` followed by _ff_pair (csrc/plan.hip ln_ff)."""
-    if _FF_FUSED and _FF_LN and len(ffp) == 6 and ops.ff_fused_serves(xraw, out, **epi):
+    if _FF_FUSED and _FF_LN and len(ffp) == 6 and _lo(xraw) is None and ops.ff_fused_serves(xraw, out, **_trk_epi(epi, out)):
         ops.ff_fused(xraw, ffp[4], ffp[5], out, bias=ffp[3], ln=(ln[0], ln[1], 1e-5), ln_V=ln_V, ln_vdiv=ln_vdiv,
-                     ln_vmod=ln_vmod, **epi)
+                     ln_vmod=ln_vmod, **_trk_epi(epi, out))
         return
     if ln_V is not None:
-        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, V=ln_V, vdiv=ln_vdiv, vmod=ln_vmod)
+        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, V=ln_V, vdiv=ln_vdiv, vmod=ln_vmod, x_lo=_lo(xraw))
     else:
-        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t)
+        ops.layernorm(xraw, ln[0], ln[1], 1e-5, t, x_lo=_lo(xraw))
     _ff_pair(ws, t, ffp, ubox, out, C, rows_per_image=rows_per_image, **epi)
 
 
@@ -174,15 +191,17 @@ def _gn_scratch(ctx, n_img, S, C, ips):
 def _gemm_groupnorm(ctx, A, W, out, gkw, n_img, S, C, ips, gamma, beta, eps, y):
     """`gemm` whose output goes straight into GroupNorm + SiLU (plan.hip gemm_groupnorm): where the launch serves it, its
     epilogue writes the norm's chunk partials and the norm is finalize + apply."""
+    gkw = _trk_epi(gkw, out)
     if S % 64 == 0 and ops.gemm_gn_partials_serves(A, W, out, **gkw):
         need = ops.groupnorm_fused_scratch_floats(n_img, S, ips)
         if ctx.gn_part is None or ctx.gn_part.numel() < need:
             ctx.gn_part = torch.empty(max(need, 1 << 18), dtype=torch.float32, device=ctx.ws.device)
         ops.gemm(A, W, out, gn_partials=ctx.gn_part, **gkw)
-        ops.groupnorm_from_partials(out, n_img, S, C, ips, gamma, beta, eps, True, y, ctx.gn_part)
+        ops.groupnorm_from_partials(out, n_img, S, C, ips, gamma, beta, eps, True, y, ctx.gn_part, x_lo=_lo(out))
     else:
         ops.gemm(A, W, out, **gkw)
-        ops.groupnorm(out, None, n_img, S, C, ips, gamma, beta, eps, True, y, _gn_scratch(ctx, n_img, S, C, ips))
+        ops.groupnorm(out, None, n_img, S, C, ips, gamma, beta, eps, True, y, _gn_scratch(ctx, n_img, S, C, ips),
+                      x_lo=_lo(out))
 
 
 # ------------------------------------------------------------------------------------------- res block
@@ -225,11 +244,11 @@ class SpatioTemporalResBlock(nn.Module):
         N, S = B * F, H * W
         M = N * S
         cin, cout = self.cin, self.cout
-        out = ws.alloc((M, cout))
+        out = ws.trunk((M, cout))
         mk = ws.mark()
         part = _gn_scratch(ctx, N, S, max(cin, cout), 1)
         xn = ws.alloc((M, cin))
-        ops.groupnorm(x, x2, N, S, cin, 1, pk["g1"], pk["b1"], self.eps, True, xn, part)
+        ops.groupnorm(x, x2, N, S, cin, 1, pk["g1"], pk["b1"], self.eps, True, xn, part, x_lo=_lo(x), x2_lo=_lo(x2))
         h = ws.alloc((M, cout))
         vs = ctx.temb[:, self.temb_off[0]:]
         hn = ws.alloc((M, cout))
@@ -237,12 +256,12 @@ class SpatioTemporalResBlock(nn.Module):
                                                    V=vs, vmode=1, vdiv=F * S),
                         N, S, cout, 1, pk["g2"], pk["b2"], self.eps, hn)
         if "wsc" in pk:
-            res = ws.alloc((M, cout))
+            res = ws.trunk((M, cout))
             ops.gemm(x, pk["wsc"], res, N=cout, cin=cin, A2=x2, c_split=x.shape[1] if x2 is not None else 0,
-                     bias=pk["bsc"])
+                     bias=pk["bsc"], out_lo=_lo(res))
         else:
             res = x
-        xs = ws.alloc((M, cout))
+        xs = ws.trunk((M, cout))
         # temporal res block on (B, C, F, H, W): GroupNorm statistics over (C/32, F, H, W), conv along F
         _gemm_groupnorm(ctx, hn, pk["w2"], xs, dict(N=cout, cin=cout, taps=9, mode=1, conv=(H, W, H, W, 1, 0), bias=pk["cb2"],
                                                     R1=res),
@@ -252,7 +271,8 @@ class SpatioTemporalResBlock(nn.Module):
                                                     V=vt, vmode=1, vdiv=F * S),
                         N, S, cout, F, pk["tg2"], pk["tb2"], self.eps, hn)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2) = xs + (1-a)*conv2
-        kw2 = dict(N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"], s_acc=1.0 - pk["alpha"], R1=xs)
+        kw2 = _trk_epi(dict(N=cout, cin=cout, taps=3, mode=2, temporal=(F, S), bias=pk["tcb2"], s_acc=1.0 - pk["alpha"], R1=xs),
+                       out)
         ctx.gn_cross_valid = False
         if feeds_norm and S % 64 == 0 and ops.gemm_gn_partials_serves(hn, pk["tw2"], out, **kw2):
             need = ops.groupnorm_fused_scratch_floats(N, S, 1)
@@ -356,26 +376,26 @@ class TransformerSpatioTemporalModel(nn.Module):
         N, S = B * F, H * W
         M = N * S
         emb = self.frame_embedding(F, x.device)
-        out = ws.alloc((M, C))
+        out = ws.trunk((M, C))
         mk = ws.mark()
         part = _gn_scratch(ctx, N, S, C, 1)
         t = ws.alloc((M, C))
         if ctx.gn_cross_valid:       # statistics from the res block's last GEMM (SpatioTemporalResBlock.run, feeds_norm)
             ctx.gn_cross_valid = False
-            ops.groupnorm_from_partials(x, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, ctx.gn_cross)
+            ops.groupnorm_from_partials(x, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, ctx.gn_cross, x_lo=_lo(x))
         else:
-            ops.groupnorm(x, None, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, part)
-        h0 = ws.alloc((M, C))
-        ops.gemm(t, pk["pin"][0], h0, N=C, cin=C, bias=pk["pin"][1])
+            ops.groupnorm(x, None, N, S, C, 1, pk["gn"][0], pk["gn"][1], 1e-6, False, t, part, x_lo=_lo(x))
+        h0 = ws.trunk((M, C))
+        ops.gemm(t, pk["pin"][0], h0, N=C, cin=C, bias=pk["pin"][1], out_lo=_lo(h0))
         # ---- spatial BasicTransformerBlock
-        ops.layernorm(h0, pk["s_ln1"][0], pk["s_ln1"][1], 1e-5, t)
+        ops.layernorm(h0, pk["s_ln1"][0], pk["s_ln1"][1], 1e-5, t, x_lo=_lo(h0))
         qkv = ws.alloc((M, 3 * C))
         ops.gemm(t, pk["s_qkv"], qkv, N=3 * C, cin=C, n_scale2=C, s_acc2=ops.Q_PRESCALE)   # q block pre-scaled
         a = ws.alloc((M, C))
         ops.attention_spatial(qkv, a, N, S, C, prescaled=True)
-        h1 = ws.alloc((M, C))
+        h1 = ws.trunk((M, C))
         xs_vec = ctx.xattn[:, self.xattn_off[0]:]      # attn2 with one key == to_out(to_v(ehs[b])) for every query
-        ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], R1=h0, V=xs_vec, vmode=1, vdiv=F * S)
+        ops.gemm(a, pk["s_o"][0], h1, N=C, cin=C, bias=pk["s_o"][1], **_trk_epi(dict(R1=h0, V=xs_vec, vmode=1, vdiv=F * S), h1))
         u = [None]                                      # 4C-wide GEGLU output: allocated by _ff_pair on first need
         h2 = h0                                         # h0 is dead from here on
         _ln_ff(ws, h1, pk["s_ln3"], t, pk["s_ff"], u, h2, C, rows_per_image=S, R1=h1)
@@ -383,24 +403,25 @@ class TransformerSpatioTemporalModel(nn.Module):
         g0 = h1                                         # h1 is dead
         _ln_ff(ws, h2, pk["t_lnin"], t, pk["t_ffin"], u, g0, C, ln_V=emb, ln_vdiv=S, ln_vmod=F, rows_per_image=S, R1=h2, V=emb, vmode=1, vdiv=S,
                vmod=F)
-        g1 = ws.alloc((M, C))
+        g1 = ws.trunk((M, C))
         xt_vec = ctx.xattn[:, self.xattn_off[1]:]
         # diffusers 0.27.2: time_context rows ordered (s, b), tokens ordered (b, s)
         vkw = dict(vmode=2, vdiv=F * S, vS=S, vmod=B) if (ctx.quirk and B > 1) else dict(vmode=1, vdiv=F * S)
-        fkw = dict(bias=pk["t_o"][1], R1=g0, V=xt_vec, ln=(pk["t_ln1"][0], pk["t_ln1"][1], 1e-5), **vkw)
+        # (split trunk: the in-kernel LayerNorm normalises the hi plane of g0, as in the plan)
+        fkw = _trk_epi(dict(bias=pk["t_o"][1], R1=g0, V=xt_vec, ln=(pk["t_ln1"][0], pk["t_ln1"][1], 1e-5), **vkw), g1)
         if _TEMPORAL_FUSED and ops.temporal_fused_serves(g0, pk["t_wf"], g1, B, F, S, **fkw):
             # norm1 + attn1 over the frames + residual + the cross-attention vector in ONE launch (csrc/plan.hip run_tr)
             ops.temporal_fused(g0, pk["t_wf"], g1, B, F, S, **fkw)
         else:
-            ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t)
+            ops.layernorm(g0, pk["t_ln1"][0], pk["t_ln1"][1], 1e-5, t, x_lo=_lo(g0))
             ops.gemm(t, pk["t_qkv"], qkv, N=3 * C, cin=C)
             ops.attention_temporal(qkv, a, B, F, S, C)
-            ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], R1=g0, V=xt_vec, **vkw)
+            ops.gemm(a, pk["t_o"][0], g1, N=C, cin=C, bias=pk["t_o"][1], **_trk_epi(dict(R1=g0, V=xt_vec, **vkw), g1))
         # AlphaBlender folded: h3 = a*h2 + (1-a)*(g1 + ff)
         al = pk["alpha"]
         h3 = g0
         _ln_ff(ws, g1, pk["t_ln3"], t, pk["t_ff"], u, h3, C, rows_per_image=S, s_acc=1.0 - al, R1=g1, s1=1.0 - al, R2=h2, s2=al)
-        ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], R1=x)
+        ops.gemm(h3, pk["pout"][0], out, N=C, cin=C, bias=pk["pout"][1], **_trk_epi(dict(R1=x), out))
         ws.release(mk)
         if ctx.trace is not None:
             ctx.trace.append((self, out.clone(), H, W))
@@ -421,9 +442,9 @@ class Downsample2D(nn.Module):
     def run(self, ctx, x, H, W):
         N = ctx.B * ctx.F
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        out = ctx.ws.alloc((N * Ho * Wo, self.C))
+        out = ctx.ws.trunk((N * Ho * Wo, self.C))
         ops.gemm(x, self._pk[0], out, N=self.C, cin=self.C, taps=9, mode=1, conv=(H, W, Ho, Wo, 2, 0),
-                 bias=self._pk[1])
+                 bias=self._pk[1], out_lo=_lo(out))
         return out, Ho, Wo
 
 
@@ -440,9 +461,9 @@ class Upsample2D(nn.Module):
     def run(self, ctx, x, H, W):
         """nearest x2 upsample fused into the conv's gather (source pixel = (y>>1, x>>1))."""
         N = ctx.B * ctx.F
-        out = ctx.ws.alloc((N * 4 * H * W, self.C))
+        out = ctx.ws.trunk((N * 4 * H * W, self.C))
         ops.gemm(x, self._pk[0], out, N=self.C, cin=self.C, taps=9, mode=1, conv=(H, W, 2 * H, 2 * W, 1, 1),
-                 bias=self._pk[1])
+                 bias=self._pk[1], out_lo=_lo(out))
         return out, 2 * H, 2 * W
 
 

@@ -46,7 +46,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
     _plan_kind = "unet"
     # Storage of the RESIDUAL TRUNK (conv_in output, block / AlphaBlender outputs, skip tensors): "same" = one element per
     # value like every activation; "fp16x2" = split into hi + lo fp16 planes (fp32's bytes, 21+ significant bits) under fp16
-    # branches -- fp16 models on the C++ plan only; model-level error against the fp32 oracle 1.3e-3 -> < 1e-3.
+    # branches -- fp16 models, both executors; model-level error against the fp32 oracle 1.3e-3 -> < 1e-3.
     trunk_dtype = os.environ.get("CTRLV_TRUNK", "same")
 
     def _build_encoder(self, in_channels, down_block_types, block_out_channels, addition_time_embed_dim,
@@ -235,9 +235,10 @@ class SpatioTemporalEncoderBase(HipModelMixin):
 
     def _ensure_ready(self, sample):
         el = self.el_dtype
-        if self.trunk_dtype != "same":
-            raise _lib.CtrlvHipError('trunk_dtype="fp16x2" runs on the C++ plan only (the per-op Python executor -- traces, '
-                                     "the per-kernel profiler -- stores the trunk as plain elements)")
+        if self.trunk_dtype not in ("same", "fp16x2"):
+            raise ValueError(f'trunk_dtype must be "same" or "fp16x2" (got {self.trunk_dtype!r})')
+        if self.trunk_dtype != "same" and el != torch.float16:
+            raise ValueError('trunk_dtype="fp16x2" needs an fp16 model (the split planes are fp16 elements)')
         _lib.load(el)                             # raises if the HIP library is missing: no fallback
         if not sample.is_cuda:
             raise _lib.CtrlvHipError("ctrlv_amd models run on a HIP device only; there is no CPU forward "
@@ -256,6 +257,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         if lane == 0:
             self._ws = ws
         ws.el = el
+        ws.split = self.trunk_dtype == "fp16x2"   # trunk tensors (Workspace.trunk) carry a lo plane, as in the C++ plan
         ws.reset()
         return ws
 
@@ -343,8 +345,8 @@ class SpatioTemporalEncoderBase(HipModelMixin):
         col = ws.alloc((M, pk["cin_kp"]))
         ops.im2col3x3(x16, N, h, w, col)
         c0 = self.conv_in.weight.shape[0]
-        x = ws.alloc((M, c0))
-        ops.gemm(col, pk["cin_w"], x, N=pk["cin_w"].shape[0], cin=pk["cin_kp"], bias=pk["cin_b"])
+        x = ws.trunk((M, c0))
+        ops.gemm(col, pk["cin_w"], x, N=pk["cin_w"].shape[0], cin=pk["cin_kp"], bias=pk["cin_b"], out_lo=getattr(x, "lo", None))
         return x
 
     def _run_down_mid(self, ctx, x, h, w):

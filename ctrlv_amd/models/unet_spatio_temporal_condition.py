@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import ops, packing
-from .blocks import CrossAttnUpBlockSpatioTemporal, UpBlockSpatioTemporal, _f32, _gn_scratch
+from .blocks import CrossAttnUpBlockSpatioTemporal, UpBlockSpatioTemporal, _f32, _gn_scratch, _lo
 from .encoder import SpatioTemporalEncoderBase, _tup
 
 
@@ -188,9 +188,15 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
             mk = ws.mark()
+            def add_res(t, r):                                 # (split trunk: the sum is re-split into the tensor's two planes)
+                rr = self._residual_rows(ws, r, t.shape[0], t.shape[1])
+                if _lo(t) is not None:
+                    ops.axpby_split(t, _lo(t), rr, 1.0, 1.0, t, _lo(t))
+                else:
+                    ops.axpby(t, rr, 1.0, 1.0, t)
             for (s, sh, sw), r in zip(taps, down_block_additional_residuals):
-                ops.axpby(s, self._residual_rows(ws, r, s.shape[0], s.shape[1]), 1.0, 1.0, s)
-            ops.axpby(x, self._residual_rows(ws, mid_block_additional_residuals, x.shape[0], x.shape[1]), 1.0, 1.0, x)
+                add_res(s, r)
+            add_res(x, mid_block_additional_residuals)
             ws.release(mk)
         skips = [t[0] for t in taps]
         for blk in self.up_blocks:                                                             # :140-158
@@ -198,7 +204,7 @@ class UNetSpatioTemporalConditionModel(SpatioTemporalEncoderBase):
         M, c0 = x.shape
         part = _gn_scratch(ctx, N, H * W, c0, 1)                                               # :161-163
         xn = ws.alloc((M, c0))
-        ops.groupnorm(x, None, N, H * W, c0, 1, pk["gno"][0], pk["gno"][1], 1e-5, True, xn, part)
+        ops.groupnorm(x, None, N, H * W, c0, 1, pk["gno"][0], pk["gno"][1], 1e-5, True, xn, part, x_lo=_lo(x))
         co = self.config.out_channels
         co_p = (co + 3) // 4 * 4
         y = ws.alloc((M, co_p))

@@ -18,6 +18,7 @@ class Workspace:
         self.off = 0              # bump offset inside the active block
         self.peak = 0
         self.el = torch.bfloat16  # element type of the forward using this arena (default dtype of alloc)
+        self.split = False        # residual trunk stored as hi + lo planes (trunk_dtype "fp16x2")
 
     def _block_for(self, nbytes):
         while True:
@@ -44,6 +45,14 @@ class Workspace:
         used = sum(b.numel() for b in self.blocks[:self.cur]) + self.off
         if used > self.peak:
             self.peak = used
+        return t
+
+    def trunk(self, shape):
+        """A RESIDUAL-TRUNK tensor (block inputs / outputs, everything a branch result is added back into): one plane, or --
+        split mode -- the hi plane carrying its lo plane as the attribute `.lo` (value = hi + lo; GEMM A operands read the
+        hi plane in place, residual operands and norm inputs read both: csrc/plan.hip `Trk`)."""
+        t = self.alloc(shape)
+        t.lo = self.alloc(shape) if self.split else None
         return t
 
     def mark(self):

@@ -63,6 +63,36 @@ def test_plan_and_python_executors_are_bit_identical(hip_lib, order, B, F, h, w,
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("order", ["sb", "bs"])
+@pytest.mark.parametrize("B,F,h,w", [(2, 3, 16, 16), (1, 5, 24, 8)])
+def test_plan_and_python_executors_are_bit_identical_with_a_split_trunk(hip_lib, order, B, F, h, w):
+    """trunk_dtype = "fp16x2" (the residual trunk as hi + lo fp16 planes) in BOTH executors: the per-op Python
+    executor carries the lo plane of every trunk tensor beside its hi plane (Workspace.trunk) and hands the same operands to
+    the same launches as csrc/plan.hip -- ControlNet residuals, UNet output with and without them, bit for bit; and the mode
+    really is on (the plain fp16 trunk gives other bits)."""
+    import ctrlv_ref as R
+    cfg = dict(R.TINY_CONFIG)
+    _, _, hu, hc = make_pair(cfg, DEV, time_context_order=order, dtype=torch.float16)
+    inputs = make_inputs(cfg, B, F, h, w, dtype=torch.float16)
+    res = {}
+    for m in (hu, hc):
+        m.trunk_dtype = "fp16x2"
+    for ex in ("plan", "python"):
+        hu.executor = hc.executor = ex
+        res[ex] = _fwd(hu, hc, inputs, torch.float16)
+        res[ex + "_plain"] = _fwd(hu, hc, inputs, torch.float16, with_ctrl=False)
+    a, b = res["plan"], res["python"]
+    assert torch.equal(a["unet"], b["unet"]) and torch.equal(a["mid"], b["mid"])
+    assert all(torch.equal(x, y) for x, y in zip(a["down"], b["down"]))
+    assert torch.equal(res["plan_plain"]["unet"], res["python_plain"]["unet"])
+    for m in (hu, hc):
+        m.trunk_dtype = "same"
+    same = _fwd(hu, hc, inputs, torch.float16)
+    assert not torch.equal(same["unet"], b["unet"])
+    hu.executor = hc.executor = "plan"
+
+
+@torch.no_grad()
 def test_plan_follows_parameter_updates_and_context_order(hip_lib):
     """load_state_dict / .to() rebuild the plan; flipping time_context_order on a live model reaches the plan."""
     import ctrlv_ref as R

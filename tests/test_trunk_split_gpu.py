@@ -430,7 +430,7 @@ def test_split_trunk_clip_independence_and_determinism(hip_lib):
         assert torch.equal(got["mid"], both["mid"][b * 3:(b + 1) * 3])
 
 
-def test_split_trunk_needs_fp16_and_the_plan(hip_lib):
+def test_split_trunk_needs_fp16(hip_lib):
     import ctrlv_ref as R
     cfg = dict(R.TINY_CONFIG)
     ou, oc, hu, hc = make_pair(cfg, DEV)                  # bf16 models
@@ -460,3 +460,25 @@ def test_fullwidth_split_trunk_meets_north_star(full_pair_f16, B, h, w):
     for k in ("unet", "controlnet_mid", "controlnet_down"):
         assert e["fp16x2"]["l2"][k] < NORTH_STAR_TOL, e
         assert e["fp16x2"]["both"][k] < 1.5e-3, e
+
+
+@torch.no_grad()
+def test_fullwidth_split_trunk_executors_are_bit_identical(full_pair_f16):
+    """Production widths, split trunk: the per-op Python executor (models/blocks.py, lo planes carried by Workspace.trunk)
+    and the C++ plan agree bit for bit -- this size runs the C = 320 fused feed-forward and the fused temporal block with
+    split residual / output planes, which the tiny configuration does not reach."""
+    cfg, pair = full_pair_f16
+    _, _, hu, hc = pair
+    inputs = make_inputs(cfg, 2, 2, 32, 32, dtype=EL)
+    _set_trunk((hu, hc), "fp16x2")
+    res = {}
+    try:
+        for ex in ("plan", "python"):
+            hu.executor = hc.executor = ex
+            res[ex] = hip_forward(hu, hc, inputs, DEV, with_unet_no_ctrl=False)
+    finally:
+        hu.executor = hc.executor = "plan"
+        _set_trunk((hu, hc), "same")
+    for k in ("unet", "mid"):
+        assert torch.equal(res["plan"][k], res["python"][k]), k
+    assert all(torch.equal(a, b) for a, b in zip(res["plan"]["down"], res["python"]["down"]))
