@@ -5,6 +5,7 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes         -> pmc_hbm_traffic_summary.json (build-id stamped)
 #   4. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... + in-kernel clock   -> pmc_mfma_busy_summary.json (tools/pmc_mfma_pass.sh)
 #   5. the other configurations of the same build, incl. bench.py --dtype fp16 --trunk fp16x2 (north_star's tolerance)
+#   6. the cfg5 training step per kernel (rocprofv3 kernel trace cut at the step marks) and every weight-gradient shape
 # usage: tools/round_profile.sh <tag> [extra bench args]
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-round}; shift
@@ -33,3 +34,12 @@ python3 tools/train_bench.py --steps 4 --warmup 2 > $OUT/train_step.json 2>> $OU
 python3 tools/train_bench.py --steps 4 --warmup 2 --gradient-checkpointing 1 > $OUT/train_step_checkpointed.json 2>> $OUT/bench.err
 python3 tools/pipeline_bench.py > $OUT/pipeline_clip_latency.json 2>> $OUT/bench.err
 tail -1 $OUT/bench_svd_unet.json | cut -c1-160; tail -1 $OUT/bench_320x512.json | cut -c1-160; tail -1 $OUT/train_step.json | cut -c1-200; tail -2 $OUT/pipeline_clip_latency.json | cut -c1-300
+# 6. training step per kernel; the weight-gradient shapes on the LDS-DMA kernel and on the register-staged one
+python3 tools/wgrad_bench.py > $OUT/wgrad_bench.txt 2>&1
+CTRLV_WGRAD_PP=0 python3 tools/wgrad_bench.py > $OUT/wgrad_bench_register_staged.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tprof -o p -- python3 $R/tools/train_bench.py --steps 2 --warmup 2 --mark-steps 1 > $OUT/tprof.log 2>&1
+cd $R
+python3 tools/trace_last_step.py $OUT/tprof/p_kernel_trace.csv $OUT/train_last_step_kernels.csv > $OUT/train_last_step.txt 2>&1
+rm -rf $OUT/tprof
+head -3 $OUT/train_last_step.txt
