@@ -45,6 +45,8 @@ def store(x, trunk=False):
     dt = _TRUNK_DTYPE[0] if (trunk and _TRUNK_DTYPE[0] != "same") else _STORE_DTYPE[0]
     if _STORE_ABSMAX[0] is not None:
         _STORE_ABSMAX[0].append(float(x.detach().abs().max()))
+    if callable(dt):           # a rounding function (tests/trunk_precision_study.py: split-plane trunk formats)
+        return dt(x)
     return x if dt is None else x.to(dt).to(x.dtype)
 
 
@@ -62,7 +64,8 @@ def store_absmax():
 
 @contextlib.contextmanager
 def storage_rounding(dtype=torch.bfloat16, trunk_dtype="same"):
-    """trunk_dtype: "same" (default: like every other store), None (trunk kept in fp32) or a torch dtype."""
+    """trunk_dtype: "same" (default: like every other store), None (trunk kept in fp32), a torch dtype, or a function
+    x -> rounded x (a storage format torch has no dtype for: hi + lo planes)."""
     prev = _STORE_DTYPE[0], _TRUNK_DTYPE[0]
     _STORE_DTYPE[0], _TRUNK_DTYPE[0] = dtype, trunk_dtype
     try:

@@ -61,11 +61,25 @@ def main():
             h16 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
         with R.storage_rounding(torch.float16, trunk_dtype=None):
             h16t = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
+        # split-plane trunk formats under fp16 branches: hi = rne_fp16(v) plus a lo plane rne(v - hi) in fp16 (what
+        # trunk_dtype="fp16x2" stores: 4 bytes per element) or in 8-bit e5m2 (the top byte of that fp16 lo: 3 bytes)
+        def split(lo_dtype):
+            def f(x):
+                hi = x.to(torch.float16).float()
+                return hi + (x - hi).to(lo_dtype).float()
+            return f
+        with R.storage_rounding(torch.float16, trunk_dtype=split(torch.float16)):
+            h16x2 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
+        with R.storage_rounding(torch.float16, trunk_dtype=split(torch.float8_e5m2)):
+            h16x8 = oracle_forward(ou, oc, inp, with_unet_no_ctrl=False)
         print(f"{name}")
         for key in ("unet", "mid"):
             print(f"  {key:5s}  bf16 everywhere {rel_l2(all16[key], ref[key]):.3e}   fp32 trunk + bf16 branches "
                   f"{rel_l2(trunk32[key], ref[key]):.3e}   fp16 everywhere {rel_l2(h16[key], ref[key]):.3e}   "
                   f"fp32 trunk + fp16 branches {rel_l2(h16t[key], ref[key]):.3e}")
+        for key in ("unet", "mid"):
+            print(f"  {key:5s}  fp16 branches over a split trunk: hi + fp16 lo {rel_l2(h16x2[key], ref[key]):.3e}   "
+                  f"hi + e5m2 lo (3 bytes per element) {rel_l2(h16x8[key], ref[key]):.3e}")
         srt = sorted(amax)
         print(f"  max |value| over the {len(amax)} storage points of the fp16 run: {srt[-1]:.1f} (median {srt[len(srt) // 2]:.2f}, "
               f"smallest per-tensor max {srt[0]:.3g}); fp16 max 65504")
