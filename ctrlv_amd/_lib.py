@@ -186,7 +186,7 @@ def _status_recorder(lib, fn):
         return rc
     call.__name__ = getattr(fn, "__name__", "ctrlv_fn")
     return call
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class CtrlvHipError(RuntimeError):

@@ -71,7 +71,7 @@ extern "C" int ctrlv_last_error(char* buf, size_t n) {
   return (int)strlen(g_err);
 }
 
-extern "C" int ctrlv_abi_version(void) { return 19; }
+extern "C" int ctrlv_abi_version(void) { return 20; }
 extern "C" int ctrlv_elem_dtype(void) { return CTRLV_ELEM_DTYPE; }
 
 // sha256 prefix of ctrlv_amd/csrc/* + include/*.h at build time (stamped by __graft_entry__.build()): the host layer

@@ -130,19 +130,19 @@ __global__ void axpby_kernel(const el_t* x, const el_t* __restrict__ r, float a,
 
 // (y, y_lo) = split(a * (x + x_lo) + b * r) on a SPLIT skip tensor (common.h split_lo8); n a multiple of 8
 // (in place allowed: y == x and ylo == xlo, so none of the four carries __restrict__)
-__global__ void axpby_split_kernel(const el_t* x, const el_t* xlo, const el_t* __restrict__ r, float a, float b, el_t* y,
-                                   el_t* ylo, size_t n) {
+__global__ void axpby_split_kernel(const el_t* x, const lo_t* xlo, const el_t* __restrict__ r, float a, float b, el_t* y,
+                                   lo_t* ylo, size_t n) {
   const size_t nv = n >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     float fx[8], fr[8];
     unpack_elx8(((const uint4*)x)[i], fx);
-    if (xlo) add_lo8(fx, ((const uint4*)xlo)[i]);
+    if (xlo) add_lo8(fx, ((const uint2*)xlo)[i]);
     unpack_elx8(((const uint4*)r)[i], fr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fx[e] = a * fx[e] + b * fr[e];
     const uint4 hi = pack_elx8(fx);
     ((uint4*)y)[i] = hi;
-    ((uint4*)ylo)[i] = split_lo8(fx, hi);
+    ((uint2*)ylo)[i] = split_lo8(fx, hi);
   }
 }
 
@@ -268,7 +268,7 @@ extern "C" int ctrlv_axpby_split(const void* x, const void* x_lo, const void* r,
                                  size_t n, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && r && y && y_lo && n > 0 && n % 8 == 0, "axpby_split: bad arguments (n must be a multiple of 8)");
   hipLaunchKernelGGL(axpby_split_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const el_t*)x,
-                     (const el_t*)x_lo, (const el_t*)r, a, b, (el_t*)y, (el_t*)y_lo, n);
+                     (const lo_t*)x_lo, (const el_t*)r, a, b, (el_t*)y, (lo_t*)y_lo, n);
   CTRLV_LAUNCH_CHECK();
   return CTRLV_OK;
 }

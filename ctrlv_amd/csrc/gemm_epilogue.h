@@ -66,11 +66,12 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             o[2] = __builtin_fmaf(d.s1, el_lo_f32(rv.y), o[2]);
             o[3] = __builtin_fmaf(d.s1, el_hi_f32(rv.y), o[3]);
             if (d.R1_lo) {      // SPLIT trunk operand: R1 + R1_lo, one fma per plane (the ping-pong epilogue's sequence)
-              const uint2 rl = *(const uint2*)((const el_t*)d.R1_lo + (long)m * d.ldr1 + ncol);
-              o[0] = __builtin_fmaf(d.s1, el_lo_f32(rl.x), o[0]);
-              o[1] = __builtin_fmaf(d.s1, el_hi_f32(rl.x), o[1]);
-              o[2] = __builtin_fmaf(d.s1, el_lo_f32(rl.y), o[2]);
-              o[3] = __builtin_fmaf(d.s1, el_hi_f32(rl.y), o[3]);
+              float rl[4];                  // (lo planes: one byte per element)
+              unpack_lo4(*(const unsigned*)((const lo_t*)d.R1_lo + (long)m * d.ldr1 + ncol), rl);
+              o[0] = __builtin_fmaf(d.s1, rl[0], o[0]);
+              o[1] = __builtin_fmaf(d.s1, rl[1], o[1]);
+              o[2] = __builtin_fmaf(d.s1, rl[2], o[2]);
+              o[3] = __builtin_fmaf(d.s1, rl[3], o[3]);
             }
           }
           if (d.R2) {
@@ -80,11 +81,12 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
             o[2] = __builtin_fmaf(d.s2, el_lo_f32(rv.y), o[2]);
             o[3] = __builtin_fmaf(d.s2, el_hi_f32(rv.y), o[3]);
             if (d.R2_lo) {
-              const uint2 rl = *(const uint2*)((const el_t*)d.R2_lo + (long)m * d.ldr2 + ncol);
-              o[0] = __builtin_fmaf(d.s2, el_lo_f32(rl.x), o[0]);
-              o[1] = __builtin_fmaf(d.s2, el_hi_f32(rl.x), o[1]);
-              o[2] = __builtin_fmaf(d.s2, el_lo_f32(rl.y), o[2]);
-              o[3] = __builtin_fmaf(d.s2, el_hi_f32(rl.y), o[3]);
+              float rl[4];                  // (lo planes: one byte per element)
+              unpack_lo4(*(const unsigned*)((const lo_t*)d.R2_lo + (long)m * d.ldr2 + ncol), rl);
+              o[0] = __builtin_fmaf(d.s2, rl[0], o[0]);
+              o[1] = __builtin_fmaf(d.s2, rl[1], o[1]);
+              o[2] = __builtin_fmaf(d.s2, rl[2], o[2]);
+              o[3] = __builtin_fmaf(d.s2, rl[3], o[3]);
             }
           }
           if (vrow) {
@@ -105,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const ctrlv_gemm_desc& d, f32x16 (
 #pragma clang fp contract(off)
               const float l0 = o[0] - el_lo_f32(pk.x), l1 = o[1] - el_hi_f32(pk.x), l2 = o[2] - el_lo_f32(pk.y),
                           l3 = o[3] - el_hi_f32(pk.y);
-              *(uint2*)((el_t*)d.out_lo + (long)m * d.ldo + ncol) = make_uint2(pack_elx2(l0, l1), pack_elx2(l2, l3));
+              *(unsigned*)((lo_t*)d.out_lo + (long)m * d.ldo + ncol) = pack_lo4(l0, l1, l2, l3);   // (one byte per element)
             }
           }
         }

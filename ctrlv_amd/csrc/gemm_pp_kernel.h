@@ -131,6 +131,7 @@ __device__ __forceinline__ void stg_read4x16(const char* a0, const char* a1, con
 // EPI: compile-time operand set -- bit 0: row-vector table V, bit 1: residual R1, bit 2: residual R2 (bias and s_acc
 // are always honoured).  SiLU / fp32 output are served by the 128x128 kernel of gemm.hip only.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // ROW-HALO staging of the 3x3 gather (round 4; north_star: "convs with coalesced HBM reads and LDS halo staging").
 // The three horizontal taps (dx = -1, 0, +1) of one (dy, 32-channel block) read the SAME input pixels shifted by one:
@@ -185,6 +186,11 @@ __device__ __forceinline__ void pp_store_out(const u32x4_t& pv, __amdgpu_buffer_
   __builtin_amdgcn_raw_buffer_store_b128(pv, rs, voff, soff, 0);
   store_data_hazard_guard(pv);
 }
+// the eight lo bytes of a split output (one byte per element: byte offsets are the element offsets)
+__device__ __forceinline__ void pp_store_out_lo(const u32x2_t& pv, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(pv, rs, voff, soff, 0);
+  asm volatile("s_nop 1" ::"v"(pv));
+}
 
 template <int WTN>
 __device__ __forceinline__ void pp_bias_store(char* bias_lds, const u32x4_t& v, int lane) {
@@ -232,13 +238,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
       (void*)((EPI & 4) ? d.R2 : d.W), 0, (EPI & 4) ? (int)((long)d.M * d.ldr2 * 2) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((EPI & 1) ? (const void*)d.V : d.W), 0, (EPI & 1) ? (int)(pp_vtable_rows(d) * d.ldv * 4) : 0, kFlags);
-  // (LO: a missing lo plane is an empty descriptor -- its loads return zeros, hi + 0)
+  // (LO: a missing lo plane is an empty descriptor -- its loads return zeros, hi + 0.  lo planes hold ONE BYTE per element
+  //  (common.h lo_t): their byte offsets are the hi plane's halved)
   const __amdgpu_buffer_rsrc_t rsOL = __builtin_amdgcn_make_buffer_rsrc(
-      (LO && d.out_lo) ? d.out_lo : (void*)d.W, 0, (LO && d.out_lo) ? (int)((long)d.M * d.ldo * 2) : 0, kFlags);
+      (LO && d.out_lo) ? d.out_lo : (void*)d.W, 0, (LO && d.out_lo) ? (int)((long)d.M * d.ldo) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsR1L = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((LO && (EPI & 2) && d.R1_lo) ? d.R1_lo : d.W), 0, (LO && (EPI & 2) && d.R1_lo) ? (int)((long)d.M * d.ldr1 * 2) : 0, kFlags);
+      (void*)((LO && (EPI & 2) && d.R1_lo) ? d.R1_lo : d.W), 0, (LO && (EPI & 2) && d.R1_lo) ? (int)((long)d.M * d.ldr1) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsR2L = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((LO && (EPI & 4) && d.R2_lo) ? d.R2_lo : d.W), 0, (LO && (EPI & 4) && d.R2_lo) ? (int)((long)d.M * d.ldr2 * 2) : 0, kFlags);
+      (void*)((LO && (EPI & 4) && d.R2_lo) ? d.R2_lo : d.W), 0, (LO && (EPI & 4) && d.R2_lo) ? (int)((long)d.M * d.ldr2) : 0, kFlags);
 
   // byte offset of the row-vector table row of (i, pass): two integer divisions per row, hoisted out of the sub-tiles
   // (GNS: the launcher guarantees vmode 1 with vdiv a multiple of the 64-row wave tile: one table row per wave tile, a scalar)
@@ -264,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
     // Residual operands are streamed from HBM (~1 us): they are prefetched through a window that GROWS as the
     // epilogue retires accumulators -- every finished sub-tile frees 16 accumulator registers, enough for the R1 rows of
     // two more sub-tiles (one with R2) -- so a 10-sub-tile epilogue pays the memory latency about once, not ten times.
-    struct Res { u32x4_t r1[2], r2[2], r1l[LO ? 2 : 1], r2l[LO ? 2 : 1]; };
+    struct Res { u32x4_t r1[2], r2[2]; u32x2_t r1l[LO ? 2 : 1], r2l[LO ? 2 : 1]; };
     constexpr bool HAS_RES = (EPI & 6) != 0;
     // sub-tiles in flight before the first one is processed: bounded by what the 320-wide tile (252+ VGPRs) can hold
     // (LO: every residual row is two planes -- one sub-tile ahead, one more per processed one)
@@ -287,11 +294,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         if (EPI & 2)
           q[s].r1[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR1, ok ? r1_base : kOOB, (dr * d.ldr1 + j * 32) * 2, 0);
         if (LO && (EPI & 2))
-          q[s].r1l[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR1L, ok ? r1_base : kOOB, (dr * d.ldr1 + j * 32) * 2, 0);
+          q[s].r1l[pass] = __builtin_amdgcn_raw_buffer_load_b64(rsR1L, ok ? (r1_base >> 1) : kOOB, dr * d.ldr1 + j * 32, 0);
         if (EPI & 4)
           q[s].r2[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR2, ok ? r2_base : kOOB, (dr * d.ldr2 + j * 32) * 2, 0);
         if (LO && (EPI & 4))
-          q[s].r2l[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsR2L, ok ? r2_base : kOOB, (dr * d.ldr2 + j * 32) * 2, 0);
+          q[s].r2l[pass] = __builtin_amdgcn_raw_buffer_load_b64(rsR2L, ok ? (r2_base >> 1) : kOOB, dr * d.ldr2 + j * 32, 0);
       }
     };
     if (HAS_RES) {
@@ -383,8 +390,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
           if (LO) {
-            const u32x4_t rl = q[HAS_RES ? s : 0].r1l[pass];
-            unpack_elx8(make_uint4(rl.x, rl.y, rl.z, rl.w), f);
+            const u32x2_t rl = q[HAS_RES ? s : 0].r1l[pass];
+            unpack_lo8(make_uint2(rl.x, rl.y), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s1, f[e], o[e]);
           }
@@ -396,8 +403,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
           if (LO) {
-            const u32x4_t rl = q[HAS_RES ? s : 0].r2l[pass];
-            unpack_elx8(make_uint4(rl.x, rl.y, rl.z, rl.w), f);
+            const u32x2_t rl = q[HAS_RES ? s : 0].r2l[pass];
+            unpack_lo8(make_uint2(rl.x, rl.y), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(d.s2, f[e], o[e]);
           }
@@ -433,9 +440,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const ctrlv_gemm_desc& d, f32x
         const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
         pp_store_out(pv, rsO, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
         if (LO) {
-          const uint4 pl = split_lo8(o, pk);
-          const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
-          pp_store_out(pvl, rsOL, ok ? o_base : kOOB, ((i * 32 + pass * 16) * d.ldo + j * 32) * 2);
+          const uint2 pl = split_lo8(o, pk);
+          const u32x2_t pvl = {pl.x, pl.y};
+          pp_store_out_lo(pvl, rsOL, ok ? (o_base >> 1) : kOOB, (i * 32 + pass * 16) * d.ldo + j * 32);
         }
       }
       if (GNS && i == TM - 1) {

@@ -25,9 +25,9 @@ __device__ __forceinline__ uint4 gn_load(const el_t* x, const el_t* x2, int c_sp
   return *(const uint4*)(x + row * ld + c0);
 }
 // SPLIT inputs (ctrlv_gemm_desc.out_lo): the lo planes of x / x2, same shapes and pitches; a null plane reads as zeros.
-struct GnLo { const el_t* x; const el_t* x2; };
+struct GnLo { const lo_t* x; const lo_t* x2; };     // (one byte per element: common.h lo_t)
 // the lo-plane pointer that belongs to column block c0 (fixed per thread), or null; `first` = that half's first column
-__device__ __forceinline__ const el_t* gn_lo_plane(const GnLo& lo, const el_t* x2, int c_split, int C, int c0, int* ld, int* first) {
+__device__ __forceinline__ const lo_t* gn_lo_plane(const GnLo& lo, const el_t* x2, int c_split, int C, int c0, int* ld, int* first) {
   if (x2 != nullptr && c0 >= c_split) { *ld = C - c_split; *first = c_split; return lo.x2; }
   *ld = x2 != nullptr ? c_split : C; *first = 0;
   return lo.x;
@@ -50,7 +50,7 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   const int c0 = col * 8;
   int lo_ld = 0, lo_first = 0;
-  const el_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
+  const lo_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
   // (float2 arithmetic: v_pk_add_f32 / v_pk_fma_f32, two channels per instruction)
   f32x2_t sm2[4], sq2[4], piv2[4];
   {
@@ -68,7 +68,7 @@ __global__ void gn_stats_kernel(const el_t* __restrict__ x, const el_t* __restri
   auto accum = [&](const uint4& v, long row) {
     float f[8];
     unpack_elx8(v, f);
-    if (SPLIT && lop) add_lo8(f, *(const uint4*)(lop + row * lo_ld + (c0 - lo_first)));
+    if (SPLIT && lop) add_lo8(f, *(const uint2*)(lop + row * lo_ld + (c0 - lo_first)));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const f32x2_t dl = f32x2_t{f[2 * e], f[2 * e + 1]} - piv2[e];
@@ -189,11 +189,11 @@ __global__ void gn_apply_kernel(const el_t* __restrict__ x, const el_t* __restri
   const int r0 = chunk * s.rows_per_chunk;
   const int r1 = min(s.S, r0 + s.rows_per_chunk);
   int lo_ld = 0, lo_first = 0;
-  const el_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
+  const lo_t* const lop = SPLIT ? gn_lo_plane(lo, x2, s.c_split, s.C, c0, &lo_ld, &lo_first) : nullptr;
   auto apply_row = [&](const uint4& v, long row) {
     float f[8];
     unpack_elx8(v, f);
-    if (SPLIT && lop) add_lo8(f, *(const uint4*)(lop + row * lo_ld + (c0 - lo_first)));
+    if (SPLIT && lop) add_lo8(f, *(const uint2*)(lop + row * lo_ld + (c0 - lo_first)));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = f[e] * a[e] + b[e];
@@ -247,7 +247,7 @@ int gn_shape(int n_img, int S, int C, int imgs_per_stat, int c_split, bool has_x
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 template <int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, const el_t* __restrict__ xlo, int M, int C,
+__global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, const lo_t* __restrict__ xlo, int M, int C,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
                                                  el_t* __restrict__ y) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const el_t* __restrict__ x, con
       if (cv < CV) {
         const uint4 v = cur[k];
         unpack_elx8(v, f[k]);
-        if (xlo) add_lo8(f[k], *(const uint4*)(xlo + m * C + cv * 8));
+        if (xlo) add_lo8(f[k], *(const uint2*)(xlo + m * C + cv * 8));
         if (vrow) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[k][e] += vrow[cv * 8 + e];
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // wave-instructions per row.  Same arithmetic as ln_kernel (two passes in registers: mean, then centred squares; the
 // optional row vector added first), different summation tree.  gamma / beta live in LDS (C floats each).
 template <int NCH, bool SPLIT>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x, const el_t* __restrict__ xlo, int M, int C, int lpr_log2,
+__global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x, const lo_t* __restrict__ xlo, int M, int C, int lpr_log2,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, const float* __restrict__ V, int vdiv, int vmod, int ldv,
                                                       el_t* __restrict__ y) {
@@ -388,21 +388,23 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const el_t* __restrict__ x
   const float inv_c = 1.0f / (float)C;
   const long step = (long)gridDim.x * 4 * RPW;
   long m = ((long)blockIdx.x * 4 + wid) * RPW + rsub;
-  uint4 nxt[NCH], nxl[SPLIT ? NCH : 1];
+  uint4 nxt[NCH];
+  uint2 nxl[SPLIT ? NCH : 1];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     nxt[k] = m < M ? *(const uint4*)(x + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
-    if (SPLIT) nxl[k] = m < M ? *(const uint4*)(xlo + m * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+    if (SPLIT) nxl[k] = m < M ? *(const uint2*)(xlo + m * C + (j + k * LPR) * 8) : make_uint2(0, 0);
   }
   for (; m - rsub < M; m += step) {                // (wave-uniform trip count: the shuffles below need every lane)
-    uint4 cur[NCH], cul[SPLIT ? NCH : 1];
+    uint4 cur[NCH];
+    uint2 cul[SPLIT ? NCH : 1];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       cur[k] = nxt[k];
       nxt[k] = (m + step < M) ? *(const uint4*)(x + (m + step) * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
       if (SPLIT) {
         cul[k] = nxl[k];
-        nxl[k] = (m + step < M) ? *(const uint4*)(xlo + (m + step) * C + (j + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+        nxl[k] = (m + step < M) ? *(const uint2*)(xlo + (m + step) * C + (j + k * LPR) * 8) : make_uint2(0, 0);
       }
     }
     const bool ok = m < M;
@@ -475,7 +477,7 @@ extern "C" int ctrlv_groupnorm_stats_split(const void* x, const void* x_lo, cons
                                            ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials, "groupnorm_stats: null pointer");
   CTRLV_CHECK_ARG(x2 || !x2_lo, "groupnorm_stats: x2_lo without x2");
-  const GnLo lo{(const el_t*)x_lo, (const el_t*)x2_lo};
+  const GnLo lo{(const lo_t*)x_lo, (const lo_t*)x2_lo};
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
@@ -506,7 +508,7 @@ extern "C" int ctrlv_groupnorm_apply_split(const void* x, const void* x_lo, cons
                                            const float* gamma, const float* beta, int silu, void* y, ctrlv_stream_t stream) {
   CTRLV_CHECK_ARG(x && partials && gamma && beta && y, "groupnorm_apply: null pointer");
   CTRLV_CHECK_ARG(x2 || !x2_lo, "groupnorm_apply: x2_lo without x2");
-  const GnLo lo{(const el_t*)x_lo, (const el_t*)x2_lo};
+  const GnLo lo{(const lo_t*)x_lo, (const lo_t*)x2_lo};
   GnShape s;
   int rc = gn_shape(n_img, S, C, imgs_per_stat, c_split, x2 != nullptr, &s);
   if (rc < 0) return rc;
@@ -546,7 +548,7 @@ extern "C" int ctrlv_groupnorm_from_partials_split(const void* x, const void* x_
   const int nt = s.CV * s.RPP;
   if (x_lo)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
-                       (const el_t*)nullptr, GnLo{(const el_t*)x_lo, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
+                       (const el_t*)nullptr, GnLo{(const lo_t*)x_lo, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(s.n_chunks, n_img), dim3(nt), 0, (hipStream_t)stream, (const el_t*)x,
                        (const el_t*)nullptr, GnLo{nullptr, nullptr}, s, stats, gamma, beta, silu, (el_t*)y);
@@ -574,17 +576,17 @@ extern "C" int ctrlv_layernorm_split(const void* x, const void* x_lo, int M, int
     if (nb > 256 * 8) nb = 256 * 8;
     if (x_lo)
       hipLaunchKernelGGL((ln_rows_kernel<5, true>), dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x,
-                         (const el_t*)x_lo, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
+                         (const lo_t*)x_lo, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
     else
       hipLaunchKernelGGL((ln_rows_kernel<5, false>), dim3((unsigned)nb), dim3(256), 2 * C * sizeof(float), st, (const el_t*)x,
-                         (const el_t*)nullptr, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
+                         (const lo_t*)nullptr, M, C, lg, gamma, beta, eps, V, vdiv, vmod, ldv, (el_t*)y);
     CTRLV_LAUNCH_CHECK();
     return CTRLV_OK;
   }
   long blocks = ((long)M + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
 #define LN_LAUNCH(NV)                                                                                             \
-  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, (const el_t*)x_lo, M, C, gamma, beta, \
+  hipLaunchKernelGGL(ln_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const el_t*)x, (const lo_t*)x_lo, M, C, gamma, beta, \
                      eps, V, vdiv, vmod, ldv, (el_t*)y)
   switch (nv) {
     case 1: LN_LAUNCH(1); break;

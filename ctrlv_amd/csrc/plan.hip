@@ -439,7 +439,7 @@ int load_tr(Loader& L, Transformer& t, int cross_dim) {
 // the ABI's tensors read `hi`; residual operands (R1 / R2) and norm inputs read both.
 struct Trk {
   el_t* hi = nullptr;
-  el_t* lo = nullptr;
+  lo_t* lo = nullptr;        // one byte per element (e5m2: common.h lo_t)
 };
 struct Ctx {
   ctrlv_plan* p;
@@ -468,7 +468,7 @@ struct Ctx {
   Trk trunk(long m, int c) {          // a trunk tensor: one plane, or hi + lo in trunk mode 1
     Trk t;
     t.hi = rows(m, c);
-    if (p->trunk_mode == 1) t.lo = rows(m, c);
+    if (p->trunk_mode == 1) t.lo = (lo_t*)alloc((size_t)m * c);
     return t;
   }
   size_t mark() const { return off; }
@@ -504,7 +504,7 @@ void gemm_work(const ctrlv_gemm_desc& d, int* fam, double* flops, double* bytes)
   *flops = 2.0 * d.M * n_alg * K;
   *bytes = (double)d.M * d.Cin * 2 + (double)d.M * n_out * ((d.out_f32 & 1) ? 4 : 2) + (double)d.N * K * 2 +
            (d.R1 ? (double)d.M * n_out * 2 : 0) + (d.R2 ? (double)d.M * n_out * 2 : 0) +
-           ((d.R1_lo ? 1 : 0) + (d.R2_lo ? 1 : 0) + (d.out_lo ? 1 : 0)) * (double)d.M * n_out * 2;
+           ((d.R1_lo ? 1 : 0) + (d.R2_lo ? 1 : 0) + (d.out_lo ? 1 : 0)) * (double)d.M * n_out;       // (lo planes: 1 byte)
 }
 // residual operand / output of a GEMM from a trunk tensor
 inline void set_r1(ctrlv_gemm_desc& d, const Trk& t, int ld) { d.R1 = t.hi; d.R1_lo = t.lo; d.ldr1 = ld; }
@@ -561,7 +561,7 @@ int groupnorm(Ctx& c, const Trk& x, const Trk& x2, int c_split, int n_img, int S
 // finalize + apply -- one read and one write of the tensor instead of two reads.  The scratch is sized from the shape alone
 // (the measuring walk has no operand pointers to ask the predicate with).
 int gemm_groupnorm(Ctx& c, ctrlv_gemm_desc d, int n_img, int S, int C, int ips, const Norm& nm, float eps, int silu, el_t* y) {
-  const Trk dout{(el_t*)d.out, (el_t*)d.out_lo};
+  const Trk dout{(el_t*)d.out, (lo_t*)d.out_lo};
   if (S % 64 != 0) {
     TRY(gemm(c, d));
     return groupnorm(c, dout, Trk{}, 0, n_img, S, C, ips, nm, eps, silu, y);
@@ -700,8 +700,8 @@ int ff_pair(Ctx& c, const FeedFwd& f, ctrlv_gemm_desc proj, ctrlv_gemm_desc outd
     if (c.dry) return CTRLV_OK;
     if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
     ProfScope ps(c, CTRLV_FAM_GEMM_LINEAR, 2.0 * outd.M * 320.0 * (2560 + 1280),
-                 (double)outd.M * 320 * 2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0) + (outd.R1_lo ? 1 : 0) + (outd.R2_lo ? 1 : 0) +
-                                             (outd.out_lo ? 1 : 0)), outd.M, 320, 320, 0x100);
+                 (double)outd.M * 320 * (2 * (2 + (outd.R1 ? 1 : 0) + (outd.R2 ? 1 : 0)) + (outd.R1_lo ? 1 : 0) + (outd.R2_lo ? 1 : 0) +
+                                         (outd.out_lo ? 1 : 0)), outd.M, 320, 320, 0x100);
     return ctrlv_ff_fused(proj.A, proj.lda, f.w1f, f.w2f, &outd, c.st);
   }
   if (*u == nullptr) *u = c.rows(proj.M, 4 * C);
@@ -827,7 +827,7 @@ int run_tr(Ctx& c, const Transformer& t, const Trk& x, int H, int W, Trk* out_) 
       if (!c.dry) {
         if (c.overflow) { ctrlv_set_error("plan forward: workspace too small (need >= %zu bytes)", c.peak); return CTRLV_E_BAD_ARG; }
         ProfScope ps(c, CTRLV_FAM_GEMM_TEMPORAL_BLOCK, 2.0 * M * C * 4.0 * C + 4.0 * B * S * (C / 64) * (double)F * F * 64,
-                     (double)M * C * 2 * ((ln_in ? 2 : 3) + (g0.lo ? 1 : 0) + (g1.lo ? 1 : 0)), (int)M, 4 * C, C, ln_in ? 1 : 0);
+                     (double)M * C * (2 * (ln_in ? 2 : 3) + (g0.lo ? 1 : 0) + (g1.lo ? 1 : 0)), (int)M, 4 * C, C, ln_in ? 1 : 0);
         TRY(ctrlv_temporal_fused(&fd, c.st));
       }
     } else {

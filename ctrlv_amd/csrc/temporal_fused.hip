@@ -109,10 +109,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(M * a.ldx * 2), kFlags);
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(a.r1 ? a.r1 : a.x), 0, a.r1 ? (int)(M * a.ldr1 * 2) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsRL = __builtin_amdgcn_make_buffer_rsrc((void*)((LO && a.r1_lo) ? a.r1_lo : a.x), 0,
-                                                                        (LO && a.r1_lo) ? (int)(M * a.ldr1 * 2) : 0, kFlags);
+                                                                        (LO && a.r1_lo) ? (int)(M * a.ldr1) : 0, kFlags);      // (lo planes: one byte per element)
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(M * a.ldo * 2), kFlags);
   const __amdgpu_buffer_rsrc_t rsOL = __builtin_amdgcn_make_buffer_rsrc((void*)((LO && a.out_lo) ? a.out_lo : a.out), 0,
-                                                                        (LO && a.out_lo) ? (int)(M * a.ldo * 2) : 0, kFlags);
+                                                                        (LO && a.out_lo) ? (int)(M * a.ldo) : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.wf), 0,
                                                                        a.bias ? kC * 4 : 0, kFlags);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.vmode ? (const void*)a.vtab : (const void*)a.wf), 0,
@@ -416,13 +416,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
       // start values (bias + the pixel's row vector) and the residual rows of both blocks: requested in the Y phase in front of
       // the chains' barrier
       f32x16 acc[2];
-      u32x4_t rr[2][2], rl[2][2];
+      u32x4_t rr[2][2];
+      u32x2_t rl[2][2];                                      // (lo planes: 8 bytes per 8 elements, byte offsets halved)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
           rr[t][hq] = __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase, (2 * np + t) * 64 + hq * 16, 0);
-          if (LO) rl[t][hq] = __builtin_amdgcn_raw_buffer_load_b128(rsRL, rbase, (2 * np + t) * 64 + hq * 16, 0);
+          if (LO) rl[t][hq] = __builtin_amdgcn_raw_buffer_load_b64(rsRL, rbase == kOOB ? kOOB : (rbase >> 1), (2 * np + t) * 32 + hq * 8, 0);
         }
       {
         // the lane's 2 x 16 start values from the strip (channels 32 nb + 16 hsel .. + 15 of the two blocks)
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = o[e] + rf[e];
           }
-          if (LO) add_lo8(o, make_uint4(rl[t][hq][0], rl[t][hq][1], rl[t][hq][2], rl[t][hq][3]));
+          if (LO) add_lo8(o, make_uint2(rl[t][hq][0], rl[t][hq][1]));
           const uint4 pk = pack_elx8(o);
           const u32x4_t pv = {pk.x, pk.y, pk.z, pk.w};
 #ifndef CTRLV_TA_NOSTORE
@@ -474,9 +475,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const TaArgs a) {
           asm volatile("" ::"v"(pv));
 #endif
           if (LO) {
-            const uint4 pl = split_lo8(o, pk);
-            const u32x4_t pvl = {pl.x, pl.y, pl.z, pl.w};
-            pp_store_out(pvl, rsOL, obase, (2 * np + t) * 64 + hq * 16);
+            const uint2 pl = split_lo8(o, pk);
+            const u32x2_t pvl = {pl.x, pl.y};
+            pp_store_out_lo(pvl, rsOL, obase == kOOB ? kOOB : (obase >> 1), (2 * np + t) * 32 + hq * 8);
           }
         }
       TSTAMP(te3);

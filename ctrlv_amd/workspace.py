@@ -49,10 +49,11 @@ class Workspace:
 
     def trunk(self, shape):
         """A RESIDUAL-TRUNK tensor (block inputs / outputs, everything a branch result is added back into): one plane, or --
-        split mode -- the hi plane carrying its lo plane as the attribute `.lo` (value = hi + lo; GEMM A operands read the
-        hi plane in place, residual operands and norm inputs read both: csrc/plan.hip `Trk`)."""
+        split mode -- the hi plane carrying its lo plane as the attribute `.lo` (value = hi + lo, the lo plane one e5m2 byte
+        per element; GEMM A operands read the hi plane in place, residual operands and norm inputs read both: csrc/plan.hip
+        `Trk`)."""
         t = self.alloc(shape)
-        t.lo = self.alloc(shape) if self.split else None
+        t.lo = self.alloc(shape, torch.uint8) if self.split else None
         return t
 
     def mark(self):

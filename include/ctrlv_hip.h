@@ -113,10 +113,12 @@ typedef struct ctrlv_gemm_desc {
   int32_t ksplit, w_cin;              /* internal (set by ctrlv_gemm for its slice launch; callers leave 0): number of K
                                          slices; channels per tap of W when Cin is a slice's channel count */
   /* SPLIT ("fp16x2") residual trunk -- libctrlv_hip_f16.so only (round 5).  A tensor of the residual stream may carry a
-   * second plane of the same shape and pitch: hi = rne(v), lo = rne(v - hi), 2 x 16 bits per element = fp32's bytes and
-   * 21+ significant bits.  R1_lo / R2_lo (optional, need R1 / R2): the operand is R1 + R1_lo (R2 + R2_lo); out_lo
-   * (optional): `out` receives hi, out_lo receives lo.  MFMA operands (A, A2) always read the hi plane: it is the
-   * element-rounded tensor.  Not with GEGLU / SiLU / fp32 output / gn_partials / raw_out. */
+   * second plane of the same shape and pitch IN ELEMENTS: hi = rne_fp16(v), lo = rne_e5m2(v - hi) -- ABI 20: the lo plane
+   * holds ONE BYTE per element (e5m2 / "bf8": fp16's sign and exponent, two mantissa bits; row pitch in bytes = the hi
+   * plane's pitch in elements), hi + lo keeps ~15 significant bits in 3 bytes per element (ABI 18-19: a 16-bit lo plane; on
+   * the oracle both give the same model-level error, tests/trunk_precision_study.py).  R1_lo / R2_lo (optional, need R1 /
+   * R2): the operand is R1 + R1_lo (R2 + R2_lo); out_lo (optional): `out` receives hi, out_lo receives lo.  MFMA operands
+   * (A, A2) always read the hi plane: it is the element-rounded tensor.  Not with GEGLU / SiLU / fp32 output / raw_out. */
   const void* R1_lo;
   const void* R2_lo;
   void* out_lo;
@@ -424,8 +426,8 @@ int ctrlv_plan_load_weights(ctrlv_plan* plan, const ctrlv_tensor_desc* tensors, 
 int ctrlv_plan_set_time_context_order(ctrlv_plan* plan, int order);
 /* Storage of the RESIDUAL TRUNK of the plan's forwards (conv_in output, every block / AlphaBlender output, the skip
  * tensors, the tensors the ControlNet residuals are added into): 0 = one element per value like every other activation
- * (default), 1 = SPLIT into hi + lo element planes (see ctrlv_gemm_desc.out_lo: fp32's bytes, 21+ significant bits under
- * fp16 branches; north_star's 1e-3 model-level tolerance).  Mode 1 needs the fp16 element library; the workspace grows
+ * (default), 1 = SPLIT into a hi element plane + a one-byte lo plane (see ctrlv_gemm_desc.out_lo: 3 bytes per element, ~15
+ * significant bits under fp16 branches; north_star's 1e-3 model-level tolerance).  Mode 1 needs the fp16 element library; the workspace grows
  * (ctrlv_plan_workspace_bytes answers for the current mode).  Model inputs / outputs / residual tensors across the ABI are
  * unchanged. */
 int ctrlv_plan_set_trunk_mode(ctrlv_plan* plan, int mode);

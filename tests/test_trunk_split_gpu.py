@@ -43,15 +43,30 @@ def g(seed=0):
     return torch.Generator().manual_seed(seed)
 
 
+LO = torch.float8_e5m2     # one byte per element: fp16's sign / exponent + two mantissa bits (csrc/common.h lo_t)
+
+
 def split(v):
-    """fp32 tensor -> (hi, lo) fp16 planes the way the kernels store them."""
+    """fp32 tensor -> (hi fp16, lo e5m2) planes the way the kernels store them."""
     hi = v.to(EL)
-    lo = (v - hi.float()).to(EL)
+    lo = (v - hi.float()).to(LO)
     return hi, lo
 
 
 def joined(hi, lo):
-    return hi.float().cpu() + lo.float().cpu()
+    return hi.float().cpu() + lo.cpu().float()
+
+
+def lo_plane(*shape, nan=False):
+    """device lo plane (optionally pre-filled with the e5m2 NaN byte: a launch must overwrite every element)"""
+    t = torch.empty(*shape, dtype=LO, device=DEV)
+    if nan:
+        t.view(torch.uint8).fill_(0x7F)
+    return t
+
+
+def same(a, b):
+    return torch.equal(a.view(torch.uint8), b.view(torch.uint8)) if a.dtype == LO else torch.equal(a, b)
 
 
 def rows_from_nchw(x):
@@ -59,10 +74,10 @@ def rows_from_nchw(x):
     return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
 
 
-def test_split_planes_carry_22_bits():
+def test_split_planes_carry_15_bits():
     v = torch.randn(4096, generator=g(1)) * 3
     hi, lo = split(v)
-    assert rel_l2(hi.float() + lo.float(), v) < 3e-7 and rel_l2(hi.float(), v) > 1e-4
+    assert rel_l2(hi.float() + lo.float(), v) < 2.5e-5 and rel_l2(hi.float(), v) > 1e-4
 
 
 @pytest.mark.parametrize("M", [300, 2048 + 77])
@@ -105,14 +120,15 @@ def test_gemm_split_epilogues(ops, M, epi):
     outs = {}
     for tile in ([0, 1] if M > 1024 else [0]):
         hi = torch.full((M, N), float("nan"), dtype=EL, device=DEV)
-        lo = torch.full((M, N), float("nan"), dtype=EL, device=DEV)
+        lo = lo_plane(M, N, nan=True)
         ops.gemm(Ad, Wp.to(DEV), hi, out_lo=lo, tile=tile, **kw)
-        # the pair is the fp32 epilogue value to ~2^-22; the hi plane alone is the plain fp16 output
-        assert parity_err(joined(hi, lo), ref, f"{epi} tile {tile}") < 2e-5
-        assert (lo.float().abs() <= hi.float().abs() * 2.0 ** -11 + 2.0 ** -24).all()     # |lo| <= half an ulp of hi
+        # the pair is the fp32 epilogue value to ~2^-15; the hi plane alone is the plain fp16 output
+        assert parity_err(joined(hi, lo), ref, f"{epi} tile {tile}") < 1e-4
+        # |lo| <= half an ulp of hi (+ its own rounding to three significant bits)
+        assert (lo.cpu().float().abs() <= hi.float().cpu().abs() * 2.0 ** -11 * 1.125 + 2.0 ** -16).all()
         outs[tile] = (hi, lo)
     if len(outs) == 2:      # ping-pong LO epilogue == 2-stage epilogue, bit for bit, in both planes
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
     # without split operands the hi plane IS the plain fp16 output of the same launch
     if epi in ("bias", "bias_a2"):
         plain = torch.empty(M, N, dtype=EL, device=DEV)
@@ -167,12 +183,12 @@ def test_gemm_split_convs(ops, kind, H, W, n, cin, cout):
     outs = {}
     for tile in ([0, 1] if M >= 1024 else [0]):
         hi = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
-        lo = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+        lo = lo_plane(M, cout, nan=True)
         ops.gemm(xd, wd, hi, out_lo=lo, tile=tile, **kw)
-        assert parity_err(joined(hi, lo), ref, f"{kind} tile {tile}") < 2e-5
+        assert parity_err(joined(hi, lo), ref, f"{kind} tile {tile}") < 1e-4
         outs[tile] = (hi, lo)
     if len(outs) == 2:
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("kind,H,W,n,ips,cout", [("conv_r1", 8, 32, 6, 1, 320), ("conv_r1", 16, 64, 3, 3, 640),
@@ -203,15 +219,15 @@ def test_gemm_split_writes_groupnorm_partials(ops, kind, H, W, n, ips, cout):
     kw.update(R1=r1h.to(DEV), R1_lo=r1l.to(DEV), s_acc=0.5)
     ref = 0.5 * ref + (r1h.double() + r1l.double())
     xd = rows_from_nchw(x).to(DEV)
-    hi0, lo0 = torch.empty(M, cout, dtype=EL, device=DEV), torch.empty(M, cout, dtype=EL, device=DEV)
+    hi0, lo0 = torch.empty(M, cout, dtype=EL, device=DEV), lo_plane(M, cout)
     ops.gemm(xd, wd, hi0, out_lo=lo0, **kw)
     hi = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
-    lo = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
+    lo = lo_plane(M, cout, nan=True)
     assert ops.gemm_gn_partials_serves(xd, wd, hi, out_lo=lo, **kw)
     part = torch.full((ops.groupnorm_fused_scratch_floats(n, S, ips),), float("nan"), dtype=torch.float32, device=DEV)
     ops.gemm(xd, wd, hi, out_lo=lo, gn_partials=part, **kw)
-    assert torch.equal(hi, hi0) and torch.equal(lo, lo0)
-    assert parity_err(joined(hi, lo), ref.float(), kind) < 2e-5
+    assert same(hi, hi0) and same(lo, lo0)
+    assert parity_err(joined(hi, lo), ref.float(), kind) < 1e-4
     gamma, beta = torch.randn(cout, generator=g(6)), torch.randn(cout, generator=g(7))
     y = torch.full((M, cout), float("nan"), dtype=EL, device=DEV)
     ops.groupnorm_from_partials(hi, n, S, cout, ips, gamma.to(DEV), beta.to(DEV), 1e-6, True, y, part, x_lo=lo)
@@ -238,7 +254,7 @@ def test_gemm_split_rejections(ops):
     A = torch.randn(M, K, generator=g(1)).to(EL).to(DEV)
     Wp = packing.pack_linear(torch.randn(N, K, generator=g(2))).to(DEV)
     hi = torch.empty(M, N, dtype=EL, device=DEV)
-    lo = torch.empty(M, N, dtype=EL, device=DEV)
+    lo = lo_plane(M, N)
     with pytest.raises(ValueError):          # the 256-wide ping-pong tile has no split epilogue
         ops.gemm(A, Wp, hi, N=N, cin=K, out_lo=lo, tile=5)
     with pytest.raises(ValueError):          # a lo plane without its hi operand
@@ -248,7 +264,7 @@ def test_gemm_split_rejections(ops):
     # the bf16 library does not serve split planes at all
     Ab, Wb = A.to(torch.bfloat16), Wp.to(torch.bfloat16)
     with pytest.raises(ValueError):
-        ops.gemm(Ab, Wb, hi.to(torch.bfloat16), N=N, cin=K, out_lo=lo.to(torch.bfloat16))
+        ops.gemm(Ab, Wb, hi.to(torch.bfloat16), N=N, cin=K, out_lo=lo)
 
 
 @pytest.mark.parametrize("C,H,W,n,ips", [(320, 9, 16, 6, 1), (320, 9, 16, 6, 3), (640, 8, 8, 4, 2), (320, 72, 128, 1, 1)])
@@ -305,14 +321,14 @@ def test_axpby_split(ops):
     x = torch.randn(n, generator=g(1)) * 3
     r = torch.randn(n, generator=g(2)).to(EL)
     hi, lo = split(x)
-    yh, yl = torch.empty(n, dtype=EL, device=DEV), torch.empty(n, dtype=EL, device=DEV)
+    yh, yl = torch.empty(n, dtype=EL, device=DEV), lo_plane(n)
     ops.axpby_split(hi.to(DEV), lo.to(DEV), r.to(DEV), 1.0, 1.0, yh, yl)
     ref = hi.float() + lo.float() + r.float()
-    assert rel_l2(joined(yh, yl), ref) < 5e-7
+    assert rel_l2(joined(yh, yl), ref) < 2.5e-5
     # in place, as the plan runs it
     xh, xl = hi.to(DEV), lo.to(DEV)
     ops.axpby_split(xh, xl, r.to(DEV), 1.0, 1.0, xh, xl)
-    assert torch.equal(xh, yh) and torch.equal(xl, yl)
+    assert same(xh, yh) and same(xl, yl)
 
 
 @pytest.mark.parametrize("M,epi", [(1000, "r1"), (2048 + 72, "r1r2"), (256 * 9, "r1v")])
@@ -338,14 +354,14 @@ def test_ff_fused_split(ops, M, epi):
         kw.update(V=V.to(DEV), vmode=1, vdiv=256, vmod=9)
     xd, W1d, b1d, W2d, b2d = x.to(DEV), W1p.to(DEV), b1p.to(DEV), W2p.to(DEV), b2.to(DEV)
     w1f, w2f = ops.ff_fused_pack(W1d, b1d, W2d)
-    hi, lo = (torch.full((M, C), float("nan"), dtype=EL, device=DEV) for _ in range(2))
+    hi, lo = torch.full((M, C), float("nan"), dtype=EL, device=DEV), lo_plane(M, C, nan=True)
     assert ops.ff_fused_serves(xd, hi, out_lo=lo, **kw)
     ops.ff_fused(xd, w1f, w2f, hi, bias=b2d, out_lo=lo, **kw)
     u = torch.empty(M, 4 * C, dtype=EL, device=DEV)
     ops.gemm(xd, W1d, u, N=8 * C, cin=C, bias=b1d, geglu=1)
     hi2, lo2 = torch.empty_like(hi), torch.empty_like(lo)
     ops.gemm(u, W2d, hi2, N=C, cin=4 * C, bias=b2d, out_lo=lo2, **kw)
-    assert parity_err(joined(hi, lo), joined(hi2, lo2)) < 5e-5      # (fp32 summation order of the second projection)
+    assert parity_err(joined(hi, lo), joined(hi2, lo2)) < 2e-4      # (fp32 summation order of the second projection)
     proj = x.float() @ W1.to(EL).float().T + b1
     h = (proj[:, :4 * C] * F.gelu(proj[:, 4 * C:])).to(EL).float()
     ref = h @ W2.to(EL).float().T + b2
