@@ -74,7 +74,7 @@ def parse():
                          "gate 2e-3; below north_star's 1e-3 with --trunk fp16x2)")
     ap.add_argument("--trunk", choices=["same", "fp16x2"], default="same",
                     help="storage of the residual trunk (with --dtype fp16): same = one fp16 element per value; fp16x2 = split "
-                         "hi + lo fp16 planes (fp32's bytes, 21+ significant bits) -- north_star's 1e-3 model-level tolerance")
+                         "fp16 hi + one-byte e5m2 lo planes (~15 significant bits in 3 bytes) -- north_star's 1e-3 model-level tolerance")
     ap.add_argument("--no-profile-step", action="store_true",
                     help="skip the extra instrumented eager step (no `roofline` in the output): for runs under rocprofv3 --pmc")
     ap.add_argument("--no-fp16-leg", action="store_true",

@@ -45,7 +45,7 @@ class SpatioTemporalEncoderBase(HipModelMixin):
     executor = os.environ.get("CTRLV_EXECUTOR", "plan")
     _plan_kind = "unet"
     # Storage of the RESIDUAL TRUNK (conv_in output, block / AlphaBlender outputs, skip tensors): "same" = one element per
-    # value like every activation; "fp16x2" = split into hi + lo fp16 planes (fp32's bytes, 21+ significant bits) under fp16
+    # value like every activation; "fp16x2" = split into an fp16 hi plane + a one-byte e5m2 lo plane (~15 significant bits in 3 bytes) under fp16
     # branches -- fp16 models, both executors; model-level error against the fp32 oracle 1.3e-3 -> < 1e-3.
     trunk_dtype = os.environ.get("CTRLV_TRUNK", "same")
 

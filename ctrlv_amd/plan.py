@@ -114,8 +114,8 @@ class Plan:
         return [(_lib.FAMILIES[r.family], r.ms, r.flops, r.bytes, (r.M, r.N, r.K, r.flags)) for r in arr[:m]]
 
     def set_trunk_mode(self, mode):
-        """Storage of the residual trunk: "same" (one element per value) or "fp16x2" (split hi + lo element planes: fp32's
-        bytes, 21+ significant bits; fp16 plans only) -- ctrlv_plan_set_trunk_mode."""
+        """Storage of the residual trunk: "same" (one element per value) or "fp16x2" (split: an fp16 hi plane + a one-byte
+        e5m2 lo plane, ~15 significant bits in 3 bytes; fp16 plans only; the name is the API's since round 5) -- ctrlv_plan_set_trunk_mode."""
         if mode not in ("same", "fp16x2"):
             raise ValueError(f'trunk_dtype must be "same" or "fp16x2", got {mode!r}')
         check(self._lib.ctrlv_plan_set_trunk_mode(self._h, 1 if mode == "fp16x2" else 0), "ctrlv_plan_set_trunk_mode")
