@@ -335,3 +335,26 @@ def test_workspace_stack_discipline():
     for _ in range(3):                 # steady state: no growth
         ws.alloc((10, 8)); mm = ws.mark(); ws.alloc((100, 64)); ws.alloc((1000, 64)); ws.release(mm); ws.reset()
     assert ws.capacity() == cap
+
+
+def test_workspace_trunk_tensors_carry_a_one_byte_lo_plane_in_split_mode():
+    """Workspace.trunk (the per-op executor's residual-trunk tensors, csrc/plan.hip `Trk`): plain mode -> one plane, `.lo` is
+    None; split mode ("fp16x2") -> the fp16 hi plane carries a uint8 (e5m2) lo plane of the same shape as the attribute `.lo`,
+    3 bytes per element, both from the arena (released together); ordinary allocations never carry one."""
+    ws = Workspace("cpu", chunk_bytes=1 << 20)
+    ws.el = torch.float16
+    t = ws.trunk((64, 320))
+    assert t.dtype == torch.float16 and t.lo is None
+    ws.reset()
+    ws.split = True
+    m = ws.mark()
+    t = ws.trunk((64, 320))
+    assert t.dtype == torch.float16 and t.lo is not None and t.lo.dtype == torch.uint8 and tuple(t.lo.shape) == (64, 320)
+    assert t.lo.data_ptr() - t.data_ptr() == 64 * 320 * 2                     # the lo plane follows the hi plane
+    assert ws.off - m[1] == 64 * 320 * 3
+    alias = t                                                                  # (h2 = h0: the alias keeps the plane)
+    assert alias.lo is t.lo
+    plain = ws.alloc((64, 320))
+    assert getattr(plain, "lo", None) is None
+    ws.release(m)
+    assert ws.trunk((64, 320)).data_ptr() == t.data_ptr()
